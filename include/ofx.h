@@ -1,0 +1,265 @@
+/*
+ * ofx.h - C-ABI of the MI355X-native batched Ofighters arena engine.
+ *
+ * This is the drop-in boundary for the hot path named in BASELINE.json
+ * (north_star): Battleground.frame() = request_actions -> generate_frame ->
+ * Observation(battleground) for thousands of independent arenas in lock-step,
+ * plus the policy forwards.  The reference has no FFI of its own (it is pure
+ * Python); each entry point below cites the reference interface it replaces
+ * (paths relative to /root/reference/ofighters).  INTEGRATION.md shows the
+ * ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes only; no C++ / torch types.
+ *  - Every bulk pointer is a DEVICE (HBM) pointer unless the name ends in
+ *    `_host`.  ofx_malloc/ofx_free/ofx_memcpy_* let a host without torch own
+ *    device buffers; a torch tensor's data_ptr() is equally valid.
+ *  - All kernels are enqueued on the handle's HIP stream and return
+ *    immediately; ofx_sync() waits.  Entry points that copy to `_host`
+ *    pointers synchronise the stream themselves.
+ *  - Return value: 0 = OFX_OK, <0 = error; ofx_last_error() returns the
+ *    thread-local message (the reference raises bare Exception(msg):
+ *    lib/battleground.py:30, lib/action.py:40,63, agents/agent.py:51).
+ *  - There is NO CPU fallback in this library: without a HIP device every
+ *    compute entry point fails with OFX_ERR_NO_DEVICE.
+ *  - A handle is thread-compatible, not thread-safe (the reference is single
+ *    threaded: lib/ofighters.py:697).
+ */
+#ifndef OFX_H
+#define OFX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OFX_VERSION 1
+
+enum {
+  OFX_OK = 0,
+  OFX_ERR_INVALID = -1,   /* bad argument / config                         */
+  OFX_ERR_NO_DEVICE = -2, /* no HIP device: there is no CPU fallback       */
+  OFX_ERR_HIP = -3,       /* a HIP runtime call failed (message has detail) */
+  OFX_ERR_STATE = -4,     /* call order violated (e.g. step before spawn)  */
+  OFX_ERR_OVERFLOW = -5   /* laser capacity exceeded since the last check  */
+};
+
+/* One POD with the reference's module-level constants as defaults
+ * (ofx_default_config fills them in):
+ *   width/height 400           lib/observation.py:10-11
+ *   ship_radius 8, hull 1      lib/ship.py:43-45
+ *   laser_radius 2             lib/laser.py:23
+ *   ship_speed 8               lib/ship.py:24
+ *   laser_speed 10 * LIGHT 1   lib/ship.py:86, lib/laser.py:13,24
+ *   rewards death 0 kill 0 aim 2 trajectory 1   agents/qlearnIA_V2.py:39-44
+ *   episode_ticks 200          lib/ofighters.py:59 (MAX_TIME)               */
+typedef struct ofx_config {
+  int32_t n_arenas;     /* N  arenas advanced in lock-step on this device   */
+  int32_t n_ships;      /* M  ships per arena, 1..64                        */
+  int32_t laser_cap;    /* L  laser slots per arena (multiple of 64)        */
+  int32_t width, height;
+  int32_t ship_radius, laser_radius;
+  int32_t ship_speed, laser_speed;
+  int32_t reward_death, reward_kill, reward_aim, reward_trajectory;
+  int32_t episode_ticks;
+  int32_t device;       /* HIP device ordinal                               */
+  int32_t arena_base;   /* global id of local arena 0 (multi-GPU sharding:
+                           keys the counter RNG so results do not depend on
+                           the number of GPUs)                              */
+} ofx_config;
+
+/* One ship's action for one tick == lib/action.py:12-56 Action
+ * (shoot, thrust, pointing) ; valid==0 is the reference's `None`
+ * (lib/ship.py:308: no-op).  Array layout [N][M].                           */
+typedef struct ofx_action {
+  int32_t px, py;
+  uint8_t shoot, thrust, valid, _pad;
+} ofx_action;
+
+/* scripted behaviours of agents/agent.py:38-51 (+ "none" = always None)     */
+enum {
+  OFX_BOT_IDLE = 0,   /* idlebot          agent.py:99-104  */
+  OFX_BOT_RANDOM = 1, /* random_play      agent.py:123-133 */
+  OFX_BOT_TURRET = 2, /* crazy_turret     agent.py:136-144 */
+  OFX_BOT_RUNNER = 3, /* crazy_runner     agent.py:147-155 */
+  OFX_BOT_THRUST = 4, /* never_back_down  agent.py:107-112 */
+  OFX_BOT_SHOOT = 5   /* mass_shooter     agent.py:115-120 */
+};
+
+/* state fields readable through ofx_get_host / ofx_device_ptr               */
+enum {
+  OFX_F_SHIP_X = 0,      /* int32 [N][M]   Ship.body.x            ship.py:43   */
+  OFX_F_SHIP_Y = 1,      /* int32 [N][M]                                       */
+  OFX_F_SHIP_PX = 2,     /* int32 [N][M]   Ship.pointing.x        ship.py:53   */
+  OFX_F_SHIP_PY = 3,     /* int32 [N][M]                                       */
+  OFX_F_SHIP_ALIVE = 4,  /* uint8 [N][M]   Ship.is_playable()     ship.py:108  */
+  OFX_F_REWARD = 5,      /* int32 [N][M]   Agent.reward           agent.py:25  */
+  OFX_F_SCORE = 6,       /* int32 [N][M]   Agent.score            agent.py:23  */
+  OFX_F_N_LASERS = 7,    /* int32 [N]      len(Battleground.lasers)            */
+  OFX_F_LASER_X = 8,     /* float64 [N][L] Laser.body.x           laser.py:23  */
+  OFX_F_LASER_Y = 9,     /* float64 [N][L]                                     */
+  OFX_F_LASER_OWNER = 10,/* uint8 [N][L]   index of Laser.owner in ships       */
+  OFX_F_LASER_DEAD = 11, /* uint8 [N][L]   Laser.state=="destroyed" laser.py:66 */
+  OFX_F_KILLER = 12,     /* int16 [N][M]   list index of the laser that killed
+                            the ship THIS tick, -1 otherwise (laser.py:52-60) */
+  OFX_F_TIME = 13,       /* int32 [N]      Battleground.time  battleground.py:154 */
+  OFX_F_LAST_SCORES = 14,/* int32 [N][M]   Agent.scores[-1]       agent.py:62  */
+  OFX_F_HULL = 15,       /* int32 [N][M]   Ship.hull              ship.py:45,129 */
+  OFX_F_LASER_DX = 16,   /* float64 [N][L] per-tick displacement  laser.py:45  */
+  OFX_F_LASER_DY = 17,   /* float64 [N][L]                                     */
+  OFX_F_OBS_REWARD = 18, /* int32 [N][M]   reward as seen by Agent.step this
+                            tick (obs.reward, observation.py:103)             */
+  OFX_F_COUNT = 19
+};
+
+/* observation map element types for ofx_rasterise                           */
+enum {
+  OFX_MAP_U8 = 0,   /* 1 byte / cell  (default; 320 000 B per arena)         */
+  OFX_MAP_F32 = 1,
+  OFX_MAP_F64 = 2,  /* the reference's dtype (observation.py:86,91)          */
+  OFX_MAP_BITS = 3  /* 1 bit / cell, MSB-first per byte == numpy.packbits;
+                       row stride = ceil(W/8)*... see ofx_map_bytes          */
+};
+
+typedef struct ofx_handle ofx_handle;
+
+/* ---- library ---------------------------------------------------------- */
+int ofx_version(void);
+const char *ofx_last_error(void);
+int ofx_device_count(void); /* 0 when no HIP device is visible              */
+void ofx_default_config(ofx_config *cfg);
+
+/* ---- device memory helpers (host side needs no torch) ------------------ */
+int ofx_malloc(void **dev_ptr, size_t bytes);
+int ofx_free(void *dev_ptr);
+int ofx_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
+int ofx_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
+
+/* ---- lifetime ----------------------------------------------------------
+ * replaces Battleground.__init__ (lib/battleground.py:13-106) for N arenas   */
+int ofx_create(const ofx_config *cfg, ofx_handle **out);
+int ofx_destroy(ofx_handle *h);
+int ofx_sync(ofx_handle *h);
+void *ofx_stream(ofx_handle *h);             /* the hipStream_t of the handle */
+int ofx_set_stream(ofx_handle *h, void *hip_stream); /* adopt caller's stream */
+
+/* ---- spawn / restart ---------------------------------------------------
+ * ofx_spawn: ships at draws[N][M][2] (x,y), pointing = position, alive,
+ *   reward = score = 0, no lasers            (battleground.py:79-81, ship.py:35-58)
+ * ofx_restart: Battleground.restart (battleground.py:108-117) -> Ship.reset
+ *   (ship.py:92-106) -> Agent.reset (agent.py:59-64) with their quirks:
+ *   pointing = OLD position, `x or old` keeps the coordinate when the draw is 0,
+ *   hull not restored, reward NOT cleared, score appended then zeroed.
+ *   arena_mask[N] (uint8, may be NULL = all) selects the arenas to restart.
+ * draws are the reference's randint(0, dim) values (inclusive: may equal W/H). */
+int ofx_spawn(ofx_handle *h, const int32_t *draws);
+int ofx_restart(ofx_handle *h, const int32_t *draws, const uint8_t *arena_mask);
+/* same, draws generated on device by the counter RNG (seed, episode)         */
+int ofx_spawn_random(ofx_handle *h, uint64_t seed);
+int ofx_restart_random(ofx_handle *h, uint64_t seed, uint32_t episode);
+
+/* ---- the tick ----------------------------------------------------------
+ * ofx_step = Agent.step bookkeeping for every ship, dead included
+ *            (score += reward; reward = 0: agents/agent.py:66-74, ship.py:260-262)
+ *          + GUI laser clean-up of lasers destroyed in the previous tick
+ *            (lib/ofighters.py:619-625,702-707)
+ *          + Battleground.generate_frame(actions) (battleground.py:153-160):
+ *            Laser.move for every laser in list order (laser.py:36-62), then
+ *            Ship.move(action) in index order (ship.py:303-339: pointing,
+ *            thrust ship.py:213-222, shoot ship.py:134-156 + form.py:159-188,
+ *            aim / trajectory rewards ship.py:158-210).
+ * actions: device [N][M] ofx_action.                                         */
+int ofx_step(ofx_handle *h, const ofx_action *actions);
+
+/* ---- observation -------------------------------------------------------
+ * ofx_rasterise = Observation.analyse_battleground (lib/observation.py:79-95)
+ *   with Circle.binary_draw -> skimage.draw.disk((y,x), r, shape) arithmetic
+ *   (lib/form.py:222-228; scikit-image 0.18.3 draw.py:11-43,46-143).
+ *   Maps are [N][W rows = y][H cols = x]; playable ships (r=ship_radius) into
+ *   ship_map, every listed laser incl. just-destroyed (r=laser_radius) into
+ *   laser_map.  NULL output pointers select the handle's internal buffers
+ *   (see ofx_map_ptr).
+ * ofx_observe_head = Observation.analyse_ship + toVector head
+ *   (observation.py:101-123): float64 [N][M][8] =
+ *   reward, can_shoot(1), pointing.x, pointing.y, dim.x, dim.y, pos.x, pos.y;
+ *   done[N][M] uint8 = not playable (may be NULL).                           */
+int ofx_rasterise(ofx_handle *h, int map_type, void *ship_map, void *laser_map);
+size_t ofx_map_bytes(const ofx_handle *h, int map_type); /* bytes of ONE arena's ONE map */
+void *ofx_map_ptr(ofx_handle *h, int map_type, int which /*0 ship,1 laser*/);
+int ofx_observe_head(ofx_handle *h, double *head, uint8_t *done);
+
+/* ---- scripted bots on device -------------------------------------------
+ * behaviours[M] (host, OFX_BOT_*) ; actions out device [N][M].  Draws come
+ * from Philox4x32-10 keyed by (seed) with counter (global arena, ship, tick),
+ * so any GPU count reproduces the same stream.  Same action LAW as
+ * agents/agent.py:99-155 (not the Mersenne-Twister stream).                  */
+int ofx_bot_actions(ofx_handle *h, const int32_t *behaviours_host, uint64_t seed,
+                    uint32_t tick, ofx_action *actions);
+
+/* ---- state access ------------------------------------------------------ */
+int ofx_get_host(ofx_handle *h, int field, void *dst_host, size_t bytes);
+void *ofx_device_ptr(ofx_handle *h, int field);
+size_t ofx_field_bytes(const ofx_handle *h, int field);
+/* number of lasers dropped because an arena's list was full since the last
+ * call (never silent truncation); resets the counter.                        */
+int ofx_overflow_count(ofx_handle *h, int64_t *count_host);
+
+/* ---- episodic scores (the only cross-GPU quantity) ----------------------
+ * Writes int64 [M+1] to a DEVICE buffer: sum over local arenas of the score
+ * each ship slot banked at the most recent ofx_restart (Agent.reset:
+ * scores.append(score), agents/agent.py:61-63) and, last, the arena count.
+ * The caller all-reduces it (RCCL via torch.distributed).                    */
+int ofx_episode_scores(ofx_handle *h, int64_t *sums);
+
+/* ---- scratch MLP forward -----------------------------------------------
+ * Neural_network.feed (agents/neural_network.py:396-420): a <- sigmoid(W a + b)
+ * per layer, float64, column vectors.  layers_host[n_layers] sizes;
+ * weights: concatenated row-major W_i (n_{i+1} x n_i); biases concatenated;
+ * x [batch][layers[0]] ; y [batch][layers[-1]] ; argmax int32 [batch] may be
+ * NULL (Neural_network.max_sol_index, neural_network.py:423-429).            */
+int ofx_scratch_feed(ofx_handle *h, const int32_t *layers_host, int32_t n_layers,
+                     const double *weights, const double *biases, const double *x,
+                     int32_t batch, double *y, int32_t *argmax);
+/* same network fed with the live observation vector of every (arena, ship)
+ * (toVector order, observation.py:119-125; needs layers[0] == 8 + 2*W*H):
+ * the binary map tail is consumed as a sparse gather of W_1 columns.
+ * y [N][M][layers[-1]].                                                      */
+int ofx_scratch_feed_obs(ofx_handle *h, const int32_t *layers_host, int32_t n_layers,
+                         const double *weights, const double *biases, double *y,
+                         int32_t *argmax);
+
+/* ---- bi-head policy forward --------------------------------------------
+ * Trainer.pointer_model graph + inference glue
+ * (agents/qlearnIA_V2.py:123-190, 206-220).  See ofx_policy.h-style layout
+ * notes in DESIGN.md; weights are one float32 blob described by
+ * ofx_policy_layout().                                                       */
+typedef struct ofx_policy_desc {
+  int32_t n_floats;        /* total length of the weight blob                 */
+  int32_t offset[48];      /* start of each tensor, order given in DESIGN.md  */
+  int32_t count[48];
+  int32_t n_tensors;
+} ofx_policy_desc;
+int ofx_policy_layout(const ofx_handle *h, ofx_policy_desc *desc_host);
+/* ship_mask[N][M] uint8 (NULL = every ship) selects which ships get a
+ * forward; act_values float32 [N][M][2]; iaction int32 [N][M];
+ * ipointer int32 [N][M][2] = (x, y) of the heat-map arg-max
+ * (unravel_index(order='F'), qlearnIA_V2.py:218-220); heatmap float32
+ * [N][M][W][H] or NULL (never materialised when NULL).                       */
+int ofx_policy_forward(ofx_handle *h, const float *weights, const uint8_t *ship_mask,
+                       float *act_values, int32_t *iaction, int32_t *ipointer,
+                       float *heatmap);
+/* QlearnIA.play action packing (qlearnIA_V2.py:447-454): exactly one of
+ * shoot/thrust set, pointer always set.                                      */
+int ofx_policy_actions(ofx_handle *h, const int32_t *iaction, const int32_t *ipointer,
+                       const uint8_t *ship_mask, ofx_action *actions);
+
+/* ---- timing helpers (HIP events on the handle's stream) ---------------- */
+int ofx_timer_start(ofx_handle *h);
+int ofx_timer_stop(ofx_handle *h, float *ms_host); /* synchronises */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OFX_H */

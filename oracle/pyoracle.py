@@ -1,0 +1,192 @@
+"""ctypes wrapper around oracle/libofx_oracle.so.
+
+TEST INFRASTRUCTURE: may be imported only by tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg.  The product package (ofighters_amd) never
+imports this module and has no CPU fallback.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class OrcCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "n_ships", "width", "height", "ship_radius", "laser_radius", "ship_speed",
+        "laser_speed", "reward_death", "reward_kill", "reward_aim", "reward_trajectory")]
+
+
+def default_cfg(n_ships=8, **kw):
+    cfg = OrcCfg(n_ships, 400, 400, 8, 2, 8, 10, 0, 0, 2, 1)
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libofx_oracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("ofx_oracle.c", "policy_oracle.c", "Makefile")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "libofx_oracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        vp, i32p, u8p, i64p, f64p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
+        L.orc_create.restype = vp
+        L.orc_create.argtypes = [C.POINTER(OrcCfg)]
+        L.orc_destroy.argtypes = [vp]
+        L.orc_spawn.argtypes = [vp, i32p]
+        L.orc_set_ship.argtypes = [vp, C.c_int, C.c_long, C.c_long, C.c_long, C.c_long]
+        L.orc_restart.argtypes = [vp, i32p]
+        L.orc_step.argtypes = [vp, i32p]
+        L.orc_n_lasers.argtypes = [vp]
+        L.orc_n_lasers.restype = C.c_int
+        L.orc_get_ships.argtypes = [vp, i32p, i32p, u8p, i64p, i64p, i32p, i64p, i64p]
+        L.orc_get_lasers.argtypes = [vp, f64p, f64p, i32p, u8p]
+        L.orc_obs_head.argtypes = [vp, f64p, u8p]
+        L.orc_rasterise.argtypes = [vp, u8p, u8p]
+        L.orc_disk.argtypes = [u8p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double]
+        L.orc_thrust.argtypes = [C.POINTER(OrcCfg), C.POINTER(C.c_long), C.POINTER(C.c_long), C.c_long, C.c_long]
+        L.orc_edge.argtypes = [C.c_long] * 6 + [C.POINTER(C.c_long), C.POINTER(C.c_long)]
+        L.orc_edge.restype = C.c_int
+        L.orc_enemy_aimed.argtypes = [C.POINTER(OrcCfg)] + [C.c_long] * 4
+        L.orc_enemy_aimed.restype = C.c_int
+        L.orc_enemy_on_trajectory.argtypes = [C.POINTER(OrcCfg)] + [C.c_long] * 6
+        L.orc_enemy_on_trajectory.restype = C.c_int
+        L.orc_nn_feed.argtypes = [i32p, C.c_int, f64p, f64p, f64p, f64p]
+        L.orc_philox.argtypes = [C.c_uint32] * 4 + [C.c_uint64, vp]
+        L.orc_bot_actions.argtypes = [vp, i32p, C.c_uint64, C.c_uint32, C.c_uint32, i32p]
+        L.orc_reset_draws.argtypes = [C.POINTER(OrcCfg), C.c_uint64, C.c_uint32, C.c_uint32, i32p]
+        L.orc_run_random.argtypes = [C.POINTER(OrcCfg), C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int]
+        L.orc_run_random.restype = C.c_uint64
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Arena:
+    """One reference Battleground restated on the CPU."""
+
+    def __init__(self, cfg=None, **kw):
+        self.cfg = cfg if cfg is not None else default_cfg(**kw)
+        self.M = self.cfg.n_ships
+        self._h = lib().orc_create(C.byref(self.cfg))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_destroy(self._h)
+            self._h = None
+
+    def spawn(self, draws):
+        d = np.ascontiguousarray(draws, dtype=np.int32).reshape(self.M, 2)
+        lib().orc_spawn(self._h, _p(d))
+
+    def set_ship(self, i, x, y, px, py):
+        lib().orc_set_ship(self._h, i, int(x), int(y), int(px), int(py))
+
+    def restart(self, draws):
+        d = np.ascontiguousarray(draws, dtype=np.int32).reshape(self.M, 2)
+        lib().orc_restart(self._h, _p(d))
+
+    def step(self, actions):
+        """actions [M,5] int32: valid, shoot, thrust, px, py"""
+        a = np.ascontiguousarray(actions, dtype=np.int32).reshape(self.M, 5)
+        lib().orc_step(self._h, _p(a))
+
+    def ships(self):
+        M = self.M
+        out = dict(xy=np.zeros((M, 2), np.int32), pt=np.zeros((M, 2), np.int32), alive=np.zeros(M, np.uint8),
+                   reward=np.zeros(M, np.int64), score=np.zeros(M, np.int64), killer=np.zeros(M, np.int32),
+                   last_score=np.zeros(M, np.int64), hull=np.zeros(M, np.int64))
+        lib().orc_get_ships(self._h, _p(out["xy"]), _p(out["pt"]), _p(out["alive"]), _p(out["reward"]),
+                            _p(out["score"]), _p(out["killer"]), _p(out["last_score"]), _p(out["hull"]))
+        return out
+
+    def lasers(self):
+        n = lib().orc_n_lasers(self._h)
+        out = dict(x=np.zeros(n), y=np.zeros(n), owner=np.zeros(n, np.int32), destroyed=np.zeros(n, np.uint8))
+        if n:
+            lib().orc_get_lasers(self._h, _p(out["x"]), _p(out["y"]), _p(out["owner"]), _p(out["destroyed"]))
+        return out
+
+    def obs_head(self):
+        head = np.zeros((self.M, 8))
+        done = np.zeros(self.M, np.uint8)
+        lib().orc_obs_head(self._h, _p(head), _p(done))
+        return head, done
+
+    def rasterise(self):
+        W, H = self.cfg.width, self.cfg.height
+        sm = np.zeros((W, H), np.uint8)
+        lm = np.zeros((W, H), np.uint8)
+        lib().orc_rasterise(self._h, _p(sm), _p(lm))
+        return sm, lm
+
+    def bot_actions(self, behaviours, seed, global_arena, tick):
+        b = np.ascontiguousarray(behaviours, dtype=np.int32)
+        act = np.zeros((self.M, 5), np.int32)
+        lib().orc_bot_actions(self._h, _p(b), C.c_uint64(seed), global_arena, tick, _p(act))
+        return act
+
+
+def disk(r, c, radius, rows=400, cols=400):
+    m = np.zeros((rows, cols), np.uint8)
+    lib().orc_disk(_p(m), rows, cols, float(r), float(c), float(radius))
+    return m
+
+
+def thrust(cfg, x, y, px, py):
+    cx, cy = C.c_long(int(x)), C.c_long(int(y))
+    lib().orc_thrust(C.byref(cfg), C.byref(cx), C.byref(cy), int(px), int(py))
+    return cx.value, cy.value
+
+
+def edge(x, y, radius, xn, yn, distance):
+    ex, ey = C.c_long(0), C.c_long(0)
+    ok = lib().orc_edge(int(x), int(y), int(radius), int(xn), int(yn), int(distance), C.byref(ex), C.byref(ey))
+    return (ex.value, ey.value) if ok else None
+
+
+def enemy_aimed(cfg, px, py, ex, ey):
+    return bool(lib().orc_enemy_aimed(C.byref(cfg), int(px), int(py), int(ex), int(ey)))
+
+
+def enemy_on_trajectory(cfg, sx, sy, px, py, ex, ey):
+    return bool(lib().orc_enemy_on_trajectory(C.byref(cfg), int(sx), int(sy), int(px), int(py), int(ex), int(ey)))
+
+
+def nn_feed(layers, weights, biases, x):
+    layers = np.ascontiguousarray(layers, dtype=np.int32)
+    w = np.ascontiguousarray(np.concatenate([np.asarray(a, np.float64).ravel() for a in weights]))
+    b = np.ascontiguousarray(np.concatenate([np.asarray(a, np.float64).ravel() for a in biases]))
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.zeros(int(layers[-1]))
+    lib().orc_nn_feed(_p(layers), len(layers), _p(w), _p(b), _p(x), _p(y))
+    return y
+
+
+def philox(c0, c1, c2, c3, seed):
+    out = np.zeros(4, np.uint32)
+    lib().orc_philox(c0, c1, c2, c3, C.c_uint64(seed), _p(out))
+    return out
+
+
+def reset_draws(cfg, seed, global_arena, episode):
+    d = np.zeros((cfg.n_ships, 2), np.int32)
+    lib().orc_reset_draws(C.byref(cfg), C.c_uint64(seed), global_arena, episode, _p(d))
+    return d
+
+
+def run_random(cfg, n_arenas, ticks, seed, do_raster, episode_ticks=200):
+    return lib().orc_run_random(C.byref(cfg), n_arenas, ticks, C.c_uint64(seed), int(do_raster), episode_ticks)
