@@ -1,0 +1,183 @@
+#!/usr/bin/env python
+"""bench.py - arena-steps/sec of the hot path on N MI355X (one process per GPU).
+
+A "step" is one lock-step of the per-GPU arena batch: on-device random-bot
+actions (agents/agent.py:123-133 law, counter RNG) -> ofx_step (physics +
+collision + reward) -> ofx_rasterise (u8 ship/laser maps) [-> policy forward,
+once built], with Battleground.restart + the episodic score all-reduce (RCCL)
+every 200 ticks.  Arenas shard by global id (weak scaling: 4096 per GPU); the
+only collective is the [M+1] int64 score all-reduce at episode ends.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) including
+  roofline     - dominant kernel's algorithmic bytes / measured HIP-event time
+  cpu_baseline - the CPU oracle timed on a bounded sample (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SEED = 0x0F160001
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--arenas", type=int, default=4096, help="arenas per GPU")
+    ap.add_argument("--ships", type=int, default=8)
+    ap.add_argument("--workload", default="step+obs", choices=["step", "step+obs"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import numpy as np
+    import torch
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+
+    from ofighters_amd import ArenaBatch, _native as nat
+
+    N, M = args.arenas, args.ships
+    b = ArenaBatch(N, M, device=local_rank, arena_base=rank * N)
+    beh = ["random"] * M
+    ep_ticks = b.cfg.episode_ticks
+    do_obs = args.workload != "step"
+    scores = torch.zeros(M + 1, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()  # the handle's stream is non-blocking w.r.t. torch's
+    score_log = []
+
+    def episode_end():
+        # Agent.reset banks the episode score (agents/agent.py:61-63); the
+        # per-slot sums over all arenas of all GPUs are the one cross-GPU number.
+        b.restart_random(SEED)
+        b.episode_scores_into(scores.data_ptr())
+        b.sync()
+        if dist is not None:
+            dist.all_reduce(scores)
+        score_log.append(scores.clone())
+        torch.cuda.synchronize()
+
+    tick = [0]
+    EV = [0]
+
+    def lockstep(timed):
+        t = tick[0]
+        if t > 0 and t % ep_ticks == 0:
+            episode_end()
+        b.bot_actions(beh, SEED, tick=t)
+        if timed and not do_obs:
+            b.event_record(EV[0])
+        b.step(actions_ptr=b._actions.ptr)
+        if timed and not do_obs:
+            b.event_record(EV[0] + 1)
+            EV[0] += 2
+        if do_obs:
+            if timed:
+                b.event_record(EV[0])
+            b.rasterise(nat.MAP_U8)
+            if timed:
+                b.event_record(EV[0] + 1)
+                EV[0] += 2
+        tick[0] = t + 1
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    b.spawn_random(SEED)
+    for _ in range(args.warmup):
+        lockstep(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lockstep(True)
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # dominant kernel: average launch duration from the HIP events recorded on
+    # the handle's stream inside the timed region
+    n_ev = EV[0] // 2
+    k_ms = [b.event_elapsed(2 * i, 2 * i + 1) for i in range(min(n_ev, 32000))]
+    k_avg_ms = float(np.mean(k_ms)) if k_ms else float("nan")
+    overflow = b.overflow_count()
+    if do_obs:
+        kernel = "k_raster<u8>"
+        alg_bytes = N * 2 * b.W * b.H * 1          # two u8 maps written per arena (SURVEY 8d cfg 3)
+    else:
+        kernel = "k_step"
+        alg_bytes = N * 3200                        # SURVEY 8d cfg 2: ~3.2 KB per arena-step
+    achieved = alg_bytes / (k_avg_ms * 1e-3) / 1e9
+
+    out = {
+        "metric": "arena-steps/sec (env.step+obs+policy fwd) at 4096 arenas, 1/2/4/8 MI355X",
+        "value": world * N * args.steps / dt,
+        "unit": "arena-steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": ("%d arenas x %d ships per GPU, random-bot actions + step" % (N, M))
+                        + (" + 2D obs rasterise (u8 maps)" if do_obs else "")
+                        + "; policy forward not yet in the timed region (BASELINE configs[2], not [3])",
+            "arenas_per_gpu": N, "ships": M, "laser_cap": b.L, "episode_ticks": ep_ticks,
+            "parallelism": "arena-sharded x%d, RCCL all-reduce of episodic scores only" % world,
+            "laser_overflow": overflow,
+        },
+        "roofline": {
+            "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "avg_kernel_ms": k_avg_ms, "algorithmic_bytes_per_launch": alg_bytes,
+        },
+    }
+    if score_log:
+        out["config"]["last_episode_score_sum"] = int(score_log[-1][:M].sum().item())
+        out["config"]["last_episode_arenas"] = int(score_log[-1][M].item())
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # CPU oracle (a port, 1 thread) on a bounded sample of the same workload
+        from oracle import pyoracle
+        cfg = pyoracle.default_cfg(M)
+        n_s, t_s = (1024, 200) if do_obs else (4096, 200)
+        c0 = time.perf_counter()
+        pyoracle.run_random(cfg, n_s, t_s, SEED, int(do_obs), ep_ticks)
+        cdt = time.perf_counter() - c0
+        out["cpu_baseline"] = {
+            "value": n_s * t_s / cdt, "unit": "arena-steps/s", "cores": 1, "kind": "port",
+            "sample": "%d arenas x %d ticks of the same workload (C oracle, single thread)" % (n_s, t_s),
+        }
+    if rank == 0:
+        print(json.dumps(out))
+    b.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

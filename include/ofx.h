@@ -258,6 +258,11 @@ int ofx_policy_actions(ofx_handle *h, const int32_t *iaction, const int32_t *ipo
 /* ---- timing helpers (HIP events on the handle's stream) ---------------- */
 int ofx_timer_start(ofx_handle *h);
 int ofx_timer_stop(ofx_handle *h, float *ms_host); /* synchronises */
+/* Non-blocking per-kernel timing for bench.py: record numbered events on the
+ * handle's stream (created on first use, idx in [0, 65536)), read the elapsed
+ * time between two of them later (synchronises on the second).              */
+int ofx_event_record(ofx_handle *h, int32_t idx);
+int ofx_event_elapsed(ofx_handle *h, int32_t idx_from, int32_t idx_to, float *ms_host);
 
 #ifdef __cplusplus
 }

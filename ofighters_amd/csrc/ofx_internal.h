@@ -1,0 +1,86 @@
+// ofx_internal.h - handle layout and helpers shared by the HIP translation
+// units of libofx.so (gfx950 only; no CPU fallback, no CUDA shims).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/ofx.h"
+
+#define OFX_WAVE 64
+#define OFX_ARENAS_PER_BLOCK 4 /* one 64-lane wave per arena, 256-thread blocks */
+
+void ofx_set_error(const char *fmt, ...);
+
+#define OFX_HIP(call)                                                                  \
+  do {                                                                                 \
+    hipError_t _e = (call);                                                            \
+    if (_e != hipSuccess) {                                                            \
+      ofx_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__,   \
+                    __LINE__);                                                         \
+      return OFX_ERR_HIP;                                                              \
+    }                                                                                  \
+  } while (0)
+
+// Structure-of-arrays arena state, all in HBM.  Ships: [N][M]; lasers [N][L];
+// per-arena scalars [N].  A wave reads one arena's M ship words / 64 laser
+// slots as one coalesced segment per array.
+struct ofx_state {
+  int32_t *ship_x, *ship_y, *ship_px, *ship_py, *hull;
+  int32_t *reward, *score, *obs_reward, *last_score;
+  uint8_t *alive;
+  int16_t *killer;
+  int32_t *time, *n_lasers;
+  double *laser_x, *laser_y, *laser_dx, *laser_dy;
+  uint8_t *laser_owner, *laser_dead;
+  unsigned long long *overflow;    // [1]
+  long long *episode_sums;         // [M+1]
+};
+
+struct ofx_handle {
+  ofx_config cfg;
+  hipStream_t stream;
+  bool own_stream;
+  bool spawned;
+  ofx_state st;
+  double hit_thresh;               // largest d2 with rn(sqrt(d2)) <= r_laser + r_ship
+  // observation maps (lazily allocated per type): [type][which]
+  void *maps[5][2];
+  int32_t *bot_behaviours;         // device [M]
+  // scratch for nn / policy
+  void *scratch;
+  size_t scratch_bytes;
+  hipEvent_t ev0, ev1;
+  bool events;
+  hipEvent_t *ring;                // numbered events for ofx_event_record
+  int ring_n;
+};
+
+// kernels / launchers implemented in the other translation units
+int ofx_launch_step(ofx_handle *h, const ofx_action *actions);
+int ofx_launch_raster(ofx_handle *h, int map_type, void *ship_map, void *laser_map);
+int ofx_ensure_scratch(ofx_handle *h, size_t bytes);
+
+#define OFX_MAP_BITS_LSB 4 /* internal: 1 bit / cell, pixel p -> bit (p & 31) of word p >> 5 */
+
+// Philox4x32-10 counter RNG (Salmon et al. SC'11); same constants / round
+// structure as the oracle's restatement so both produce one stream.
+__host__ __device__ inline void ofx_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                  uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+#define OFX_STREAM_BOT 0u
+#define OFX_STREAM_RESET 1u
+
+__host__ __device__ inline int32_t ofx_draw_int(uint32_t r, int32_t n_inclusive) {
+  return (int32_t)(((uint64_t)r * (uint64_t)(n_inclusive + 1)) >> 32);
+}

@@ -1,0 +1,246 @@
+"""ArenaBatch - host-side driver of N lock-stepped arenas on one MI355X.
+
+The batched analogue of ``Battleground`` (lib/battleground.py:10-173): the
+per-tick order is the reference's ``frame()`` (battleground.py:163-166)
+
+    request_actions -> generate_frame(actions) -> Observation(battleground)
+
+with the GUI's laser clean-up between ticks (lib/ofighters.py:619-625,702-707)
+and ``restart()`` between episodes.  All arithmetic happens in libofx.so
+(hand-written HIP); this module only marshals numpy / device pointers.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as nat
+
+_FIELD_DTYPE = {
+    nat.F_SHIP_X: np.int32, nat.F_SHIP_Y: np.int32, nat.F_SHIP_PX: np.int32, nat.F_SHIP_PY: np.int32,
+    nat.F_SHIP_ALIVE: np.uint8, nat.F_REWARD: np.int32, nat.F_SCORE: np.int32, nat.F_N_LASERS: np.int32,
+    nat.F_LASER_X: np.float64, nat.F_LASER_Y: np.float64, nat.F_LASER_OWNER: np.uint8,
+    nat.F_LASER_DEAD: np.uint8, nat.F_KILLER: np.int16, nat.F_TIME: np.int32, nat.F_LAST_SCORES: np.int32,
+    nat.F_HULL: np.int32, nat.F_LASER_DX: np.float64, nat.F_LASER_DY: np.float64, nat.F_OBS_REWARD: np.int32,
+}
+_MAP_DTYPE = {nat.MAP_U8: np.uint8, nat.MAP_F32: np.float32, nat.MAP_F64: np.float64, nat.MAP_BITS: np.uint8}
+
+ACTION_DTYPE = np.dtype([("px", np.int32), ("py", np.int32), ("shoot", np.uint8), ("thrust", np.uint8),
+                         ("valid", np.uint8), ("_pad", np.uint8)])
+assert ACTION_DTYPE.itemsize == C.sizeof(nat.OfxAction) == 12
+
+
+class DeviceBuffer:
+    """A raw HBM allocation owned by the host side (ofx_malloc / ofx_free)."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        nat.check(nat.lib().ofx_malloc(C.byref(p), self.nbytes))
+        self.ptr = p.value
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        if arr.nbytes > self.nbytes:
+            raise Exception("DeviceBuffer.upload: %d bytes into a %d byte buffer" % (arr.nbytes, self.nbytes))
+        nat.check(nat.lib().ofx_memcpy_h2d(self.ptr, arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+        return self
+
+    def download(self, dtype, shape):
+        out = np.empty(shape, dtype=dtype)
+        if out.nbytes > self.nbytes:
+            raise Exception("DeviceBuffer.download: %d bytes from a %d byte buffer" % (out.nbytes, self.nbytes))
+        nat.check(nat.lib().ofx_memcpy_d2h(out.ctypes.data_as(C.c_void_p), self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            nat.lib().ofx_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def pack_actions(valid, shoot, thrust, px, py):
+    """numpy -> [N][M] ofx_action records (lib/action.py:12-56; valid=0 is None)."""
+    valid = np.asarray(valid)
+    a = np.zeros(valid.shape, dtype=ACTION_DTYPE)
+    a["valid"] = valid
+    a["shoot"] = shoot
+    a["thrust"] = thrust
+    a["px"] = px
+    a["py"] = py
+    return a
+
+
+class ArenaBatch:
+    def __init__(self, n_arenas, n_ships=8, **cfg):
+        self.cfg = nat.default_config(n_arenas=n_arenas, n_ships=n_ships, **cfg)
+        h = C.c_void_p()
+        nat.check(nat.lib().ofx_create(C.byref(self.cfg), C.byref(h)))
+        self._h = h.value
+        self.N, self.M, self.L = self.cfg.n_arenas, self.cfg.n_ships, self.cfg.laser_cap
+        self.W, self.H = self.cfg.width, self.cfg.height
+        self._actions = DeviceBuffer(self.N * self.M * ACTION_DTYPE.itemsize)
+        self._draws = None
+        self._head = None
+        self._done = None
+        self.tick = 0
+        self.episode = 0
+
+    # ---------------------------------------------------------------- lifetime
+    def close(self):
+        if getattr(self, "_h", None):
+            nat.lib().ofx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def sync(self):
+        nat.check(nat.lib().ofx_sync(self._h))
+
+    # --------------------------------------------------------- spawn / restart
+    def _draw_buf(self, draws):
+        d = np.ascontiguousarray(draws, dtype=np.int32).reshape(self.N, self.M, 2)
+        if self._draws is None:
+            self._draws = DeviceBuffer(d.nbytes)
+        return self._draws.upload(d).ptr
+
+    def spawn(self, draws):
+        """Battleground.__init__ positions: draws [N,M,2] = randint(0,W), randint(0,H)."""
+        nat.check(nat.lib().ofx_spawn(self._h, self._draw_buf(draws)))
+        self.tick = 0
+
+    def spawn_random(self, seed):
+        nat.check(nat.lib().ofx_spawn_random(self._h, seed))
+        self.tick = 0
+
+    def restart(self, draws, arena_mask=None):
+        mptr = None
+        if arena_mask is not None:
+            m = np.ascontiguousarray(arena_mask, dtype=np.uint8).reshape(self.N)
+            self._mask = DeviceBuffer(m.nbytes).upload(m)
+            mptr = self._mask.ptr
+        nat.check(nat.lib().ofx_restart(self._h, self._draw_buf(draws), mptr))
+        self.episode += 1
+
+    def restart_random(self, seed):
+        self.episode += 1
+        nat.check(nat.lib().ofx_restart_random(self._h, seed, self.episode))
+
+    def set_ships(self, x=None, y=None, px=None, py=None):
+        """Crafted starts (test / fixture use): overwrite ship fields [N,M]."""
+        for f, v in ((nat.F_SHIP_X, x), (nat.F_SHIP_Y, y), (nat.F_SHIP_PX, px), (nat.F_SHIP_PY, py)):
+            if v is not None:
+                a = np.ascontiguousarray(v, dtype=np.int32).reshape(self.N, self.M)
+                self.sync()
+                nat.check(nat.lib().ofx_memcpy_h2d(nat.lib().ofx_device_ptr(self._h, f),
+                                                   a.ctypes.data_as(C.c_void_p), a.nbytes))
+
+    # -------------------------------------------------------------------- tick
+    def step(self, actions=None, actions_ptr=None):
+        """One lock-step.  `actions`: structured array [N,M] (pack_actions) or
+        `actions_ptr`: device pointer to [N][M] ofx_action."""
+        if actions_ptr is None:
+            a = np.ascontiguousarray(actions, dtype=ACTION_DTYPE).reshape(self.N, self.M)
+            actions_ptr = self._actions.upload(a).ptr
+        nat.check(nat.lib().ofx_step(self._h, actions_ptr))
+        self.tick += 1
+
+    def bot_actions(self, behaviours, seed, tick=None, out_ptr=None):
+        """Scripted bots on device (agents/agent.py:99-155 laws) -> device actions."""
+        b = np.array([nat.BEHAVIOURS[x] if not isinstance(x, (int, np.integer)) else int(x) for x in behaviours],
+                     dtype=np.int32)
+        if b.shape != (self.M,):
+            raise Exception("behaviours must have one entry per ship")
+        out_ptr = out_ptr or self._actions.ptr
+        nat.check(nat.lib().ofx_bot_actions(self._h, b.ctypes.data_as(C.c_void_p), seed,
+                                            self.tick if tick is None else tick, out_ptr))
+        return out_ptr
+
+    def actions_host(self):
+        return self._actions.download(ACTION_DTYPE, (self.N, self.M))
+
+    # ------------------------------------------------------------- observation
+    def rasterise(self, map_type=nat.MAP_U8, ship_ptr=None, laser_ptr=None):
+        nat.check(nat.lib().ofx_rasterise(self._h, map_type, ship_ptr, laser_ptr))
+
+    def maps_host(self, map_type=nat.MAP_U8):
+        """(ship_map, laser_map) as numpy [N,W,H] ([N,W*H/8] for MAP_BITS)."""
+        self.rasterise(map_type)
+        per = nat.lib().ofx_map_bytes(self._h, map_type)
+        dt = np.dtype(_MAP_DTYPE[map_type])
+        shape = (self.N, per) if map_type == nat.MAP_BITS else (self.N, self.W, self.H)
+        out = []
+        for which in (0, 1):
+            a = np.empty(shape, dtype=dt)
+            self.sync()
+            nat.check(nat.lib().ofx_memcpy_d2h(a.ctypes.data_as(C.c_void_p),
+                                               nat.lib().ofx_map_ptr(self._h, map_type, which), a.nbytes))
+            out.append(a)
+        return out
+
+    def observe_head(self):
+        """obs.vector[:8] for every ship + done flags (observation.py:101-123)."""
+        if self._head is None:
+            self._head = DeviceBuffer(self.N * self.M * 8 * 8)
+            self._done = DeviceBuffer(self.N * self.M)
+        nat.check(nat.lib().ofx_observe_head(self._h, self._head.ptr, self._done.ptr))
+        self.sync()
+        return (self._head.download(np.float64, (self.N, self.M, 8)),
+                self._done.download(np.uint8, (self.N, self.M)))
+
+    # ------------------------------------------------------------ state access
+    def get(self, field):
+        dt = np.dtype(_FIELD_DTYPE[field])
+        nbytes = nat.lib().ofx_field_bytes(self._h, field)
+        a = np.empty(nbytes // dt.itemsize, dtype=dt)
+        nat.check(nat.lib().ofx_get_host(self._h, field, a.ctypes.data_as(C.c_void_p), nbytes))
+        n = self.N
+        return a.reshape(n, -1) if a.size != n else a
+
+    def device_ptr(self, field):
+        return nat.lib().ofx_device_ptr(self._h, field)
+
+    def overflow_count(self):
+        v = C.c_int64(0)
+        nat.check(nat.lib().ofx_overflow_count(self._h, C.byref(v)))
+        return v.value
+
+    def episode_scores_host(self):
+        """int64 [M+1]: per-slot sums banked at the last restart + arena count."""
+        buf = DeviceBuffer(8 * (self.M + 1))
+        nat.check(nat.lib().ofx_episode_scores(self._h, buf.ptr))
+        self.sync()
+        return buf.download(np.int64, (self.M + 1,))
+
+    def episode_scores_into(self, dev_ptr):
+        nat.check(nat.lib().ofx_episode_scores(self._h, dev_ptr))
+
+    # ------------------------------------------------------------------ timing
+    def timer_start(self):
+        nat.check(nat.lib().ofx_timer_start(self._h))
+
+    def timer_stop(self):
+        ms = C.c_float(0)
+        nat.check(nat.lib().ofx_timer_stop(self._h, C.byref(ms)))
+        return ms.value
+
+    def event_record(self, idx):
+        nat.check(nat.lib().ofx_event_record(self._h, idx))
+
+    def event_elapsed(self, a, b):
+        ms = C.c_float(0)
+        nat.check(nat.lib().ofx_event_elapsed(self._h, a, b, C.byref(ms)))
+        return ms.value

@@ -58,7 +58,8 @@ def test_step_trace(name):
 
 
 def test_raster_cases():
-    z = np.load(GOLDEN + "/raster_cases.npz")
+    zf = np.load(GOLDEN + "/raster_cases.npz")
+    z = {k: zf[k] for k in zf.files}
     for (x, y, r), bits in zip(z["cases"], z["maps"]):
         cx, cy = (float(int(x)), float(int(y))) if r == 8.0 else (x, y)
         got = pyoracle.disk(cy, cx, r)          # disk((y, x)): row = y
@@ -66,7 +67,8 @@ def test_raster_cases():
 
 
 def test_geometry_cases():
-    z = np.load(GOLDEN + "/geometry.npz")
+    zf = np.load(GOLDEN + "/geometry.npz")
+    z = {k: zf[k] for k in zf.files}   # NpzFile re-inflates on every access
     cfg = pyoracle.default_cfg()
     for k in range(len(z["inp"])):
         sx, sy, px, py, ex, ey = (int(v) for v in z["inp"][k])
@@ -95,7 +97,8 @@ def test_angle_with_comment_values():
 
 
 def test_scratch_nn():
-    z = np.load(GOLDEN + "/scratch_nn.npz")
+    zf = np.load(GOLDEN + "/scratch_nn.npz")
+    z = {k: zf[k] for k in zf.files}
     for tag in "abc":
         layers = [int(v) for v in z["layers_" + tag]]
         np.random.seed(int(z["seed_" + tag]))
