@@ -115,6 +115,7 @@ class ArenaBatch:
         d = np.ascontiguousarray(draws, dtype=np.int32).reshape(self.N, self.M, 2)
         if self._draws is None:
             self._draws = DeviceBuffer(d.nbytes)
+        self.sync()  # raw copies are not ordered with the handle's stream
         return self._draws.upload(d).ptr
 
     def spawn(self, draws):
@@ -130,6 +131,7 @@ class ArenaBatch:
         mptr = None
         if arena_mask is not None:
             m = np.ascontiguousarray(arena_mask, dtype=np.uint8).reshape(self.N)
+            self.sync()
             self._mask = DeviceBuffer(m.nbytes).upload(m)
             mptr = self._mask.ptr
         nat.check(nat.lib().ofx_restart(self._h, self._draw_buf(draws), mptr))
@@ -154,6 +156,7 @@ class ArenaBatch:
         `actions_ptr`: device pointer to [N][M] ofx_action."""
         if actions_ptr is None:
             a = np.ascontiguousarray(actions, dtype=ACTION_DTYPE).reshape(self.N, self.M)
+            self.sync()  # the previous tick may still be reading the buffer
             actions_ptr = self._actions.upload(a).ptr
         nat.check(nat.lib().ofx_step(self._h, actions_ptr))
         self.tick += 1
@@ -170,6 +173,7 @@ class ArenaBatch:
         return out_ptr
 
     def actions_host(self):
+        self.sync()
         return self._actions.download(ACTION_DTYPE, (self.N, self.M))
 
     # ------------------------------------------------------------- observation
