@@ -190,3 +190,73 @@ def reset_draws(cfg, seed, global_arena, episode):
 
 def run_random(cfg, n_arenas, ticks, seed, do_raster, episode_ticks=200):
     return lib().orc_run_random(C.byref(cfg), n_arenas, ticks, C.c_uint64(seed), int(do_raster), episode_ticks)
+
+
+# ------------------------------------------------------------------ policy
+def policy_layout():
+    """(offsets, counts, total) of the float32 weight blob (oracle/policy_oracle.c header)."""
+    L = lib()
+    L.orc_policy_layout.argtypes = [C.c_void_p, C.c_void_p]
+    L.orc_policy_layout.restype = C.c_int
+    off = np.zeros(64, np.int32)
+    cnt = np.zeros(64, np.int32)
+    n = L.orc_policy_layout(_p(off), _p(cnt))
+    return off[:n].copy(), cnt[:n].copy(), int(off[n])
+
+
+POLICY_TENSORS = (
+    [("conv%d.%s" % (i, s)) for i in (1, 2, 3, 4) for s in ("kernel", "bias", "gamma", "beta", "mean", "var")]
+    + ["dense1.kernel", "dense1.bias", "dense2.kernel", "dense2.bias", "output1.kernel", "output1.bias",
+       "updense1.kernel", "updense1.bias"]
+    + [("upconv%d.%s" % (i, s)) for i in (1, 2, 3) for s in ("kernel", "bias", "gamma", "beta", "mean", "var")]
+    + ["upconv4.kernel", "upconv4.bias"])
+
+
+def policy_init(seed, trained_like=False):
+    """Synthetic weights of the pointer_model architecture (no checkpoint ships with
+    the reference): he_uniform convs, glorot_uniform dense, zero bias, BN gamma=1
+    beta=0 mean=0 var=1 as at construction (qlearnIA_V2.py:129-186).  With
+    trained_like=True biases and BN statistics are randomised too so every term
+    of the graph is exercised."""
+    off, cnt, total = policy_layout()
+    rs = np.random.RandomState(seed)
+    w = np.zeros(total, np.float32)
+    shapes = {}
+    cin = {"conv1": 2, "conv2": 8, "conv3": 8, "conv4": 8, "upconv1": 1, "upconv2": 2, "upconv3": 4, "upconv4": 8}
+    cout = {"conv1": 8, "conv2": 8, "conv3": 8, "conv4": 8, "upconv1": 2, "upconv2": 4, "upconv3": 8, "upconv4": 1}
+    dense = {"dense1": (5008, 100), "dense2": (100, 50), "output1": (50, 2), "updense1": (100, 625)}
+    for name, o, c in zip(POLICY_TENSORS, off, cnt):
+        layer, kind = name.split(".")
+        if kind == "kernel":
+            if layer in dense:
+                fi, fo = dense[layer]
+                lim = np.sqrt(6.0 / (fi + fo))
+                shapes[name] = (fi, fo)
+            else:
+                lim = np.sqrt(6.0 / (9 * cin[layer]))
+                shapes[name] = (3, 3, cin[layer], cout[layer])
+            w[o:o + c] = rs.uniform(-lim, lim, c)
+        elif kind == "gamma":
+            w[o:o + c] = rs.uniform(0.5, 1.5, c) if trained_like else 1.0
+        elif kind == "var":
+            w[o:o + c] = rs.uniform(0.5, 2.0, c) if trained_like else 1.0
+        elif kind in ("beta", "mean", "bias"):
+            w[o:o + c] = rs.uniform(-0.2, 0.2, c) if trained_like else 0.0
+        if name not in shapes:
+            shapes[name] = (c,)
+    return w, {n: (int(o), shapes[n]) for n, o in zip(POLICY_TENSORS, off)}
+
+
+def policy_forward(ship_map, laser_map, vec8, weights, want_heat=True):
+    L = lib()
+    L.orc_policy_forward.argtypes = [C.c_void_p] * 8
+    sm = np.ascontiguousarray(ship_map, np.uint8)
+    lm = np.ascontiguousarray(laser_map, np.uint8)
+    v = np.ascontiguousarray(vec8, np.float32)
+    w = np.ascontiguousarray(weights, np.float32)
+    act = np.zeros(2, np.float32)
+    heat = np.zeros((400, 400), np.float32) if want_heat else None
+    ia = np.zeros(1, np.int32)
+    ip = np.zeros(2, np.int32)
+    L.orc_policy_forward(_p(sm), _p(lm), _p(v), _p(w), _p(act), _p(heat), _p(ia), _p(ip))
+    return act, heat, int(ia[0]), (int(ip[0]), int(ip[1]))

@@ -1,0 +1,78 @@
+"""Cross-check of the bi-head policy restatement (oracle/policy_oracle.c) against
+torch CPU ops.  This is NOT reference parity (keras/tensorflow are absent and no
+weights ship: parity of P1 is unpinned) - it checks that the
+C restatement computes the declared graph."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import pyoracle
+
+
+def torch_forward(sm, lm, vec8, w, lay):
+    def T(name):
+        o, shp = lay[name]
+        return torch.from_numpy(w[o:o + int(np.prod(shp))].reshape(shp).copy())
+
+    def conv(x, name):                              # HWIO -> OIHW
+        return F.conv2d(x, T(name + ".kernel").permute(3, 2, 0, 1), T(name + ".bias"), padding=1)
+
+    def bn(x, name):
+        return F.batch_norm(x, T(name + ".mean"), T(name + ".var"), T(name + ".gamma"), T(name + ".beta"),
+                            training=False, eps=1e-3)
+
+    x = torch.from_numpy(np.stack([sm, lm], 0).astype(np.float32))[None]      # NCHW
+    for i in (1, 2, 3, 4):
+        x = F.max_pool2d(F.relu(bn(conv(x, "conv%d" % i), "conv%d" % i)), 2)
+    flat = x.permute(0, 2, 3, 1).reshape(1, -1)                              # Flatten (h,w,c)
+    cat = torch.cat([torch.from_numpy(vec8.astype(np.float32))[None], flat], 1)
+    d1 = F.relu(cat @ T("dense1.kernel") + T("dense1.bias"))
+    d2 = F.relu(d1 @ T("dense2.kernel") + T("dense2.bias"))
+    act = d2 @ T("output1.kernel") + T("output1.bias")
+    u = F.relu(d1 @ T("updense1.kernel") + T("updense1.bias")).reshape(1, 1, 25, 25)
+    for i in (1, 2, 3):
+        u = F.interpolate(u, scale_factor=2, mode="bilinear", align_corners=False)
+        u = F.relu(bn(conv(u, "upconv%d" % i), "upconv%d" % i))
+    u = F.interpolate(u, scale_factor=2, mode="bilinear", align_corners=False)
+    heat = conv(u, "upconv4")[0, 0]
+    return act[0].numpy(), heat.numpy()
+
+
+def scene(seed):
+    rs = np.random.RandomState(seed)
+    sm = np.zeros((400, 400), np.uint8)
+    lm = np.zeros((400, 400), np.uint8)
+    for _ in range(8):
+        x, y = rs.randint(0, 401, 2)
+        sm |= pyoracle.disk(float(y), float(x), 8.0)
+    for _ in range(30):
+        x, y = rs.uniform(0, 400, 2)
+        lm |= pyoracle.disk(y, x, 2.0)
+    vec8 = np.array([rs.randint(0, 4), 1, rs.randint(0, 401), rs.randint(0, 401), 400, 400,
+                     rs.randint(0, 400), rs.randint(0, 400)], np.float32)
+    return sm, lm, vec8
+
+
+def test_layout():
+    off, cnt, total = pyoracle.policy_layout()
+    assert len(off) == 52 and len(pyoracle.POLICY_TENSORS) == 52
+    # conv 152+584*3, dense1 500900, dense2 5050, out1 102, updense 63125, upconvs 20+76+296+73
+    assert total == (152 + 3 * 584 + 4 * 32) + 500900 + 5050 + 102 + 63125 + (20 + 76 + 296 + 73) + (2 + 4 + 8) * 4
+    assert total == 571730                      # ~571 k params
+
+
+def test_oracle_matches_torch():
+    torch.set_num_threads(4)
+    for seed, trained in ((0, False), (1, True)):
+        w, lay = pyoracle.policy_init(seed, trained_like=trained)
+        sm, lm, vec8 = scene(seed)
+        act, heat, ia, ip = pyoracle.policy_forward(sm, lm, vec8, w)
+        tact, theat = torch_forward(sm, lm, vec8, w, lay)
+        np.testing.assert_allclose(act, tact, rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(heat, theat, rtol=2e-4, atol=2e-4 * float(np.abs(theat).max()))
+        assert ia == int(np.argmax(act))
+        k = int(np.argmax(heat))
+        assert ip == (k % 400, k // 400)                     # (x, y): unravel_index(order='F')
+        assert ip == tuple(int(v) for v in np.unravel_index(k, (400, 400), order="F"))
+        # the torch heat-map agrees on the arg-max up to fp32 noise
+        assert theat[ip[1], ip[0]] >= theat.max() - 2e-4 * float(np.abs(theat).max())
