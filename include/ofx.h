@@ -237,8 +237,8 @@ int ofx_scratch_feed_obs(ofx_handle *h, const int32_t *layers_host, int32_t n_la
  * ofx_policy_layout().                                                       */
 typedef struct ofx_policy_desc {
   int32_t n_floats;        /* total length of the weight blob                 */
-  int32_t offset[48];      /* start of each tensor, order given in DESIGN.md  */
-  int32_t count[48];
+  int32_t offset[64];      /* start of each tensor, order given in DESIGN.md  */
+  int32_t count[64];
   int32_t n_tensors;
 } ofx_policy_desc;
 int ofx_policy_layout(const ofx_handle *h, ofx_policy_desc *desc_host);

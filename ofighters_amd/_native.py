@@ -50,7 +50,7 @@ class OfxAction(C.Structure):
 
 
 class OfxPolicyDesc(C.Structure):
-    _fields_ = [("n_floats", C.c_int32), ("offset", C.c_int32 * 48), ("count", C.c_int32 * 48),
+    _fields_ = [("n_floats", C.c_int32), ("offset", C.c_int32 * 64), ("count", C.c_int32 * 64),
                 ("n_tensors", C.c_int32)]
 
 

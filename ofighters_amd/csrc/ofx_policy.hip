@@ -1,20 +1,626 @@
-// ofx_policy.hip - bi-head policy forward (agents/qlearnIA_V2.py:123-190,206-220)
+// ofx_policy.hip - bi-head "pointer_model" forward for every (arena, ship)
+// (agents/qlearnIA_V2.py:123-190 graph, :206-220 inference glue, :447-454
+// action packing).  fp32 like Keras.  Conventions (BN eps 1e-3, HWIO kernels,
+// (h,w,c) flatten, vector-first concat, half-pixel bilinear x2) are the ones
+// declared in oracle/policy_oracle.c; parity of this path is UNPINNED
+// (keras/tensorflow and weights are absent), it is checked against that
+// restatement with an fp32 tolerance.
+//
+// Work split (what is shared per arena):
+//   trunk   4 x [conv3x3 + BN + ReLU + maxpool2]   once per ARENA  (image is the same for its ships)
+//   dense1  [5008 -> 100]: the 5000 trunk features once per arena on MFMA
+//           (v_mfma_f32_32x32x2_f32, exact fp32), the 8-scalar head per ship
+//   head-1  dense2 + output1 per ship (VALU, tiny)
+//   head-2  updense1 [100 -> 625] on MFMA, then 4 x [bilinear x2 + conv3x3]
+//           per ship; the last conv (8 -> 1 at 400x400) is evaluated in the
+//           4-phase low-resolution form with the arg-max fused, so the
+//           (400,400) heat-map is only materialised on request.
+//
+// Direct convolutions are fp32 VALU kernels: an LDS-staged input tile (halo 1,
+// bilinear upsampling fused into the staging), a 2x2 register tile of outputs
+// x all output channels per thread, weights as wave-uniform scalar operands
+// (s_load + v_fma with an SGPR source).  BatchNorm is folded into the conv
+// weights by k_policy_prepare.
+#include <string.h>
+
 #include "ofx_internal.h"
 
-extern "C" int ofx_policy_layout(const ofx_handle *h, ofx_policy_desc *desc) {
-  (void)h; (void)desc;
-  ofx_set_error("ofx_policy_layout: not built yet");
-  return OFX_ERR_INVALID;
+#define PS 400 /* the model's fixed input side: Input((DEFAULT_WIDTH, DEFAULT_HEIGHT, 2)) */
+
+static const int kTrunkCin[4] = {2, 8, 8, 8};
+static const int kUpCin[4] = {1, 2, 4, 8};
+static const int kUpCout[4] = {2, 4, 8, 1};
+
+// ---- user blob layout (identical to oracle/policy_oracle.c) -------------------
+static int policy_layout(int32_t *offset, int32_t *count) {
+  int n = 0, off = 0;
+#define T(c) do { offset[n] = off; count[n] = (c); off += (c); n++; } while (0)
+  for (int i = 0; i < 4; i++) { T(9 * kTrunkCin[i] * 8); T(8); T(8); T(8); T(8); T(8); }
+  T(5008 * 100); T(100);
+  T(100 * 50); T(50);
+  T(50 * 2); T(2);
+  T(100 * 625); T(625);
+  for (int i = 0; i < 3; i++) { int co = kUpCout[i]; T(9 * kUpCin[i] * co); T(co); T(co); T(co); T(co); T(co); }
+  T(9 * 8 * 1); T(1);
+#undef T
+  offset[n] = off;
+  return n;
 }
+
+extern "C" int ofx_policy_layout(const ofx_handle *h, ofx_policy_desc *desc) {
+  (void)h;
+  if (!desc) { ofx_set_error("ofx_policy_layout: null desc"); return OFX_ERR_INVALID; }
+  memset(desc, 0, sizeof(*desc));
+  desc->n_tensors = policy_layout(desc->offset, desc->count);
+  desc->n_floats = desc->offset[desc->n_tensors];
+  return OFX_OK;
+}
+
+// ---- prepared (BN-folded) weights ------------------------------------------------
+struct PrepLayout {
+  int tw[4], tb[4];   // trunk folded kernels [9][cin][8], biases [8]
+  int uw[3], ub[3];   // upconv1..3 folded
+  int w4eff;          // [4 phases][9 low-res taps][8 ci]
+  int w4raw;          // [9][8]
+  int b4;             // [1]
+  int total;
+};
+
+static PrepLayout prep_layout() {
+  PrepLayout L;
+  int off = 0;
+  for (int i = 0; i < 4; i++) { L.tw[i] = off; off += 9 * kTrunkCin[i] * 8; L.tb[i] = off; off += 8; }
+  for (int i = 0; i < 3; i++) { L.uw[i] = off; off += 9 * kUpCin[i] * kUpCout[i]; L.ub[i] = off; off += kUpCout[i]; }
+  L.w4eff = off; off += 4 * 9 * 8;
+  L.w4raw = off; off += 72;
+  L.b4 = off; off += 1;
+  L.total = (off + 63) & ~63;
+  return L;
+}
+
+struct PrepParams {
+  const float *w;
+  float *prep;
+  int src_k[7], src_b[7], src_g[7], cin[7], cout[7], dst_w[7], dst_b[7];
+  int src_k4, src_b4, dst_w4eff, dst_w4raw, dst_b4;
+};
+
+// interpolation coefficients of the x2 half-pixel bilinear: output row 2i+a, conv
+// tap dy in {-1,0,1} touches low-res rows i-1, i, i+1 with these weights
+__device__ inline float up_coef(int a, int dy, int t) {
+  // a=0: dy-1 -> row 2i-1 = .75 L[i-1] + .25 L[i]; dy0 -> .25 L[i-1] + .75 L[i]; dy+1 -> .75 L[i] + .25 L[i+1]
+  // a=1: dy-1 -> row 2i   = .25 L[i-1] + .75 L[i]; dy0 -> .75 L[i] + .25 L[i+1]; dy+1 -> .25 L[i] + .75 L[i+1]
+  const float c0[3][3] = {{0.75f, 0.25f, 0.f}, {0.25f, 0.75f, 0.f}, {0.f, 0.75f, 0.25f}};
+  const float c1[3][3] = {{0.25f, 0.75f, 0.f}, {0.f, 0.75f, 0.25f}, {0.f, 0.25f, 0.75f}};
+  return a ? c1[dy][t] : c0[dy][t];
+}
+
+__global__ void k_policy_prepare(PrepParams p) {
+  const int tid = threadIdx.x;
+  for (int l = 0; l < 7; l++) {  // BN fold: y = (conv + b) * inv + (beta - mean * inv)
+    const int cin = p.cin[l], cout = p.cout[l];
+    const float *g = p.w + p.src_g[l];  // gamma, beta, mean, var consecutive, each [cout]
+    for (int e = tid; e < 9 * cin * cout; e += blockDim.x) {
+      const int co = e % cout;
+      const float inv = g[co] / sqrtf(g[3 * cout + co] + 1e-3f);
+      p.prep[p.dst_w[l] + e] = p.w[p.src_k[l] + e] * inv;
+    }
+    for (int co = tid; co < cout; co += blockDim.x) {
+      const float inv = g[co] / sqrtf(g[3 * cout + co] + 1e-3f);
+      p.prep[p.dst_b[l] + co] = p.w[p.src_b[l] + co] * inv + (g[cout + co] - g[2 * cout + co] * inv);
+    }
+  }
+  // upconv4 (linear, no BN): effective weights of the 4 output phases on the low-res grid
+  for (int e = tid; e < 4 * 9 * 8; e += blockDim.x) {
+    const int ci = e % 8, tap = (e / 8) % 9, ph = e / 72;
+    const int a = ph >> 1, b = ph & 1, ty = tap / 3, tx = tap % 3;
+    float acc = 0.f;
+    for (int dy = 0; dy < 3; dy++)
+      for (int dx = 0; dx < 3; dx++)
+        acc += p.w[p.src_k4 + (dy * 3 + dx) * 8 + ci] * (up_coef(a, dy, ty) * up_coef(b, dx, tx));
+    p.prep[p.dst_w4eff + e] = acc;
+  }
+  for (int e = tid; e < 72; e += blockDim.x) p.prep[p.dst_w4raw + e] = p.w[p.src_k4 + e];
+  if (tid == 0) p.prep[p.dst_b4] = p.w[p.src_b4];
+}
+
+// ---- generic direct 3x3 convolution ------------------------------------------------
+struct ConvParams {
+  const float *in;                 // MODE 0 / 2: planar [img][CIN][Hin][Win]
+  const unsigned *bits[2];         // MODE 1: [arena][PS*PS/32] LSB-first (ch0 ship, ch1 laser)
+  const float *w, *b;              // folded [9][CIN][COUT], [COUT]
+  float *out;                      // planar [img][COUT][Ho][Wo] or HWC [img][Ho][Wo][COUT]
+  const uint8_t *mask;             // per image, may be null
+  int H, W;                        // conv domain (input after any upsampling) = conv output size
+  int tiles_x, tiles;              // tiles per row / per image
+};
+
+// MODE: 0 planar f32 input, 1 two 1-bit maps, 2 planar f32 input upsampled x2 (bilinear, half-pixel)
+template <int CIN, int COUT, int TH, int TW, int MODE, bool POOL, bool OUT_HWC>
+__global__ __launch_bounds__(((TH / 2) * (TW / 2) + 63) / 64 * 64) void k_conv(ConvParams p) {
+  constexpr int NT = (TH / 2) * (TW / 2);
+  constexpr int NTB = (NT + 63) / 64 * 64;
+  constexpr int TWP = TW + 2;
+  __shared__ __align__(16) float tile[CIN][TH + 2][TWP];
+  const int img = blockIdx.x / p.tiles, t = blockIdx.x - img * p.tiles;
+  if (p.mask && !p.mask[img]) return;  // block-uniform
+  const int ty0 = (t / p.tiles_x) * TH, tx0 = (t % p.tiles_x) * TW;
+  const int tid = threadIdx.x;
+  const int H = p.H, W = p.W;
+
+  // ---- stage the (TH+2) x (TW+2) x CIN input patch (zero outside the image: padding 'same') ----
+  for (int e = tid; e < CIN * (TH + 2) * TWP; e += NTB) {
+    const int c = e % TWP, r = (e / TWP) % (TH + 2), ci = e / (TWP * (TH + 2));
+    const int gy = ty0 - 1 + r, gx = tx0 - 1 + c;
+    float v = 0.f;
+    if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+      if (MODE == 0) {
+        v = p.in[(((size_t)img * CIN + ci) * H + gy) * W + gx];
+      } else if (MODE == 1) {
+        const int cell = gy * W + gx;
+        v = (float)((p.bits[ci][(size_t)img * ((PS * PS) >> 5) + (cell >> 5)] >> (cell & 31)) & 1u);
+      } else {
+        const int Hs = H >> 1, Ws = W >> 1;
+        const float sy = ((float)gy + 0.5f) * 0.5f - 0.5f, sx = ((float)gx + 0.5f) * 0.5f - 0.5f;
+        const float fy = floorf(sy), fx = floorf(sx);
+        const float ly = sy - fy, lx = sx - fx;
+        int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1, x1 = x0 + 1;
+        y0 = max(y0, 0); x0 = max(x0, 0); y1 = min(y1, Hs - 1); x1 = min(x1, Ws - 1);
+        const float *s = p.in + ((size_t)img * CIN + ci) * Hs * Ws;
+        const float a = s[y0 * Ws + x0], b = s[y0 * Ws + x1], d = s[y1 * Ws + x0], g = s[y1 * Ws + x1];
+        const float top = a + (b - a) * lx, bot = d + (g - d) * lx;
+        v = top + (bot - top) * ly;
+      }
+    }
+    tile[ci][r][c] = v;
+  }
+  __syncthreads();
+  if (tid >= NT) return;
+  const int tr = tid / (TW / 2), tc = tid - tr * (TW / 2);
+
+  float acc[2][2][COUT];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int co = 0; co < COUT; co++) acc[i][j][co] = 0.f;
+
+#pragma unroll
+  for (int ci = 0; ci < CIN; ci++) {
+    float v[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const float2 lo = *reinterpret_cast<const float2 *>(&tile[ci][2 * tr + r][2 * tc]);
+      const float2 hi = *reinterpret_cast<const float2 *>(&tile[ci][2 * tr + r][2 * tc + 2]);
+      v[r][0] = lo.x; v[r][1] = lo.y; v[r][2] = hi.x; v[r][3] = hi.y;
+    }
+#pragma unroll
+    for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+      for (int dx = 0; dx < 3; dx++)
+#pragma unroll
+        for (int co = 0; co < COUT; co++) {
+          const float wv = p.w[((dy * 3 + dx) * CIN + ci) * COUT + co];  // wave-uniform -> scalar load
+#pragma unroll
+          for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) acc[i][j][co] = __builtin_fmaf(v[i + dy][j + dx], wv, acc[i][j][co]);
+        }
+  }
+
+  // ---- epilogue: folded bias, ReLU, optional 2x2 max-pool ----
+  const int oy = ty0 + 2 * tr, ox = tx0 + 2 * tc;
+#pragma unroll
+  for (int co = 0; co < COUT; co++) {
+    const float bias = p.b[co];
+    float o00 = fmaxf(acc[0][0][co] + bias, 0.f), o01 = fmaxf(acc[0][1][co] + bias, 0.f);
+    float o10 = fmaxf(acc[1][0][co] + bias, 0.f), o11 = fmaxf(acc[1][1][co] + bias, 0.f);
+    if (POOL) {
+      const float m = fmaxf(fmaxf(o00, o01), fmaxf(o10, o11));
+      const int Ho = H >> 1, Wo = W >> 1, py = oy >> 1, px = ox >> 1;
+      if (OUT_HWC) p.out[(((size_t)img * Ho + py) * Wo + px) * COUT + co] = m;
+      else p.out[(((size_t)img * COUT + co) * Ho + py) * Wo + px] = m;
+    } else {
+      float *o = p.out + (((size_t)img * COUT + co) * H + oy) * W + ox;
+      *reinterpret_cast<float2 *>(o) = make_float2(o00, o01);
+      *reinterpret_cast<float2 *>(o + W) = make_float2(o10, o11);
+    }
+  }
+}
+
+// ---- fp32 MFMA GEMM for the dense layers -------------------------------------------
+// C[M][N] = act(A[M][K] (lda) x B[K][N] (ldb) + bias[N])   one wave per 32x32 tile,
+// v_mfma_f32_32x32x2_f32: lane l holds A[row l&31][k l>>5], B[k l>>5][col l&31];
+// C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void k_gemm_f32(const float *A, int lda, const float *B, int ldb, const float *bias,
+                                                  float *C, int ldc, int M, int N, int K, int relu) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int tiles_n = (N + 31) / 32;
+  const int tile = blockIdx.x * 4 + wv;
+  if (tile >= ((M + 31) / 32) * tiles_n) return;
+  const int m0 = (tile / tiles_n) * 32, n0 = (tile % tiles_n) * 32;
+  const int r = m0 + (lane & 31), c = n0 + (lane & 31), kh = lane >> 5;
+  const bool rv = r < M, cv = c < N;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; i++) acc[i] = 0.f;
+  const float *ap = A + (size_t)(rv ? r : 0) * lda + kh;
+  const float *bp = B + (size_t)kh * ldb + (cv ? c : 0);
+  for (int k0 = 0; k0 < K; k0 += 2) {
+    const bool kv = k0 + kh < K;
+    const float a = (rv && kv) ? ap[k0] : 0.f;
+    const float b = (cv && kv) ? bp[(size_t)k0 * ldb] : 0.f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+  }
+  if (cv) {
+    const float bv = bias ? bias[c] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int row = m0 + (i & 3) + 8 * (i >> 2) + 4 * kh;
+      if (row < M) {
+        float v = acc[i] + bv;
+        if (relu) v = fmaxf(v, 0.f);
+        C[(size_t)row * ldc + c] = v;
+      }
+    }
+  }
+}
+
+// ---- per-ship dense1 finish + head-1 ---------------------------------------------
+// d1 = relu(G1[arena] + vec8 . K1[0:8] + b1) ; d2 = relu(d1 K2 + b2) ; act = d2 K3 + b3
+struct HeadParams {
+  int N, M;
+  ofx_state st;
+  const float *g1;            // [N][100]  trunk part of dense1 (no bias)
+  const float *k1, *b1, *k2, *b2, *k3, *b3;
+  const uint8_t *mask;
+  float *d1;                  // [S][100]
+  float *act;                 // [S][2] or null
+  int32_t *iaction;           // [S] or null
+};
+
+__global__ __launch_bounds__(256) void k_head_dense(HeadParams p) {
+  __shared__ float sd1[4][100];
+  __shared__ float sd2[4][50];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int s = blockIdx.x * 4 + wv;
+  const bool on = s < p.N * p.M && (!p.mask || p.mask[s]);
+  const int a = on ? s / p.M : 0;
+  float vec[8];
+  if (on) {  // obs.vector[:8] (observation.py:119-123): reward, can_shoot, pointing, dim, pos
+    vec[0] = (float)p.st.reward[s]; vec[1] = 1.f;
+    vec[2] = (float)p.st.ship_px[s]; vec[3] = (float)p.st.ship_py[s];
+    vec[4] = (float)PS; vec[5] = (float)PS;
+    vec[6] = (float)p.st.ship_x[s]; vec[7] = (float)p.st.ship_y[s];
+    for (int o = lane; o < 100; o += 64) {
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; k++) acc += vec[k] * p.k1[k * 100 + o];
+      acc += p.g1[(size_t)a * 100 + o];
+      acc += p.b1[o];
+      acc = fmaxf(acc, 0.f);
+      sd1[wv][o] = acc;
+      p.d1[(size_t)s * 100 + o] = acc;
+    }
+  }
+  __syncthreads();
+  if (on && lane < 50) {
+    float acc = 0.f;
+    for (int k = 0; k < 100; k++) acc += sd1[wv][k] * p.k2[k * 50 + lane];
+    sd2[wv][lane] = fmaxf(acc + p.b2[lane], 0.f);
+  }
+  __syncthreads();
+  if (on && lane < 2) {
+    float acc = 0.f;
+    for (int k = 0; k < 50; k++) acc += sd2[wv][k] * p.k3[k * 2 + lane];
+    acc += p.b3[lane];
+    if (p.act) p.act[(size_t)s * 2 + lane] = acc;
+    const float other = __shfl_xor(acc, 1);
+    if (lane == 0 && p.iaction) p.iaction[s] = other > acc ? 1 : 0;  // np.argmax: first maximum
+  }
+}
+
+// ---- last layer: bilinear x2 + conv3x3 (8 -> 1, linear) in 4-phase low-res form + arg-max ----
+// Output (2i+a, 2j+b) = sum over the 3x3 low-res neighbourhood of (i,j) and 8 channels of
+// Weff[a][b][ty][tx][ci] * L[i+ty-1][j+tx-1][ci], L clamp-extended.  The conv's zero padding
+// differs from the clamp extension only for the 1-pixel frame of the output; those outputs
+// subtract the taps that fall outside:  T = G - sum_{outside taps} w[dy][dx][ci] * U[clamp].
+struct Up4Params {
+  const float *in;            // planar [S][8][200][200]
+  const float *weff, *wraw, *b4;
+  const uint8_t *mask;
+  unsigned long long *best;   // [S] packed (ordered value << 32) | ~index
+  float *heat;                // [S][400][400] or null
+};
+
+constexpr int U4_TH = 10, U4_TW = 50, U4_LS = PS / 2;  // low-res tile, 1 x 2 low-res px per thread
+
+// Taps of a frame output (y, x) that fall into the conv's zero padding, evaluated on the
+// clamp-extended low-res tile: sum w[dy][dx][ci] * U[clamp(y+dy)][clamp(x+dx)][ci].
+// Rare (1 % of the outputs): kept out of line and rolled so the hot path stays small.
+__device__ __forceinline__ float frame_correction(const float *tile, const float *wraw, int y, int x, int i0, int j0) {
+  constexpr int TWP = U4_TW + 2, PLANE = (U4_TH + 2) * TWP;
+  float corr = 0.f;
+#pragma unroll 1
+  for (int tap = 0; tap < 9; tap++) {
+    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+    const int uy = y + dy, ux = x + dx;
+    if (uy >= 0 && uy < PS && ux >= 0 && ux < PS) continue;
+    const int cy = min(max(uy, 0), PS - 1), cx = min(max(ux, 0), PS - 1);
+    // U[cy][cx] (bilinear x2, half-pixel): rows ya, ya+1 with weight wy on the second
+    const int ky = cy >> 1, kx = cx >> 1;
+    const int ya = (cy & 1) ? ky : ky - 1, xa = (cx & 1) ? kx : kx - 1;
+    const float wy = (cy & 1) ? 0.25f : 0.75f, wx = (cx & 1) ? 0.25f : 0.75f;
+    const float *t0 = tile + (ya - (i0 - 1)) * TWP + (xa - (j0 - 1));
+#pragma unroll 1
+    for (int ci = 0; ci < 8; ci++) {
+      const float *t = t0 + ci * PLANE;
+      const float l00 = t[0], l01 = t[1], l10 = t[TWP], l11 = t[TWP + 1];
+      const float top = l00 + (l01 - l00) * wx, bot = l10 + (l11 - l10) * wx;
+      corr += wraw[tap * 8 + ci] * (top + (bot - top) * wy);
+    }
+  }
+  return corr;
+}
+
+__device__ inline unsigned ordered_f32(float v) {
+  const unsigned u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(256) void k_upconv4(Up4Params p) {
+  constexpr int TWP = U4_TW + 2;
+  __shared__ __align__(16) float tile[8][U4_TH + 2][TWP];
+  constexpr int tiles_x = U4_LS / U4_TW, tiles_y = U4_LS / U4_TH, tiles = tiles_x * tiles_y;
+  const int s = blockIdx.x / tiles, t = blockIdx.x - s * tiles;
+  if (p.mask && !p.mask[s]) return;
+  const int i0 = (t / tiles_x) * U4_TH, j0 = (t % tiles_x) * U4_TW;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < 8 * (U4_TH + 2) * TWP; e += 256) {
+    const int c = e % TWP, r = (e / TWP) % (U4_TH + 2), ci = e / (TWP * (U4_TH + 2));
+    const int gi = min(max(i0 - 1 + r, 0), U4_LS - 1), gj = min(max(j0 - 1 + c, 0), U4_LS - 1);  // clamp extension
+    tile[ci][r][c] = p.in[(((size_t)s * 8 + ci) * U4_LS + gi) * U4_LS + gj];
+  }
+  __syncthreads();
+  constexpr int NT = U4_TH * (U4_TW / 2);
+  float bestv = -INFINITY;
+  unsigned bestk = 0xFFFFFFFFu;
+  if (tid < NT) {
+    const int tr = tid / (U4_TW / 2), tc = tid - tr * (U4_TW / 2);
+    float acc[2][4];  // [low-res px q][phase]
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+      for (int ph = 0; ph < 4; ph++) acc[q][ph] = 0.f;
+#pragma unroll
+    for (int ci = 0; ci < 8; ci++) {
+      float v[3][4];
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        const float2 lo = *reinterpret_cast<const float2 *>(&tile[ci][tr + r][2 * tc]);
+        const float2 hi = *reinterpret_cast<const float2 *>(&tile[ci][tr + r][2 * tc + 2]);
+        v[r][0] = lo.x; v[r][1] = lo.y; v[r][2] = hi.x; v[r][3] = hi.y;
+      }
+#pragma unroll
+      for (int ph = 0; ph < 4; ph++)
+#pragma unroll
+        for (int ty = 0; ty < 3; ty++)
+#pragma unroll
+          for (int tx = 0; tx < 3; tx++) {
+            const float wv = p.weff[(ph * 9 + ty * 3 + tx) * 8 + ci];
+            acc[0][ph] = __builtin_fmaf(v[ty][tx], wv, acc[0][ph]);
+            acc[1][ph] = __builtin_fmaf(v[ty][tx + 1], wv, acc[1][ph]);
+          }
+    }
+    const float bias = p.b4[0];
+    const int li = i0 + tr;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int lj = j0 + 2 * tc + q;
+#pragma unroll
+      for (int ph = 0; ph < 4; ph++) {
+        const int a = ph >> 1, b = ph & 1;
+        const int y = 2 * li + a, x = 2 * lj + b;
+        float val = acc[q][ph] + bias;
+        if (y == 0 || y == PS - 1 || x == 0 || x == PS - 1)
+          val -= frame_correction(&tile[0][0][0], p.wraw, y, x, i0, j0);
+        const unsigned k = (unsigned)(y * PS + x);
+        if (p.heat) p.heat[(size_t)s * PS * PS + k] = val;
+        if (val > bestv || (val == bestv && k < bestk)) { bestv = val; bestk = k; }
+      }
+    }
+  }
+  // wave arg-max (first maximum in C order), then one 64-bit atomicMax per wave
+  unsigned long long key = ((unsigned long long)ordered_f32(bestv) << 32) | (unsigned long long)(~bestk);
+  if (bestk == 0xFFFFFFFFu) key = 0ull;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long other = __shfl_xor(key, o);
+    key = other > key ? other : key;
+  }
+  if ((tid & 63) == 0 && key) atomicMax(&p.best[s], key);
+}
+
+__global__ void k_policy_finish(int S, const uint8_t *mask, const unsigned long long *best, int32_t *ipointer) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S || (mask && !mask[s])) return;
+  const unsigned k = ~(unsigned)(best[s] & 0xFFFFFFFFull);
+  ipointer[2 * s] = (int)(k % PS);      // unravel_index(order='F') of a C-order flat index = (x, y)
+  ipointer[2 * s + 1] = (int)(k / PS);  // qlearnIA_V2.py:218-220
+}
+
+// QlearnIA.play packing (qlearnIA_V2.py:447-454): exactly one of shoot / thrust, pointer always set
+__global__ void k_policy_actions(int S, const ofx_state st, const int32_t *iaction, const int32_t *ipointer,
+                                 const uint8_t *mask, ofx_action *out) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S || (mask && !mask[s])) return;
+  ofx_action a;
+  a.valid = st.alive[s] ? 1 : 0;  // a dead ship's action is None (ship.py:260-262)
+  a.shoot = iaction[s] == 0;
+  a.thrust = iaction[s] == 1;
+  a.px = ipointer[2 * s];
+  a.py = ipointer[2 * s + 1];
+  a._pad = 0;
+  out[s] = a;
+}
+
+// ---- workspace -----------------------------------------------------------------------
+struct PolicyWs {
+  float *prep, *p1, *p2, *p3, *p4, *g1, *d1, *u0, *up1, *up2, *up3;
+  unsigned long long *best;
+  int32_t *iaction, *ipointer;
+};
+
+static size_t al(size_t b) { return (b + 255) & ~(size_t)255; }
+
+static int policy_workspace(ofx_handle *h, PolicyWs *ws) {
+  const size_t N = h->cfg.n_arenas, S = N * h->cfg.n_ships;
+  const PrepLayout L = prep_layout();
+  const size_t sz[] = {al(4ull * L.total),          al(4ull * N * 8 * 200 * 200), al(4ull * N * 8 * 100 * 100),
+                       al(4ull * N * 8 * 50 * 50),   al(4ull * N * 5000),          al(4ull * N * 100),
+                       al(4ull * S * 100),           al(4ull * S * 625),           al(4ull * S * 2 * 50 * 50),
+                       al(4ull * S * 4 * 100 * 100), al(4ull * S * 8 * 200 * 200), al(8ull * S),
+                       al(4ull * S),                 al(8ull * S)};
+  size_t total = 0;
+  for (size_t b : sz) total += b;
+  int rc = ofx_ensure_scratch(h, total);
+  if (rc) return rc;
+  char *base = (char *)h->scratch;
+  void **dst[] = {(void **)&ws->prep, (void **)&ws->p1, (void **)&ws->p2, (void **)&ws->p3, (void **)&ws->p4,
+                  (void **)&ws->g1,   (void **)&ws->d1, (void **)&ws->u0, (void **)&ws->up1, (void **)&ws->up2,
+                  (void **)&ws->up3,  (void **)&ws->best, (void **)&ws->iaction, (void **)&ws->ipointer};
+  for (int i = 0; i < 14; i++) { *dst[i] = base; base += sz[i]; }
+  return OFX_OK;
+}
+
+template <int CIN, int COUT, int TH, int TW, int MODE, bool POOL, bool OUT_HWC>
+static int launch_conv(ofx_handle *h, ConvParams p, int images, int H) {
+  p.H = H; p.W = H;
+  p.tiles_x = H / TW;
+  p.tiles = p.tiles_x * (H / TH);
+  constexpr int NTB = ((TH / 2) * (TW / 2) + 63) / 64 * 64;
+  hipLaunchKernelGGL((k_conv<CIN, COUT, TH, TW, MODE, POOL, OUT_HWC>), dim3((unsigned)(images * p.tiles)), dim3(NTB), 0,
+                     h->stream, p);
+  OFX_HIP(hipGetLastError());
+  return OFX_OK;
+}
+
+static int launch_gemm(ofx_handle *h, const float *A, int lda, const float *B, int ldb, const float *bias, float *C,
+                       int ldc, int M, int N, int K, int relu) {
+  const int tiles = ((M + 31) / 32) * ((N + 31) / 32);
+  hipLaunchKernelGGL(k_gemm_f32, dim3((tiles + 3) / 4), dim3(256), 0, h->stream, A, lda, B, ldb, bias, C, ldc, M, N, K,
+                     relu);
+  OFX_HIP(hipGetLastError());
+  return OFX_OK;
+}
+
 extern "C" int ofx_policy_forward(ofx_handle *h, const float *weights, const uint8_t *ship_mask, float *act_values,
                                   int32_t *iaction, int32_t *ipointer, float *heatmap) {
-  (void)h; (void)weights; (void)ship_mask; (void)act_values; (void)iaction; (void)ipointer; (void)heatmap;
-  ofx_set_error("ofx_policy_forward: not built yet");
-  return OFX_ERR_INVALID;
+  if (!h || !weights) { ofx_set_error("ofx_policy_forward: null argument"); return OFX_ERR_INVALID; }
+  if (!h->spawned) { ofx_set_error("You must execute analyse_battleground first."); return OFX_ERR_STATE; }
+  const ofx_config &c = h->cfg;
+  if (c.width != PS || c.height != PS) {
+    // Input((DEFAULT_WIDTH, DEFAULT_HEIGHT, 2)) is fixed at 400x400 (qlearnIA_V2.py:125)
+    ofx_set_error("ofx_policy_forward: the pointer_model takes 400x400 maps (got %d x %d)", c.width, c.height);
+    return OFX_ERR_INVALID;
+  }
+  OFX_HIP(hipSetDevice(c.device));
+  const int N = c.n_arenas, S = N * c.n_ships;
+  PolicyWs ws;
+  int rc = policy_workspace(h, &ws);
+  if (rc) return rc;
+  int32_t off[64], cnt[64];
+  policy_layout(off, cnt);
+  const PrepLayout L = prep_layout();
+
+  // 0. observation bit maps + BN folding
+  if ((rc = ofx_launch_raster(h, OFX_MAP_BITS_LSB, nullptr, nullptr))) return rc;
+  PrepParams pp;
+  pp.w = weights; pp.prep = ws.prep;
+  for (int i = 0; i < 4; i++) {
+    pp.src_k[i] = off[6 * i]; pp.src_b[i] = off[6 * i + 1]; pp.src_g[i] = off[6 * i + 2];
+    pp.cin[i] = kTrunkCin[i]; pp.cout[i] = 8; pp.dst_w[i] = L.tw[i]; pp.dst_b[i] = L.tb[i];
+  }
+  const int t_d1 = 24, t_d2 = 26, t_o1 = 28, t_ud = 30, t_up = 32, t_u4 = 50;
+  for (int i = 0; i < 3; i++) {
+    pp.src_k[4 + i] = off[t_up + 6 * i]; pp.src_b[4 + i] = off[t_up + 6 * i + 1]; pp.src_g[4 + i] = off[t_up + 6 * i + 2];
+    pp.cin[4 + i] = kUpCin[i]; pp.cout[4 + i] = kUpCout[i]; pp.dst_w[4 + i] = L.uw[i]; pp.dst_b[4 + i] = L.ub[i];
+  }
+  pp.src_k4 = off[t_u4]; pp.src_b4 = off[t_u4 + 1];
+  pp.dst_w4eff = L.w4eff; pp.dst_w4raw = L.w4raw; pp.dst_b4 = L.b4;
+  hipLaunchKernelGGL(k_policy_prepare, dim3(1), dim3(256), 0, h->stream, pp);
+  OFX_HIP(hipGetLastError());
+
+  // 1. trunk, once per arena
+  ConvParams cp;
+  memset(&cp, 0, sizeof(cp));
+  cp.bits[0] = (const unsigned *)h->maps[OFX_MAP_BITS_LSB][0];
+  cp.bits[1] = (const unsigned *)h->maps[OFX_MAP_BITS_LSB][1];
+  cp.w = ws.prep + L.tw[0]; cp.b = ws.prep + L.tb[0]; cp.out = ws.p1;
+  if ((rc = launch_conv<2, 8, 16, 80, 1, true, false>(h, cp, N, 400))) return rc;
+  cp.in = ws.p1; cp.w = ws.prep + L.tw[1]; cp.b = ws.prep + L.tb[1]; cp.out = ws.p2;
+  if ((rc = launch_conv<8, 8, 10, 100, 0, true, false>(h, cp, N, 200))) return rc;
+  cp.in = ws.p2; cp.w = ws.prep + L.tw[2]; cp.b = ws.prep + L.tb[2]; cp.out = ws.p3;
+  if ((rc = launch_conv<8, 8, 10, 100, 0, true, false>(h, cp, N, 100))) return rc;
+  cp.in = ws.p3; cp.w = ws.prep + L.tw[3]; cp.b = ws.prep + L.tb[3]; cp.out = ws.p4;
+  if ((rc = launch_conv<8, 8, 10, 50, 0, true, true>(h, cp, N, 50))) return rc;  // (h,w,c) = Flatten order
+
+  // 2. dense1: trunk features on MFMA once per arena; head + head-1 per ship
+  const float *k1 = weights + off[t_d1];
+  if ((rc = launch_gemm(h, ws.p4, 5000, k1 + 8 * 100, 100, nullptr, ws.g1, 100, N, 100, 5000, 0))) return rc;
+  HeadParams hp;
+  hp.N = N; hp.M = c.n_ships; hp.st = h->st; hp.g1 = ws.g1;
+  hp.k1 = k1; hp.b1 = weights + off[t_d1 + 1];
+  hp.k2 = weights + off[t_d2]; hp.b2 = weights + off[t_d2 + 1];
+  hp.k3 = weights + off[t_o1]; hp.b3 = weights + off[t_o1 + 1];
+  hp.mask = ship_mask; hp.d1 = ws.d1; hp.act = act_values; hp.iaction = iaction ? iaction : ws.iaction;
+  hipLaunchKernelGGL(k_head_dense, dim3((S + 3) / 4), dim3(256), 0, h->stream, hp);
+  OFX_HIP(hipGetLastError());
+
+  // 3. head-2: updense1 on MFMA, then the up-convolutions per ship
+  if ((rc = launch_gemm(h, ws.d1, 100, weights + off[t_ud], 625, weights + off[t_ud + 1], ws.u0, 625, S, 625, 100, 1)))
+    return rc;
+  ConvParams up;
+  memset(&up, 0, sizeof(up));
+  up.mask = ship_mask;
+  up.in = ws.u0; up.w = ws.prep + L.uw[0]; up.b = ws.prep + L.ub[0]; up.out = ws.up1;
+  if ((rc = launch_conv<1, 2, 10, 50, 2, false, false>(h, up, S, 50))) return rc;
+  up.in = ws.up1; up.w = ws.prep + L.uw[1]; up.b = ws.prep + L.ub[1]; up.out = ws.up2;
+  if ((rc = launch_conv<2, 4, 10, 100, 2, false, false>(h, up, S, 100))) return rc;
+  up.in = ws.up2; up.w = ws.prep + L.uw[2]; up.b = ws.prep + L.ub[2]; up.out = ws.up3;
+  if ((rc = launch_conv<4, 8, 10, 100, 2, false, false>(h, up, S, 200))) return rc;
+
+  OFX_HIP(hipMemsetAsync(ws.best, 0, sizeof(unsigned long long) * S, h->stream));
+  Up4Params u4;
+  u4.in = ws.up3; u4.weff = ws.prep + L.w4eff; u4.wraw = ws.prep + L.w4raw; u4.b4 = ws.prep + L.b4;
+  u4.mask = ship_mask; u4.best = ws.best; u4.heat = heatmap;
+  constexpr int tiles4 = (U4_LS / U4_TW) * (U4_LS / U4_TH);
+  hipLaunchKernelGGL(k_upconv4, dim3((unsigned)(S * tiles4)), dim3(256), 0, h->stream, u4);
+  OFX_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_policy_finish, dim3((S + 255) / 256), dim3(256), 0, h->stream, S, ship_mask, ws.best,
+                     ipointer ? ipointer : ws.ipointer);
+  OFX_HIP(hipGetLastError());
+  return OFX_OK;
 }
+
 extern "C" int ofx_policy_actions(ofx_handle *h, const int32_t *iaction, const int32_t *ipointer,
                                   const uint8_t *ship_mask, ofx_action *actions) {
-  (void)h; (void)iaction; (void)ipointer; (void)ship_mask; (void)actions;
-  ofx_set_error("ofx_policy_actions: not built yet");
-  return OFX_ERR_INVALID;
+  if (!h || !actions) { ofx_set_error("ofx_policy_actions: null argument"); return OFX_ERR_INVALID; }
+  if (!h->spawned) { ofx_set_error("ofx_policy_actions before ofx_spawn"); return OFX_ERR_STATE; }
+  OFX_HIP(hipSetDevice(h->cfg.device));
+  const int S = h->cfg.n_arenas * h->cfg.n_ships;
+  if (!iaction || !ipointer) {  // use the results the last ofx_policy_forward kept in the workspace
+    PolicyWs ws;
+    int rc = policy_workspace(h, &ws);
+    if (rc) return rc;
+    if (!iaction) iaction = ws.iaction;
+    if (!ipointer) ipointer = ws.ipointer;
+  }
+  hipLaunchKernelGGL(k_policy_actions, dim3((S + 255) / 256), dim3(256), 0, h->stream, S, h->st, iaction, ipointer,
+                     ship_mask, actions);
+  OFX_HIP(hipGetLastError());
+  return OFX_OK;
 }

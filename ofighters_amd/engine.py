@@ -248,3 +248,43 @@ class ArenaBatch:
         ms = C.c_float(0)
         nat.check(nat.lib().ofx_event_elapsed(self._h, a, b, C.byref(ms)))
         return ms.value
+
+    # ------------------------------------------------------------------ policy
+    def policy_layout(self):
+        d = nat.OfxPolicyDesc()
+        nat.check(nat.lib().ofx_policy_layout(self._h, C.byref(d)))
+        n = d.n_tensors
+        return list(d.offset[:n]), list(d.count[:n]), d.n_floats
+
+    def policy_forward(self, weights_ptr, ship_mask_ptr=None, act_ptr=None, iaction_ptr=None, ipointer_ptr=None,
+                       heat_ptr=None):
+        """Bi-head forward for every (arena, ship) on the CURRENT state (device pointers;
+        None outputs stay inside the handle's workspace for policy_actions)."""
+        nat.check(nat.lib().ofx_policy_forward(self._h, weights_ptr, ship_mask_ptr, act_ptr, iaction_ptr,
+                                               ipointer_ptr, heat_ptr))
+
+    def policy_actions(self, out_ptr=None, iaction_ptr=None, ipointer_ptr=None, ship_mask_ptr=None):
+        """QlearnIA.play packing of the last forward into [N][M] ofx_action."""
+        out_ptr = out_ptr or self._actions.ptr
+        nat.check(nat.lib().ofx_policy_actions(self._h, iaction_ptr, ipointer_ptr, ship_mask_ptr, out_ptr))
+        return out_ptr
+
+    def policy_forward_host(self, weights, ship_mask=None, want_heat=False):
+        """Convenience for tests / the facade: numpy in, numpy out."""
+        S = self.N * self.M
+        w = np.ascontiguousarray(weights, np.float32)
+        dw = DeviceBuffer(w.nbytes).upload(w)
+        dm = None
+        if ship_mask is not None:
+            m = np.ascontiguousarray(ship_mask, np.uint8).reshape(S)
+            dm = DeviceBuffer(m.nbytes).upload(m)
+        da, di, dp = DeviceBuffer(8 * S), DeviceBuffer(4 * S), DeviceBuffer(8 * S)
+        dh = DeviceBuffer(4 * S * self.W * self.H) if want_heat else None
+        self.sync()
+        self.policy_forward(dw.ptr, dm.ptr if dm else None, da.ptr, di.ptr, dp.ptr, dh.ptr if dh else None)
+        self.sync()
+        out = dict(act=da.download(np.float32, (self.N, self.M, 2)), iaction=di.download(np.int32, (self.N, self.M)),
+                   ipointer=dp.download(np.int32, (self.N, self.M, 2)))
+        if want_heat:
+            out["heat"] = dh.download(np.float32, (self.N, self.M, self.W, self.H))
+        return out

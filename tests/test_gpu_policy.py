@@ -1,0 +1,96 @@
+"""GPU bi-head policy forward vs the CPU restatement (oracle/policy_oracle.c).
+fp32 with a different summation order (BN folded, MFMA dense, 4-phase last
+conv): tolerance 2e-4 relative to the tensor's max magnitude, written here.
+Parity with Keras itself is UNPINNED (no keras/tensorflow/weights available)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-4
+
+
+def _rollout(N, M, seed, ticks):
+    from ofighters_amd import ArenaBatch
+    b = ArenaBatch(N, M)
+    b.spawn_random(seed)
+    for t in range(ticks):
+        b.bot_actions(["turret"] * (M // 2) + ["random"] * (M - M // 2), seed, tick=t)
+        b.step(actions_ptr=b._actions.ptr)
+    return b
+
+
+@pytest.mark.parametrize("trained", [False, True])
+def test_policy_forward_vs_oracle(trained):
+    from ofighters_amd import _native as nat
+    from oracle import pyoracle
+    N, M = 3, 3
+    b = _rollout(N, M, seed=12, ticks=35)
+    w, _ = pyoracle.policy_init(3, trained_like=trained)
+    off, cnt, total = b.policy_layout()
+    ooff, ocnt, ototal = pyoracle.policy_layout()
+    assert total == ototal == len(w) and off == list(ooff) and cnt == list(ocnt)
+    out = b.policy_forward_host(w, want_heat=True)
+    head, _ = b.observe_head()
+    sm, lm = b.maps_host(nat.MAP_U8)
+    for g in range(N):
+        for i in range(M):
+            act, heat, ia, ip = pyoracle.policy_forward(sm[g], lm[g], head[g, i].astype(np.float32), w)
+            scale = max(1.0, float(np.abs(act).max()))
+            np.testing.assert_allclose(out["act"][g, i], act, rtol=0, atol=TOL * scale)
+            hs = float(np.abs(heat).max())
+            np.testing.assert_allclose(out["heat"][g, i], heat, rtol=0, atol=TOL * hs)
+            # frame pixels take the zero-padding correction path: check them explicitly
+            for sl in (np.s_[0, :], np.s_[399, :], np.s_[:, 0], np.s_[:, 399]):
+                np.testing.assert_allclose(out["heat"][g, i][sl], heat[sl], rtol=0, atol=TOL * hs)
+            if abs(float(act[0] - act[1])) > 2 * TOL * scale:
+                assert out["iaction"][g, i] == ia
+            gx, gy = out["ipointer"][g, i]
+            # the GPU's arg-max is the first maximum of ITS heat-map ...
+            k = int(np.argmax(out["heat"][g, i]))
+            assert (gx, gy) == (k % 400, k // 400)
+            # ... and a maximum of the oracle's up to the tolerance
+            assert heat[gy, gx] >= heat.max() - 2 * TOL * hs
+    b.close()
+
+
+def test_policy_mask_and_actions():
+    """ship_mask selects the policy ships (reference default: one QlearnIA ship per
+    arena, lib/ofighters.py:53); QlearnIA.play packing: exactly one of shoot/thrust."""
+    from ofighters_amd import DeviceBuffer, _native as nat
+    from oracle import pyoracle
+    N, M = 4, 4
+    b = _rollout(N, M, seed=5, ticks=20)
+    w, _ = pyoracle.policy_init(9, trained_like=True)
+    mask = np.zeros((N, M), np.uint8)
+    mask[:, 1] = 1
+    full = b.policy_forward_host(w)
+    part = b.policy_forward_host(w, ship_mask=mask)
+    assert np.array_equal(part["ipointer"][:, 1], full["ipointer"][:, 1])
+    assert np.array_equal(part["iaction"][:, 1], full["iaction"][:, 1])
+    np.testing.assert_array_equal(part["act"][:, 1], full["act"][:, 1])
+    # action packing from the workspace results of a full forward
+    dw = DeviceBuffer(w.nbytes).upload(w)
+    b.policy_forward(dw.ptr)
+    b.policy_actions()
+    acts = b.actions_host()
+    alive = b.get(nat.F_SHIP_ALIVE)
+    assert np.array_equal(acts["valid"], alive)
+    assert np.all(acts["shoot"] + acts["thrust"] == 1)
+    assert np.array_equal(acts["shoot"], (full["iaction"] == 0).astype(np.uint8))
+    assert np.array_equal(acts["px"], full["ipointer"][..., 0]) and np.array_equal(acts["py"], full["ipointer"][..., 1])
+    b.step(actions_ptr=b._actions.ptr)      # the packed actions drive a tick
+    b.close()
+
+
+def test_policy_determinism_and_trunk_sharing():
+    """Two runs give identical bits; ships of one arena differ only through their
+    8-scalar head (the trunk is computed once per arena)."""
+    from oracle import pyoracle
+    b = _rollout(2, 8, seed=3, ticks=25)
+    w, _ = pyoracle.policy_init(4, trained_like=True)
+    a1 = b.policy_forward_host(w)
+    a2 = b.policy_forward_host(w)
+    for k in a1:
+        assert np.array_equal(a1[k], a2[k])
+    b.close()
