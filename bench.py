@@ -25,6 +25,53 @@ SEED = 0x0F160001
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+def synth_policy_weights(b, seed):
+    """he_uniform convs, glorot_uniform dense, zero bias, BN gamma=1 beta=0 mean=0 var=1: the state of
+    the reference's model right after construction (agents/qlearnIA_V2.py:129-186)."""
+    import numpy as np
+    off, cnt, total = b.policy_layout()
+    rs = np.random.RandomState(seed & 0x7FFFFFFF)
+    w = np.zeros(total, np.float32)
+    cin = [2, 8, 8, 8]
+    t = 0
+
+    def uni(n, lim):
+        return rs.uniform(-lim, lim, n).astype(np.float32)
+    for i in range(4):
+        w[off[t]:off[t] + cnt[t]] = uni(cnt[t], np.sqrt(6.0 / (9 * cin[i])))
+        w[off[t + 2]:off[t + 2] + 8] = 1.0
+        w[off[t + 5]:off[t + 5] + 8] = 1.0
+        t += 6
+    for fi, fo in ((5008, 100), (100, 50), (50, 2), (100, 625)):
+        w[off[t]:off[t] + cnt[t]] = uni(cnt[t], np.sqrt(6.0 / (fi + fo)))
+        t += 2
+    for ci, co in ((1, 2), (2, 4), (4, 8)):
+        w[off[t]:off[t] + cnt[t]] = uni(cnt[t], np.sqrt(6.0 / (9 * ci)))
+        w[off[t + 2]:off[t + 2] + co] = 1.0
+        w[off[t + 5]:off[t + 5] + co] = 1.0
+        t += 6
+    w[off[t]:off[t] + cnt[t]] = uni(cnt[t], np.sqrt(6.0 / 72))
+    return w
+
+
+def cpu_policy_sample(pyoracle, cfg, w, n_arenas, ticks, n_pol, seed):
+    """CPU-oracle leg of the full workload: per tick and arena, n_pol policy forwards (the oracle has no
+    trunk sharing: one full forward per ship, like the reference), step, rasterise."""
+    import numpy as np
+    M = cfg.n_ships
+    for g in range(n_arenas):
+        a = pyoracle.Arena(cfg=cfg)
+        a.spawn(pyoracle.reset_draws(cfg, seed, g, 0))
+        for t in range(ticks):
+            sm, lm = a.rasterise()
+            head, _ = a.obs_head()
+            act = a.bot_actions(np.ones(M, np.int32), seed, g, t)
+            for i in range(n_pol):
+                _, _, ia, ip = pyoracle.policy_forward(sm, lm, head[i].astype(np.float32), w, want_heat=False)
+                act[i, 1], act[i, 2], act[i, 3], act[i, 4] = int(ia == 0), int(ia == 1), ip[0], ip[1]
+            a.step(act)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -32,7 +79,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--arenas", type=int, default=4096, help="arenas per GPU")
     ap.add_argument("--ships", type=int, default=8)
-    ap.add_argument("--workload", default="step+obs", choices=["step", "step+obs"])
+    ap.add_argument("--workload", default="step+obs+policy", choices=["step", "step+obs", "step+obs+policy"])
+    ap.add_argument("--policy-ships", type=int, default=-1, help="ships per arena driven by the bi-head policy (-1 = all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -58,6 +106,18 @@ def main():
     beh = ["random"] * M
     ep_ticks = b.cfg.episode_ticks
     do_obs = args.workload != "step"
+    do_policy = args.workload == "step+obs+policy"
+    n_pol = M if args.policy_ships < 0 else min(M, args.policy_ships)
+    if do_policy:
+        # synthetic he_uniform / glorot_uniform weights of the pointer_model architecture (no checkpoint
+        # ships with the reference); seed 0x0F160002
+        w_host = synth_policy_weights(b, 0x0F160002)
+        w_dev = torch.from_numpy(w_host).cuda()
+        mask_dev = None
+        if n_pol < M:
+            mk = np.zeros((N, M), np.uint8)
+            mk[:, :n_pol] = 1
+            mask_dev = torch.from_numpy(mk).cuda()
     scores = torch.zeros(M + 1, dtype=torch.int64, device="cuda")
     torch.cuda.synchronize()  # the handle's stream is non-blocking w.r.t. torch's
     score_log = []
@@ -81,6 +141,15 @@ def main():
         if t > 0 and t % ep_ticks == 0:
             episode_end()
         b.bot_actions(beh, SEED, tick=t)
+        if do_policy:
+            # request_actions: the policy ships' actions overwrite the scripted ones
+            if timed:
+                b.event_record(EV[0])
+            b.policy_forward(w_dev.data_ptr(), mask_dev.data_ptr() if mask_dev is not None else None)
+            if timed:
+                b.event_record(EV[0] + 1)
+                EV[0] += 2
+            b.policy_actions(ship_mask_ptr=mask_dev.data_ptr() if mask_dev is not None else None)
         if timed and not do_obs:
             b.event_record(EV[0])
         b.step(actions_ptr=b._actions.ptr)
@@ -88,10 +157,10 @@ def main():
             b.event_record(EV[0] + 1)
             EV[0] += 2
         if do_obs:
-            if timed:
+            if timed and not do_policy:
                 b.event_record(EV[0])
             b.rasterise(nat.MAP_U8)
-            if timed:
+            if timed and not do_policy:
                 b.event_record(EV[0] + 1)
                 EV[0] += 2
         tick[0] = t + 1
@@ -121,13 +190,25 @@ def main():
     k_ms = [b.event_elapsed(2 * i, 2 * i + 1) for i in range(min(n_ev, 32000))]
     k_avg_ms = float(np.mean(k_ms)) if k_ms else float("nan")
     overflow = b.overflow_count()
-    if do_obs:
+    roof_unit, roof_peak, roof_bound, roof_note = "GB/s", HBM_PEAK_GBS, "hbm", None
+    if do_policy:
+        # dense algorithmic FLOPs, no sparsity credit: trunk 53.28 MMAC once per arena +
+        # 24.37 MMAC per policy ship
+        kernel = "ofx_policy_forward (12 launches; conv kernels dominate)"
+        alg_flops = N * 2.0 * (53.28e6 + n_pol * 24.37e6)
+        achieved = alg_flops / (k_avg_ms * 1e-3) / 1e12
+        roof_unit, roof_peak, roof_bound = "TFLOP/s", 157.3, "mfma"
+        roof_note = ("fp32: the direct convolutions (99% of the FLOPs) run on the fp32 VALU whose peak equals the "
+                     "f32-input MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md); only the dense layers use MFMA")
+        alg_bytes = None
+    elif do_obs:
         kernel = "k_raster<u8>"
         alg_bytes = N * 2 * b.W * b.H * 1          # two u8 maps written per arena (SURVEY 8d cfg 3)
     else:
         kernel = "k_step"
         alg_bytes = N * 3200                        # SURVEY 8d cfg 2: ~3.2 KB per arena-step
-    achieved = alg_bytes / (k_avg_ms * 1e-3) / 1e9
+    if not do_policy:
+        achieved = alg_bytes / (k_avg_ms * 1e-3) / 1e9
 
     out = {
         "metric": "arena-steps/sec (env.step+obs+policy fwd) at 4096 arenas, 1/2/4/8 MI355X",
@@ -140,22 +221,27 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f64",
+        "dtype": "f32" if do_policy else "f64",
         "data": "synthetic",
         "config": {
             "workload": ("%d arenas x %d ships per GPU, random-bot actions + step" % (N, M))
                         + (" + 2D obs rasterise (u8 maps)" if do_obs else "")
-                        + "; policy forward not yet in the timed region (BASELINE configs[2], not [3])",
+                        + ((" + bi-head policy forward for %d ship(s)/arena, trunk shared per arena (BASELINE configs[3])"
+                            % n_pol) if do_policy else "; no policy forward (BASELINE configs[%d])" % (2 if do_obs else 1)),
             "arenas_per_gpu": N, "ships": M, "laser_cap": b.L, "episode_ticks": ep_ticks,
             "parallelism": "arena-sharded x%d, RCCL all-reduce of episodic scores only" % world,
             "laser_overflow": overflow,
         },
         "roofline": {
-            "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-            "avg_kernel_ms": k_avg_ms, "algorithmic_bytes_per_launch": alg_bytes,
+            "bound": roof_bound, "kernel": kernel, "achieved": achieved, "peak": roof_peak, "unit": roof_unit,
+            "frac": achieved / roof_peak, "traffic": None,
+            "avg_kernel_ms": k_avg_ms,
+            ("algorithmic_flops_per_launch" if do_policy else "algorithmic_bytes_per_launch"):
+                (alg_flops if do_policy else alg_bytes),
         },
     }
+    if roof_note:
+        out["roofline"]["note"] = roof_note
     if score_log:
         out["config"]["last_episode_score_sum"] = int(score_log[-1][:M].sum().item())
         out["config"]["last_episode_arenas"] = int(score_log[-1][M].item())
@@ -164,10 +250,17 @@ def main():
         # CPU oracle (a port, 1 thread) on a bounded sample of the same workload
         from oracle import pyoracle
         cfg = pyoracle.default_cfg(M)
-        n_s, t_s = (1024, 200) if do_obs else (4096, 200)
-        c0 = time.perf_counter()
-        pyoracle.run_random(cfg, n_s, t_s, SEED, int(do_obs), ep_ticks)
-        cdt = time.perf_counter() - c0
+        if do_policy:
+            # one policy forward costs ~0.3 s on one core: sample = a few arena-steps of the full workload
+            n_s, t_s = 2, 3
+            c0 = time.perf_counter()
+            cpu_policy_sample(pyoracle, cfg, w_host, n_s, t_s, n_pol, SEED)
+            cdt = time.perf_counter() - c0
+        else:
+            n_s, t_s = (1024, 200) if do_obs else (4096, 200)
+            c0 = time.perf_counter()
+            pyoracle.run_random(cfg, n_s, t_s, SEED, int(do_obs), ep_ticks)
+            cdt = time.perf_counter() - c0
         out["cpu_baseline"] = {
             "value": n_s * t_s / cdt, "unit": "arena-steps/s", "cores": 1, "kind": "port",
             "sample": "%d arenas x %d ticks of the same workload (C oracle, single thread)" % (n_s, t_s),

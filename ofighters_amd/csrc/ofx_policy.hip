@@ -21,6 +21,7 @@
 // x all output channels per thread, weights as wave-uniform scalar operands
 // (s_load + v_fma with an SGPR source).  BatchNorm is folded into the conv
 // weights by k_policy_prepare.
+#include <stdlib.h>
 #include <string.h>
 
 #include "ofx_internal.h"
@@ -60,7 +61,10 @@ extern "C" int ofx_policy_layout(const ofx_handle *h, ofx_policy_desc *desc) {
 struct PrepLayout {
   int tw[4], tb[4];   // trunk folded kernels [9][cin][8], biases [8]
   int uw[3], ub[3];   // upconv1..3 folded
-  int w4eff;          // [4 phases][9 low-res taps][8 ci]
+  int w3eff;          // [4 ci][4 phases][9 low-res taps][8 co]  (BN folded; VALU variant)
+  int w3mf;           // [half 2][k = tap*4 + ci (36)][n = phase*4 + co_local (16)]  MFMA B operand
+  int w4eff;          // [4 phases][9 low-res taps][8 ci] (v1 kernel)
+  int w4eff_c;        // [8 ci][4 phases][9 taps] (fused kernel: one contiguous slice per input channel)
   int w4raw;          // [9][8]
   int b4;             // [1]
   int total;
@@ -71,7 +75,10 @@ static PrepLayout prep_layout() {
   int off = 0;
   for (int i = 0; i < 4; i++) { L.tw[i] = off; off += 9 * kTrunkCin[i] * 8; L.tb[i] = off; off += 8; }
   for (int i = 0; i < 3; i++) { L.uw[i] = off; off += 9 * kUpCin[i] * kUpCout[i]; L.ub[i] = off; off += kUpCout[i]; }
+  L.w3eff = off; off += 4 * 9 * 4 * 8;
+  L.w3mf = off; off += 36 * 32;
   L.w4eff = off; off += 4 * 9 * 8;
+  L.w4eff_c = off; off += 8 * 4 * 9;
   L.w4raw = off; off += 72;
   L.b4 = off; off += 1;
   L.total = (off + 63) & ~63;
@@ -83,6 +90,7 @@ struct PrepParams {
   float *prep;
   int src_k[7], src_b[7], src_g[7], cin[7], cout[7], dst_w[7], dst_b[7];
   int src_k4, src_b4, dst_w4eff, dst_w4raw, dst_b4;
+  int dst_w3eff, dst_w4eff_c, dst_w3mf;
 };
 
 // interpolation coefficients of the x2 half-pixel bilinear: output row 2i+a, conv
@@ -119,8 +127,26 @@ __global__ void k_policy_prepare(PrepParams p) {
       for (int dx = 0; dx < 3; dx++)
         acc += p.w[p.src_k4 + (dy * 3 + dx) * 8 + ci] * (up_coef(a, dy, ty) * up_coef(b, dx, tx));
     p.prep[p.dst_w4eff + e] = acc;
+    p.prep[p.dst_w4eff_c + (ci * 4 + ph) * 9 + tap] = acc;
   }
   for (int e = tid; e < 72; e += blockDim.x) p.prep[p.dst_w4raw + e] = p.w[p.src_k4 + e];
+  // upconv3 (layer index 6): phase weights from the BN-folded kernel (folded in place, same thread order
+  // would race with the fold above: recompute the fold here)
+  {
+    const int cout = 8, cin = 4;
+    const float *g = p.w + p.src_g[6];
+    for (int e = tid; e < 4 * 9 * cin * cout; e += blockDim.x) {
+      const int co = e % cout, ci = (e / cout) % cin, tap = (e / (cout * cin)) % 9, ph = e / (cout * cin * 9);
+      const int a = ph >> 1, b = ph & 1, ty = tap / 3, tx = tap % 3;
+      const float inv = g[co] / sqrtf(g[3 * cout + co] + 1e-3f);
+      float acc = 0.f;
+      for (int dy = 0; dy < 3; dy++)
+        for (int dx = 0; dx < 3; dx++)
+          acc += (p.w[p.src_k[6] + ((dy * 3 + dx) * cin + ci) * cout + co] * inv) * (up_coef(a, dy, ty) * up_coef(b, dx, tx));
+      p.prep[p.dst_w3eff + ((ci * 4 + ph) * 9 + tap) * cout + co] = acc;
+      p.prep[p.dst_w3mf + ((co >> 2) * 36 + tap * 4 + ci) * 16 + ph * 4 + (co & 3)] = acc;
+    }
+  }
   if (tid == 0) p.prep[p.dst_b4] = p.w[p.src_b4];
 }
 
@@ -148,31 +174,46 @@ __global__ __launch_bounds__(((TH / 2) * (TW / 2) + 63) / 64 * 64) void k_conv(C
   const int tid = threadIdx.x;
   const int H = p.H, W = p.W;
 
-  // ---- stage the (TH+2) x (TW+2) x CIN input patch (zero outside the image: padding 'same') ----
-  for (int e = tid; e < CIN * (TH + 2) * TWP; e += NTB) {
-    const int c = e % TWP, r = (e / TWP) % (TH + 2), ci = e / (TWP * (TH + 2));
-    const int gy = ty0 - 1 + r, gx = tx0 - 1 + c;
-    float v = 0.f;
-    if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-      if (MODE == 0) {
-        v = p.in[(((size_t)img * CIN + ci) * H + gy) * W + gx];
-      } else if (MODE == 1) {
-        const int cell = gy * W + gx;
-        v = (float)((p.bits[ci][(size_t)img * ((PS * PS) >> 5) + (cell >> 5)] >> (cell & 31)) & 1u);
-      } else {
-        const int Hs = H >> 1, Ws = W >> 1;
-        const float sy = ((float)gy + 0.5f) * 0.5f - 0.5f, sx = ((float)gx + 0.5f) * 0.5f - 0.5f;
-        const float fy = floorf(sy), fx = floorf(sx);
-        const float ly = sy - fy, lx = sx - fx;
-        int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1, x1 = x0 + 1;
-        y0 = max(y0, 0); x0 = max(x0, 0); y1 = min(y1, Hs - 1); x1 = min(x1, Ws - 1);
-        const float *s = p.in + ((size_t)img * CIN + ci) * Hs * Ws;
-        const float a = s[y0 * Ws + x0], b = s[y0 * Ws + x1], d = s[y1 * Ws + x0], g = s[y1 * Ws + x1];
-        const float top = a + (b - a) * lx, bot = d + (g - d) * lx;
-        v = top + (bot - top) * ly;
+  // ---- stage the (TH+2) x (TW+2) x CIN input patch (zero outside the image: padding 'same').
+  // Loads are issued in batches of SU before any LDS store so one memory latency covers SU elements.
+  constexpr int TOTAL = CIN * (TH + 2) * TWP;
+  constexpr int SU = (MODE == 2) ? 4 : 8;
+  for (int base = 0; base < TOTAL; base += NTB * SU) {
+    float vals[SU];
+#pragma unroll
+    for (int u = 0; u < SU; u++) {
+      const int e = base + u * NTB + tid;
+      float v = 0.f;
+      if (e < TOTAL) {
+        const int c = e % TWP, r = (e / TWP) % (TH + 2), ci = e / (TWP * (TH + 2));
+        const int gy = ty0 - 1 + r, gx = tx0 - 1 + c;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+          if (MODE == 0) {
+            v = p.in[(((size_t)img * CIN + ci) * H + gy) * W + gx];
+          } else if (MODE == 1) {
+            const int cell = gy * W + gx;
+            v = (float)((p.bits[ci][(size_t)img * ((PS * PS) >> 5) + (cell >> 5)] >> (cell & 31)) & 1u);
+          } else {
+            const int Hs = H >> 1, Ws = W >> 1;
+            const float sy = ((float)gy + 0.5f) * 0.5f - 0.5f, sx = ((float)gx + 0.5f) * 0.5f - 0.5f;
+            const float fy = floorf(sy), fx = floorf(sx);
+            const float ly = sy - fy, lx = sx - fx;
+            int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1, x1 = x0 + 1;
+            y0 = max(y0, 0); x0 = max(x0, 0); y1 = min(y1, Hs - 1); x1 = min(x1, Ws - 1);
+            const float *sp = p.in + ((size_t)img * CIN + ci) * Hs * Ws;
+            const float a = sp[y0 * Ws + x0], b = sp[y0 * Ws + x1], d = sp[y1 * Ws + x0], g = sp[y1 * Ws + x1];
+            const float top = a + (b - a) * lx, bot = d + (g - d) * lx;
+            v = top + (bot - top) * ly;
+          }
+        }
       }
+      vals[u] = v;
     }
-    tile[ci][r][c] = v;
+#pragma unroll
+    for (int u = 0; u < SU; u++) {
+      const int e = base + u * NTB + tid;
+      if (e < TOTAL) (&tile[0][0][0])[e] = vals[u];
+    }
   }
   __syncthreads();
   if (tid >= NT) return;
@@ -444,6 +485,273 @@ __global__ __launch_bounds__(256) void k_upconv4(Up4Params p) {
   if ((tid & 63) == 0 && key) atomicMax(&p.best[s], key);
 }
 
+// ---- fused head tail: [bilinear x2 + conv 4->8 + BN + ReLU] -> [bilinear x2 + conv 8->1] -> arg-max ----
+// One workgroup per (ship, 40x40 tile of the 200x200 uprelu3 plane).  Both layers run in the 4-phase
+// low-resolution form (a x2 bilinear upsample followed by a 3x3 conv is, per output parity, a 3x3 conv on the
+// low-res grid with pre-combined weights), so no upsampled tensor is ever formed, and the 42 GB uprelu3 tensor
+// (N=4096, M=8) with its 84 GB of HBM traffic never exists: it lives as a 42x42 LDS tile, 4 channels at a time.
+//   stage A   24x24x4 clamp-extended patch of uprelu2 (100x100x4) -> LDS
+//   stage B   uprelu3 on the MATRIX CORES: in phase form the layer is a GEMM out[quad][ph*4+co] =
+//             sum_k in[quad][k] W[k][ph*4+co] with k = (tap, ci), K = 36 and a natural N = 4 phases x 4
+//             channels = 16 per half: v_mfma_f32_16x16x4_f32 (exact fp32, an fma chain in k order), A gathered
+//             from the LDS patch (one ds_read_b32 per lane per MFMA), B in 9 VGPRs per half.
+//   stage C   heat-map quads on the VALU: each thread owns 2x4 uprelu3 pixels = 8 quads of the 400x400 map;
+//             the 36 phase weights of a channel are broadcast LDS reads into VGPRs (an SGPR operand halves the
+//             FMA rate on gfx950: 75 vs 115 TFLOP/s measured, tools/ubench_fma.hip), each feeds 8 FMAs.
+//   The two channel halves run B(0) C(0) B(1) C(1) with the stage-C accumulators kept in registers, which
+//   halves the LDS tile (30 KB) so three workgroups share a CU; the matrix pipe is separate from the VALU, so
+//   one workgroup's stage B overlaps another's stage C.
+//   Frame outputs (first/last row/column of either layer) are the only place where the conv's zero padding
+//   differs from the clamp-extended phase form: border tiles recompute those cells from the definition
+//   (upsample, then conv with zero padding) in a small rolled pass.
+struct HeadTailParams {
+  const float *up2;            // planar [S][4][100][100]
+  const float *w3mf;           // [half 2][k = tap*4 + ci (36)][n = phase*4 + co_local (16)]  MFMA B operand
+  const float *w3raw, *b3;     // BN-folded [9][4][8], folded bias [8]
+  const float *w4eff;          // [ci 8][phase 4][tap 9]
+  const float *w4raw, *b4;     // [9][8], [1]
+  const uint8_t *mask;
+  unsigned long long *best;
+  float *heat;
+};
+
+constexpr int HT_T = 40;              // uprelu3 tile side
+constexpr int HT_Q = HT_T / 2 + 2;    // quads per side (22)
+constexpr int HT_NQ = HT_Q * HT_Q;    // 484
+constexpr int HT_MT = (HT_NQ + 15) / 16;  // 16-quad M-tiles (31)
+constexpr int HT_L2 = HT_T / 2 + 4;   // uprelu2 patch side (24)
+constexpr int HT_U3 = HT_T + 2;       // uprelu3 tile side incl. halo (42)
+constexpr int HT_U3P = HT_U3 + 2;     // row stride (even -> 8-byte aligned pair reads)
+constexpr int HT_S2 = 100, HT_S3 = 200;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// bilinear x2 (half-pixel) sample at up-res (uy, ux) of a clamp-extended low-res LDS plane whose element
+// [0][0] has low-res coordinates (o_r, o_c)
+__device__ __forceinline__ float up2d(const float *plane, int stride, int o_r, int o_c, int uy, int ux) {
+  const int ya = (uy & 1) ? (uy >> 1) : (uy >> 1) - 1, xa = (ux & 1) ? (ux >> 1) : (ux >> 1) - 1;
+  const float wy = (uy & 1) ? 0.25f : 0.75f, wx = (ux & 1) ? 0.25f : 0.75f;
+  const float *q = plane + (ya - o_r) * stride + (xa - o_c);
+  const float l00 = q[0], l01 = q[1], l10 = q[stride], l11 = q[stride + 1];
+  const float top = l00 + (l01 - l00) * wx, bot = l10 + (l11 - l10) * wx;
+  return top + (bot - top) * wy;
+}
+
+__global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
+  __shared__ __align__(16) float l2[4][HT_L2][HT_L2];
+  __shared__ __align__(16) float u3[4][HT_U3][HT_U3P];
+  __shared__ __align__(16) float w4s[8][36];
+  __shared__ float facc[2 * 2 * HT_T];              // frame-pixel sums of the heat-map (border tiles)
+  __shared__ __align__(8) unsigned short otab[512]; // quad -> (2qi-1)*U3P + (2qj-1) + 64, edge flags in bits 12-15
+  __shared__ unsigned short atab[512];              // quad -> qi*L2 + qj (A-operand gather base)
+  constexpr int tiles_x = HT_S3 / HT_T, tiles = tiles_x * tiles_x;
+  const int s = blockIdx.x / tiles, t = blockIdx.x - s * tiles;
+  if (p.mask && !p.mask[s]) return;  // block-uniform
+  const int r0 = (t / tiles_x) * HT_T, c0 = (t % tiles_x) * HT_T;  // uprelu3 coords of the tile
+  const int ib = r0 / 2 - 2, jb = c0 / 2 - 2;                      // uprelu2 coords of l2[.][0][0]
+  const bool top = r0 == 0, bot = r0 + HT_T == HT_S3, lef = c0 == 0, rig = c0 + HT_T == HT_S3;
+  const bool border = top || bot || lef || rig;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+
+  // ---- stage A: patch + tables + stage-C weights; all global loads in flight before the first LDS store ----
+  {
+    constexpr int TOTAL = 4 * HT_L2 * HT_L2;  // 2304 = 9 x 256
+    float vals[TOTAL / 256];
+#pragma unroll
+    for (int u = 0; u < TOTAL / 256; u++) {
+      const int e = u * 256 + tid;
+      const int c = e % HT_L2, r = (e / HT_L2) % HT_L2, ci = e / (HT_L2 * HT_L2);
+      const int gi = min(max(ib + r, 0), HT_S2 - 1), gj = min(max(jb + c, 0), HT_S2 - 1);
+      vals[u] = p.up2[(((size_t)s * 4 + ci) * HT_S2 + gi) * HT_S2 + gj];
+    }
+    const float wa = p.w4eff[tid], wb = tid < 32 ? p.w4eff[256 + tid] : 0.f;
+#pragma unroll
+    for (int u = 0; u < TOTAL / 256; u++) (&l2[0][0][0])[u * 256 + tid] = vals[u];
+    (&w4s[0][0])[tid] = wa;
+    if (tid < 32) (&w4s[0][0])[256 + tid] = wb;
+    for (int m = tid; m < 512; m += 256) {
+      const int mq = min(m, HT_NQ - 1), qi = mq / HT_Q, qj = mq - qi * HT_Q;
+      unsigned f = (qi == 0 ? 1u : 0u) | (qi == HT_Q - 1 ? 2u : 0u) | (qj == 0 ? 4u : 0u) | (qj == HT_Q - 1 ? 8u : 0u);
+      if (m >= HT_NQ) f = 15u;
+      otab[m] = (unsigned short)(((2 * qi - 1) * HT_U3P + (2 * qj - 1) + 64) | (f << 12));
+      atab[m] = (unsigned short)(qi * HT_L2 + qj);
+    }
+  }
+  __syncthreads();
+
+  // per-lane constants of the MFMA stage: n = lane & 15 -> (phase, local channel); kq = lane >> 4 -> input channel
+  const int n16 = lane & 15, kq = lane >> 4;
+  const int ph3 = n16 >> 2, cl3 = n16 & 3, pa3 = ph3 >> 1, pb3 = ph3 & 1;
+  const unsigned badmask = ((pa3 ? 2u : 1u) | (pb3 ? 8u : 4u)) << 12;  // cell of this phase falls outside the tile
+  const int cell_off = cl3 * HT_U3 * HT_U3P + pa3 * HT_U3P + pb3 - 64;
+
+  // stage-C ownership: 2 x 4 uprelu3 pixels per thread (200 of 256 threads)
+  const bool cthread = tid < (HT_T / 2) * (HT_T / 4);
+  const int tr = 2 * (tid / (HT_T / 4)), tc = 4 * (tid % (HT_T / 4));
+  float acc[2][4][4];  // [row][col][phase]
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int ph = 0; ph < 4; ph++) acc[i][j][ph] = 0.f;
+  if (border && tid < 2 * 2 * HT_T) facc[tid] = 0.f;
+
+#pragma unroll 1
+  for (int half = 0; half < 2; half++) {
+    // ---- stage B: 4 channels of the uprelu3 tile ----
+    {
+      float bw[9];
+#pragma unroll
+      for (int j = 0; j < 9; j++) bw[j] = p.w3mf[(half * 36 + 4 * j + kq) * 16 + n16];
+      const float bias3 = p.b3[4 * half + cl3];
+      float *ubase = &u3[0][0][0] + cell_off;
+#pragma unroll 1
+      for (int mt = wv; mt < HT_MT; mt += 4) {
+        const int m0 = mt * 16;
+        const float *abase = &l2[kq][0][0] + atab[m0 + n16];  // A row = quad m0 + (lane & 15), k = 4 j + kq
+        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 9; j++)  // tap j, channel kq
+          d = __builtin_amdgcn_mfma_f32_16x16x4f32(abase[(j / 3) * HT_L2 + (j % 3)], bw[j], d, 0, 0, 0);
+        // D: col = lane & 15, row = 4 (lane >> 4) + reg -> quads m0 + 4 kq .. + 3
+        const uint2 o2 = *reinterpret_cast<const uint2 *>(&otab[m0 + 4 * kq]);
+        const unsigned o[4] = {o2.x & 0xFFFFu, o2.x >> 16, o2.y & 0xFFFFu, o2.y >> 16};
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          if (!(o[i] & badmask)) ubase[o[i] & 0xFFFu] = fmaxf(d[i] + bias3, 0.f);
+      }
+    }
+    __syncthreads();
+    if (border) {
+      // frame cells of the uprelu3 plane: recompute from the definition (zero padding outside [0,200)^2)
+      for (int e = tid; e < 4 * 2 * HT_U3; e += 256) {
+        const int k = e % HT_U3, line = (e / HT_U3) & 1, cl = e / (2 * HT_U3);
+        int y, x;
+        if (line == 0) { if (!(top || bot)) continue; y = top ? 0 : HT_S3 - 1; x = c0 - 1 + k; }
+        else { if (!(lef || rig)) continue; x = lef ? 0 : HT_S3 - 1; y = r0 - 1 + k; }
+        if (y < 0 || y >= HT_S3 || x < 0 || x >= HT_S3) continue;
+        const int co = 4 * half + cl;
+        float sum = 0.f;
+#pragma unroll 1
+        for (int tap = 0; tap < 9; tap++) {
+          const int uy = y + tap / 3 - 1, ux = x + tap % 3 - 1;
+          if (uy < 0 || uy >= HT_S3 || ux < 0 || ux >= HT_S3) continue;
+#pragma unroll
+          for (int ci = 0; ci < 4; ci++)
+            sum += p.w3raw[(tap * 4 + ci) * 8 + co] * up2d(&l2[ci][0][0], HT_L2, ib, jb, uy, ux);
+        }
+        u3[cl][y - (r0 - 1)][x - (c0 - 1)] = fmaxf(sum + p.b3[co], 0.f);
+      }
+      __syncthreads();
+      // halo cells outside the image = clamp extension (their sources are inside the image)
+      for (int e = tid; e < 4 * 4 * HT_U3; e += 256) {
+        const int k = e % HT_U3, side = (e / HT_U3) & 3, cl = e / (4 * HT_U3);
+        const int ty = side == 0 ? 0 : side == 1 ? HT_U3 - 1 : k, tx = side == 2 ? 0 : side == 3 ? HT_U3 - 1 : k;
+        const int y = r0 - 1 + ty, x = c0 - 1 + tx;
+        if (y < 0 || y >= HT_S3 || x < 0 || x >= HT_S3) {
+          const int cy = min(max(y, 0), HT_S3 - 1), cx = min(max(x, 0), HT_S3 - 1);
+          u3[cl][ty][tx] = u3[cl][cy - (r0 - 1)][cx - (c0 - 1)];
+        }
+      }
+      __syncthreads();
+      // frame pixels of the heat-map: partial sums over this half's 4 channels, from the definition
+      for (int e = tid; e < 2 * 2 * HT_T; e += 256) {
+        const int k = e % (2 * HT_T), line = e / (2 * HT_T);
+        int y, x;
+        if (line == 0) { if (!(top || bot)) continue; y = top ? 0 : PS - 1; x = 2 * c0 + k; }
+        else { if (!(lef || rig)) continue; x = lef ? 0 : PS - 1; y = 2 * r0 + k; }
+        float sum = 0.f;
+#pragma unroll 1
+        for (int tap = 0; tap < 9; tap++) {
+          const int uy = y + tap / 3 - 1, ux = x + tap % 3 - 1;
+          if (uy < 0 || uy >= PS || ux < 0 || ux >= PS) continue;
+#pragma unroll
+          for (int cl = 0; cl < 4; cl++)
+            sum += p.w4raw[tap * 8 + 4 * half + cl] * up2d(&u3[cl][0][0], HT_U3P, r0 - 1, c0 - 1, uy, ux);
+        }
+        facc[e] += sum;
+      }
+    }
+
+    // ---- stage C: 4 channels of the heat-map quads ----
+    if (cthread) {
+#pragma unroll 1
+      for (int cl = 0; cl < 4; cl++) {
+        float v[4][6];
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+          for (int c2 = 0; c2 < 3; c2++) {
+            const float2 t2 = *reinterpret_cast<const float2 *>(&u3[cl][tr + r][tc + 2 * c2]);
+            v[r][2 * c2] = t2.x; v[r][2 * c2 + 1] = t2.y;
+          }
+        float wv4[36];
+#pragma unroll
+        for (int q = 0; q < 9; q++) {
+          const float4 t4 = *reinterpret_cast<const float4 *>(&w4s[4 * half + cl][4 * q]);
+          wv4[4 * q] = t4.x; wv4[4 * q + 1] = t4.y; wv4[4 * q + 2] = t4.z; wv4[4 * q + 3] = t4.w;
+        }
+#pragma unroll
+        for (int ph = 0; ph < 4; ph++)
+#pragma unroll
+          for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) {
+              const float wv = wv4[ph * 9 + a * 3 + b];
+#pragma unroll
+              for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j][ph] = __builtin_fmaf(v[i + a][j + b], wv, acc[i][j][ph]);
+            }
+      }
+    }
+    __syncthreads();  // the tile is overwritten by the next half
+  }
+
+  // ---- outputs + arg-max (first maximum in C order) ----
+  float bestv = -INFINITY;
+  unsigned bestk = 0xFFFFFFFFu;
+  const float bias4 = p.b4[0];
+  if (cthread) {
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int li = r0 + tr + i, lj = c0 + tc + j;
+#pragma unroll
+        for (int ph = 0; ph < 4; ph++) {
+          const int y = 2 * li + (ph >> 1), x = 2 * lj + (ph & 1);
+          if (border && (y == 0 || y == PS - 1 || x == 0 || x == PS - 1)) continue;  // taken from facc below
+          const float val = acc[i][j][ph] + bias4;
+          const unsigned k = (unsigned)(y * PS + x);
+          if (p.heat) p.heat[(size_t)s * PS * PS + k] = val;
+          if (val > bestv || (val == bestv && k < bestk)) { bestv = val; bestk = k; }
+        }
+      }
+  }
+  if (border) {
+    for (int e = tid; e < 2 * 2 * HT_T; e += 256) {
+      const int k = e % (2 * HT_T), line = e / (2 * HT_T);
+      int y, x;
+      if (line == 0) { if (!(top || bot)) continue; y = top ? 0 : PS - 1; x = 2 * c0 + k; }
+      else { if (!(lef || rig)) continue; x = lef ? 0 : PS - 1; y = 2 * r0 + k; }
+      const float val = facc[e] + bias4;
+      const unsigned kk = (unsigned)(y * PS + x);
+      if (p.heat) p.heat[(size_t)s * PS * PS + kk] = val;
+      if (val > bestv || (val == bestv && kk < bestk)) { bestv = val; bestk = kk; }
+    }
+  }
+  unsigned long long key = ((unsigned long long)ordered_f32(bestv) << 32) | (unsigned long long)(~bestk);
+  if (bestk == 0xFFFFFFFFu) key = 0ull;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long other = __shfl_xor(key, o);
+    key = other > key ? other : key;
+  }
+  if (lane == 0 && key) atomicMax(&p.best[s], key);
+}
+
 __global__ void k_policy_finish(int S, const uint8_t *mask, const unsigned long long *best, int32_t *ipointer) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= S || (mask && !mask[s])) return;
@@ -474,6 +782,12 @@ struct PolicyWs {
   int32_t *iaction, *ipointer;
 };
 
+// v1 (layer-by-layer tail through a [S][8][200][200] HBM tensor) is kept for A/B checks
+static bool policy_unfused() {
+  const char *e = getenv("OFX_POLICY_UNFUSED");
+  return e && e[0] == '1';
+}
+
 static size_t al(size_t b) { return (b + 255) & ~(size_t)255; }
 
 static int policy_workspace(ofx_handle *h, PolicyWs *ws) {
@@ -482,7 +796,7 @@ static int policy_workspace(ofx_handle *h, PolicyWs *ws) {
   const size_t sz[] = {al(4ull * L.total),          al(4ull * N * 8 * 200 * 200), al(4ull * N * 8 * 100 * 100),
                        al(4ull * N * 8 * 50 * 50),   al(4ull * N * 5000),          al(4ull * N * 100),
                        al(4ull * S * 100),           al(4ull * S * 625),           al(4ull * S * 2 * 50 * 50),
-                       al(4ull * S * 4 * 100 * 100), al(4ull * S * 8 * 200 * 200), al(8ull * S),
+                       al(4ull * S * 4 * 100 * 100), al(policy_unfused() ? 4ull * S * 8 * 200 * 200 : 256), al(8ull * S),
                        al(4ull * S),                 al(8ull * S)};
   size_t total = 0;
   for (size_t b : sz) total += b;
@@ -551,6 +865,7 @@ extern "C" int ofx_policy_forward(ofx_handle *h, const float *weights, const uin
   }
   pp.src_k4 = off[t_u4]; pp.src_b4 = off[t_u4 + 1];
   pp.dst_w4eff = L.w4eff; pp.dst_w4raw = L.w4raw; pp.dst_b4 = L.b4;
+  pp.dst_w3eff = L.w3eff; pp.dst_w4eff_c = L.w4eff_c; pp.dst_w3mf = L.w3mf;
   hipLaunchKernelGGL(k_policy_prepare, dim3(1), dim3(256), 0, h->stream, pp);
   OFX_HIP(hipGetLastError());
 
@@ -590,16 +905,26 @@ extern "C" int ofx_policy_forward(ofx_handle *h, const float *weights, const uin
   if ((rc = launch_conv<1, 2, 10, 50, 2, false, false>(h, up, S, 50))) return rc;
   up.in = ws.up1; up.w = ws.prep + L.uw[1]; up.b = ws.prep + L.ub[1]; up.out = ws.up2;
   if ((rc = launch_conv<2, 4, 10, 100, 2, false, false>(h, up, S, 100))) return rc;
-  up.in = ws.up2; up.w = ws.prep + L.uw[2]; up.b = ws.prep + L.ub[2]; up.out = ws.up3;
-  if ((rc = launch_conv<4, 8, 10, 100, 2, false, false>(h, up, S, 200))) return rc;
-
   OFX_HIP(hipMemsetAsync(ws.best, 0, sizeof(unsigned long long) * S, h->stream));
-  Up4Params u4;
-  u4.in = ws.up3; u4.weff = ws.prep + L.w4eff; u4.wraw = ws.prep + L.w4raw; u4.b4 = ws.prep + L.b4;
-  u4.mask = ship_mask; u4.best = ws.best; u4.heat = heatmap;
-  constexpr int tiles4 = (U4_LS / U4_TW) * (U4_LS / U4_TH);
-  hipLaunchKernelGGL(k_upconv4, dim3((unsigned)(S * tiles4)), dim3(256), 0, h->stream, u4);
-  OFX_HIP(hipGetLastError());
+  if (!policy_unfused()) {
+    HeadTailParams ht;
+    ht.up2 = ws.up2;
+    ht.w3mf = ws.prep + L.w3mf; ht.w3raw = ws.prep + L.uw[2]; ht.b3 = ws.prep + L.ub[2];
+    ht.w4eff = ws.prep + L.w4eff_c; ht.w4raw = ws.prep + L.w4raw; ht.b4 = ws.prep + L.b4;
+    ht.mask = ship_mask; ht.best = ws.best; ht.heat = heatmap;
+    constexpr int tiles = (HT_S3 / HT_T) * (HT_S3 / HT_T);
+    hipLaunchKernelGGL(k_head_tail, dim3((unsigned)(S * tiles)), dim3(256), 0, h->stream, ht);
+    OFX_HIP(hipGetLastError());
+  } else {
+    up.in = ws.up2; up.w = ws.prep + L.uw[2]; up.b = ws.prep + L.ub[2]; up.out = ws.up3;
+    if ((rc = launch_conv<4, 8, 10, 100, 2, false, false>(h, up, S, 200))) return rc;
+    Up4Params u4;
+    u4.in = ws.up3; u4.weff = ws.prep + L.w4eff; u4.wraw = ws.prep + L.w4raw; u4.b4 = ws.prep + L.b4;
+    u4.mask = ship_mask; u4.best = ws.best; u4.heat = heatmap;
+    constexpr int tiles4 = (U4_LS / U4_TW) * (U4_LS / U4_TH);
+    hipLaunchKernelGGL(k_upconv4, dim3((unsigned)(S * tiles4)), dim3(256), 0, h->stream, u4);
+    OFX_HIP(hipGetLastError());
+  }
   hipLaunchKernelGGL(k_policy_finish, dim3((S + 255) / 256), dim3(256), 0, h->stream, S, ship_mask, ws.best,
                      ipointer ? ipointer : ws.ipointer);
   OFX_HIP(hipGetLastError());
