@@ -537,20 +537,37 @@ __device__ __forceinline__ float up2d(const float *plane, int stride, int o_r, i
   return top + (bot - top) * wy;
 }
 
+// x2 half-pixel bilinear along one axis of a clamp-extended line: value at up-res index u from the low-res
+// samples line[(k - base) * stride]: even u = 2k -> .25 L[k-1] + .75 L[k]; odd -> .75 L[k] + .25 L[k+1]
+__device__ __forceinline__ float up1d(const float *line, int stride, int base, int u) {
+  const int k = u >> 1;
+  const int ka = (u & 1) ? k : k - 1;
+  const float w = (u & 1) ? 0.25f : 0.75f;
+  const float l0 = line[(ka - base) * stride], l1 = line[(ka + 1 - base) * stride];
+  return l0 + (l1 - l0) * w;
+}
+
+constexpr int HT_L2P = HT_L2 * HT_L2 + 16;  // plane stride of the patch: +16 floats so the 4 channel planes of
+                                            // the MFMA A-gather land on different LDS banks
+constexpr int HT_LB2 = HT_T + 4;            // frame-line length of stage B (x' in [c0-2, c0+T+1])
+constexpr int HT_LB4 = 2 * HT_T + 2;        // frame-line length of stage C (x' in [2c0-1, 2c0+2T])
+
 __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
-  __shared__ __align__(16) float l2[4][HT_L2][HT_L2];
+  __shared__ __align__(16) float l2[4 * HT_L2P];
   __shared__ __align__(16) float u3[4][HT_U3][HT_U3P];
   __shared__ __align__(16) float w4s[8][36];
-  __shared__ float facc[2 * 2 * HT_T];              // frame-pixel sums of the heat-map (border tiles)
+  __shared__ float hb2[4][HT_LB2], vb2[4][HT_LB2];  // U2[0|199][x'] , U2[y'][0|199]  (border tiles)
+  __shared__ float hb4[4][HT_LB4], vb4[4][HT_LB4];  // U3 lines of the current channel half
+  __shared__ float facc[2][2 * HT_T];               // zero-padding corrections of the heat-map frame pixels
   __shared__ __align__(8) unsigned short otab[512]; // quad -> (2qi-1)*U3P + (2qj-1) + 64, edge flags in bits 12-15
   __shared__ unsigned short atab[512];              // quad -> qi*L2 + qj (A-operand gather base)
   constexpr int tiles_x = HT_S3 / HT_T, tiles = tiles_x * tiles_x;
   const int s = blockIdx.x / tiles, t = blockIdx.x - s * tiles;
   if (p.mask && !p.mask[s]) return;  // block-uniform
   const int r0 = (t / tiles_x) * HT_T, c0 = (t % tiles_x) * HT_T;  // uprelu3 coords of the tile
-  const int ib = r0 / 2 - 2, jb = c0 / 2 - 2;                      // uprelu2 coords of l2[.][0][0]
+  const int ib = r0 / 2 - 2, jb = c0 / 2 - 2;                      // uprelu2 coords of the patch origin
   const bool top = r0 == 0, bot = r0 + HT_T == HT_S3, lef = c0 == 0, rig = c0 + HT_T == HT_S3;
-  const bool border = top || bot || lef || rig;
+  const bool hline = top || bot, vline = lef || rig, border = hline || vline;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
   // ---- stage A: patch + tables + stage-C weights; all global loads in flight before the first LDS store ----
@@ -566,7 +583,10 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
     }
     const float wa = p.w4eff[tid], wb = tid < 32 ? p.w4eff[256 + tid] : 0.f;
 #pragma unroll
-    for (int u = 0; u < TOTAL / 256; u++) (&l2[0][0][0])[u * 256 + tid] = vals[u];
+    for (int u = 0; u < TOTAL / 256; u++) {
+      const int e = u * 256 + tid;
+      l2[e + (e / (HT_L2 * HT_L2)) * 16] = vals[u];
+    }
     (&w4s[0][0])[tid] = wa;
     if (tid < 32) (&w4s[0][0])[256 + tid] = wb;
     for (int m = tid; m < 512; m += 256) {
@@ -576,14 +596,29 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
       otab[m] = (unsigned short)(((2 * qi - 1) * HT_U3P + (2 * qj - 1) + 64) | (f << 12));
       atab[m] = (unsigned short)(qi * HT_L2 + qj);
     }
+    if (tid < 2 * 2 * HT_T) (&facc[0][0])[tid] = 0.f;
   }
   __syncthreads();
+  if (border) {  // frame lines of the upsampled uprelu2 plane (block-uniform)
+    for (int e = tid; e < 2 * 4 * HT_LB2; e += 256) {
+      const int k = e % HT_LB2, ci = (e / HT_LB2) & 3, line = e / (4 * HT_LB2);
+      if (line == 0 && hline) {  // U2[0] = L[0], U2[199] = L[99] (row clamp): an x-lerp of one patch row
+        const int R = top ? 0 : HT_S2 - 1, xc = min(max(c0 - 2 + k, 0), HT_S3 - 1);
+        hb2[ci][k] = up1d(&l2[ci * HT_L2P + (R - ib) * HT_L2], 1, jb, xc);
+      } else if (line == 1 && vline) {
+        const int Cc = lef ? 0 : HT_S2 - 1, yc = min(max(r0 - 2 + k, 0), HT_S3 - 1);
+        vb2[ci][k] = up1d(&l2[ci * HT_L2P + (Cc - jb)], HT_L2, ib, yc);
+      }
+    }
+    __syncthreads();
+  }
 
   // per-lane constants of the MFMA stage: n = lane & 15 -> (phase, local channel); kq = lane >> 4 -> input channel
   const int n16 = lane & 15, kq = lane >> 4;
   const int ph3 = n16 >> 2, cl3 = n16 & 3, pa3 = ph3 >> 1, pb3 = ph3 & 1;
   const unsigned badmask = ((pa3 ? 2u : 1u) | (pb3 ? 8u : 4u)) << 12;  // cell of this phase falls outside the tile
   const int cell_off = cl3 * HT_U3 * HT_U3P + pa3 * HT_U3P + pb3 - 64;
+  const float relu_floor = border ? -INFINITY : 0.f;  // border tiles apply the ReLU in their fix-up pass
 
   // stage-C ownership: 2 x 4 uprelu3 pixels per thread (200 of 256 threads)
   const bool cthread = tid < (HT_T / 2) * (HT_T / 4);
@@ -595,11 +630,10 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
     for (int j = 0; j < 4; j++)
 #pragma unroll
       for (int ph = 0; ph < 4; ph++) acc[i][j][ph] = 0.f;
-  if (border && tid < 2 * 2 * HT_T) facc[tid] = 0.f;
 
 #pragma unroll 1
   for (int half = 0; half < 2; half++) {
-    // ---- stage B: 4 channels of the uprelu3 tile ----
+    // ---- stage B: 4 channels of the uprelu3 tile on the matrix cores ----
     {
       float bw[9];
 #pragma unroll
@@ -609,7 +643,7 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
 #pragma unroll 1
       for (int mt = wv; mt < HT_MT; mt += 4) {
         const int m0 = mt * 16;
-        const float *abase = &l2[kq][0][0] + atab[m0 + n16];  // A row = quad m0 + (lane & 15), k = 4 j + kq
+        const float *abase = &l2[kq * HT_L2P] + atab[m0 + n16];  // A row = quad m0 + (lane & 15), k = 4 j + kq
         f32x4 d = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 9; j++)  // tap j, channel kq
@@ -619,29 +653,44 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
         const unsigned o[4] = {o2.x & 0xFFFFu, o2.x >> 16, o2.y & 0xFFFFu, o2.y >> 16};
 #pragma unroll
         for (int i = 0; i < 4; i++)
-          if (!(o[i] & badmask)) ubase[o[i] & 0xFFFu] = fmaxf(d[i] + bias3, 0.f);
+          if (!(o[i] & badmask)) ubase[o[i] & 0xFFFu] = fmaxf(d[i] + bias3, relu_floor);
       }
     }
     __syncthreads();
     if (border) {
-      // frame cells of the uprelu3 plane: recompute from the definition (zero padding outside [0,200)^2)
-      for (int e = tid; e < 4 * 2 * HT_U3; e += 256) {
-        const int k = e % HT_U3, line = (e / HT_U3) & 1, cl = e / (2 * HT_U3);
-        int y, x;
-        if (line == 0) { if (!(top || bot)) continue; y = top ? 0 : HT_S3 - 1; x = c0 - 1 + k; }
-        else { if (!(lef || rig)) continue; x = lef ? 0 : HT_S3 - 1; y = r0 - 1 + k; }
-        if (y < 0 || y >= HT_S3 || x < 0 || x >= HT_S3) continue;
-        const int co = 4 * half + cl;
-        float sum = 0.f;
-#pragma unroll 1
-        for (int tap = 0; tap < 9; tap++) {
-          const int uy = y + tap / 3 - 1, ux = x + tap % 3 - 1;
-          if (uy < 0 || uy >= HT_S3 || ux < 0 || ux >= HT_S3) continue;
+      // The tile holds G + bias without ReLU.  Frame cells (row/col 0 or 199 of the plane) subtract the taps
+      // that fall into the conv's zero padding, sum w[tap][ci] U2[clamp], taken from the frame lines.
+      for (int e = tid; e < 4 * HT_U3 * HT_U3; e += 256) {
+        const int tx = e % HT_U3, ty = (e / HT_U3) % HT_U3, cl = e / (HT_U3 * HT_U3);
+        const int y = r0 - 1 + ty, x = c0 - 1 + tx;
+        if (y < 0 || y >= HT_S3 || x < 0 || x >= HT_S3) continue;  // clamp copies below
+        float v = u3[cl][ty][tx];
+        const bool fy = y == 0 || y == HT_S3 - 1, fx = x == 0 || x == HT_S3 - 1;
+        if (fy || fx) {
+          const float *w = p.w3raw + 4 * half + cl;
+          float corr = 0.f;
+          if (fy) {
+            const int trow = (y == 0) ? 0 : 2;
 #pragma unroll
-          for (int ci = 0; ci < 4; ci++)
-            sum += p.w3raw[(tap * 4 + ci) * 8 + co] * up2d(&l2[ci][0][0], HT_L2, ib, jb, uy, ux);
+            for (int dx = -1; dx <= 1; dx++) {
+              const int xx = min(max(x + dx, 0), HT_S3 - 1) - (c0 - 2);
+#pragma unroll
+              for (int ci = 0; ci < 4; ci++) corr += w[((trow * 3 + dx + 1) * 4 + ci) * 8] * hb2[ci][xx];
+            }
+          }
+          if (fx) {
+            const int tcol = (x == 0) ? 0 : 2;
+#pragma unroll
+            for (int dy = -1; dy <= 1; dy++) {
+              const int uy = y + dy;
+              if (uy < 0 || uy >= HT_S3) continue;  // counted with the row
+#pragma unroll
+              for (int ci = 0; ci < 4; ci++) corr += w[(((dy + 1) * 3 + tcol) * 4 + ci) * 8] * vb2[ci][uy - (r0 - 2)];
+            }
+          }
+          v -= corr;
         }
-        u3[cl][y - (r0 - 1)][x - (c0 - 1)] = fmaxf(sum + p.b3[co], 0.f);
+        u3[cl][ty][tx] = fmaxf(v, 0.f);
       }
       __syncthreads();
       // halo cells outside the image = clamp extension (their sources are inside the image)
@@ -655,37 +704,58 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
         }
       }
       __syncthreads();
-      // frame pixels of the heat-map: partial sums over this half's 4 channels, from the definition
+      // frame lines of the upsampled uprelu3 plane for these 4 channels
+      for (int e = tid; e < 2 * 4 * HT_LB4; e += 256) {
+        const int k = e % HT_LB4, cl = (e / HT_LB4) & 3, line = e / (4 * HT_LB4);
+        if (line == 0 && hline) {
+          const int R = top ? 0 : HT_S3 - 1, xc = min(max(2 * c0 - 1 + k, 0), PS - 1);
+          hb4[cl][k] = up1d(&u3[cl][R - (r0 - 1)][0], 1, c0 - 1, xc);
+        } else if (line == 1 && vline) {
+          const int Cc = lef ? 0 : HT_S3 - 1, yc = min(max(2 * r0 - 1 + k, 0), PS - 1);
+          vb4[cl][k] = up1d(&u3[cl][0][Cc - (c0 - 1)], HT_U3P, r0 - 1, yc);
+        }
+      }
+      __syncthreads();
+      // corrections of the heat-map frame pixels of this tile, accumulated over the two halves:
+      // facc[0][k] for (y in {0,399}, x = 2c0 + k) ; facc[1][k] for (y = 2r0 + k, x in {0,399}), rows counted once
       for (int e = tid; e < 2 * 2 * HT_T; e += 256) {
         const int k = e % (2 * HT_T), line = e / (2 * HT_T);
-        int y, x;
-        if (line == 0) { if (!(top || bot)) continue; y = top ? 0 : PS - 1; x = 2 * c0 + k; }
-        else { if (!(lef || rig)) continue; x = lef ? 0 : PS - 1; y = 2 * r0 + k; }
-        float sum = 0.f;
-#pragma unroll 1
-        for (int tap = 0; tap < 9; tap++) {
-          const int uy = y + tap / 3 - 1, ux = x + tap % 3 - 1;
-          if (uy < 0 || uy >= PS || ux < 0 || ux >= PS) continue;
+        const float *w = p.w4raw + 4 * half;
+        float corr = 0.f;
+        if (line == 0 && hline) {
+          const int trow = top ? 0 : 2, x = 2 * c0 + k;
 #pragma unroll
-          for (int cl = 0; cl < 4; cl++)
-            sum += p.w4raw[tap * 8 + 4 * half + cl] * up2d(&u3[cl][0][0], HT_U3P, r0 - 1, c0 - 1, uy, ux);
+          for (int dx = -1; dx <= 1; dx++) {
+            const int xx = min(max(x + dx, 0), PS - 1) - (2 * c0 - 1);
+#pragma unroll
+            for (int cl = 0; cl < 4; cl++) corr += w[(trow * 3 + dx + 1) * 8 + cl] * hb4[cl][xx];
+          }
+        } else if (line == 1 && vline) {
+          const int tcol = lef ? 0 : 2, y = 2 * r0 + k;
+#pragma unroll
+          for (int dy = -1; dy <= 1; dy++) {
+            const int uy = y + dy;
+            if (uy < 0 || uy >= PS) continue;
+#pragma unroll
+            for (int cl = 0; cl < 4; cl++) corr += w[((dy + 1) * 3 + tcol) * 8 + cl] * vb4[cl][uy - (2 * r0 - 1)];
+          }
         }
-        facc[e] += sum;
+        facc[line][k] += corr;
       }
     }
 
-    // ---- stage C: 4 channels of the heat-map quads ----
+    // ---- stage C: 4 channels of the heat-map quads on the VALU ----
     if (cthread) {
 #pragma unroll 1
       for (int cl = 0; cl < 4; cl++) {
-        float v[4][6];
+        float v[4][8];
 #pragma unroll
-        for (int r = 0; r < 4; r++)
-#pragma unroll
-          for (int c2 = 0; c2 < 3; c2++) {
-            const float2 t2 = *reinterpret_cast<const float2 *>(&u3[cl][tr + r][tc + 2 * c2]);
-            v[r][2 * c2] = t2.x; v[r][2 * c2 + 1] = t2.y;
-          }
+        for (int r = 0; r < 4; r++) {  // two aligned b128 reads per row: bank-conflict free across the wave
+          const float4 lo = *reinterpret_cast<const float4 *>(&u3[cl][tr + r][tc]);
+          const float4 hi = *reinterpret_cast<const float4 *>(&u3[cl][tr + r][tc + 4]);
+          v[r][0] = lo.x; v[r][1] = lo.y; v[r][2] = lo.z; v[r][3] = lo.w;
+          v[r][4] = hi.x; v[r][5] = hi.y;
+        }
         float wv4[36];
 #pragma unroll
         for (int q = 0; q < 9; q++) {
@@ -722,25 +792,16 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
 #pragma unroll
         for (int ph = 0; ph < 4; ph++) {
           const int y = 2 * li + (ph >> 1), x = 2 * lj + (ph & 1);
-          if (border && (y == 0 || y == PS - 1 || x == 0 || x == PS - 1)) continue;  // taken from facc below
-          const float val = acc[i][j][ph] + bias4;
+          float val = acc[i][j][ph] + bias4;
+          if (border) {
+            if (y == 0 || y == PS - 1) val -= facc[0][x - 2 * c0];
+            if (x == 0 || x == PS - 1) val -= facc[1][y - 2 * r0];
+          }
           const unsigned k = (unsigned)(y * PS + x);
           if (p.heat) p.heat[(size_t)s * PS * PS + k] = val;
           if (val > bestv || (val == bestv && k < bestk)) { bestv = val; bestk = k; }
         }
       }
-  }
-  if (border) {
-    for (int e = tid; e < 2 * 2 * HT_T; e += 256) {
-      const int k = e % (2 * HT_T), line = e / (2 * HT_T);
-      int y, x;
-      if (line == 0) { if (!(top || bot)) continue; y = top ? 0 : PS - 1; x = 2 * c0 + k; }
-      else { if (!(lef || rig)) continue; x = lef ? 0 : PS - 1; y = 2 * r0 + k; }
-      const float val = facc[e] + bias4;
-      const unsigned kk = (unsigned)(y * PS + x);
-      if (p.heat) p.heat[(size_t)s * PS * PS + kk] = val;
-      if (val > bestv || (val == bestv && kk < bestk)) { bestv = val; bestk = kk; }
-    }
   }
   unsigned long long key = ((unsigned long long)ordered_f32(bestv) << 32) | (unsigned long long)(~bestk);
   if (bestk == 0xFFFFFFFFu) key = 0ull;

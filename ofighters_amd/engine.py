@@ -154,6 +154,8 @@ class ArenaBatch:
     def step(self, actions=None, actions_ptr=None):
         """One lock-step.  `actions`: structured array [N,M] (pack_actions) or
         `actions_ptr`: device pointer to [N][M] ofx_action."""
+        if actions is None and actions_ptr is None:
+            actions_ptr = self._actions.ptr  # the device buffer bot_actions / policy_actions wrote
         if actions_ptr is None:
             a = np.ascontiguousarray(actions, dtype=ACTION_DTYPE).reshape(self.N, self.M)
             self.sync()  # the previous tick may still be reading the buffer
@@ -228,6 +230,8 @@ class ArenaBatch:
         nat.check(nat.lib().ofx_episode_scores(self._h, buf.ptr))
         self.sync()
         return buf.download(np.int64, (self.M + 1,))
+
+    episode_scores = episode_scores_host
 
     def episode_scores_into(self, dev_ptr):
         nat.check(nat.lib().ofx_episode_scores(self._h, dev_ptr))

@@ -1,0 +1,41 @@
+"""CPU stand-in for ArenaBatch built on the oracle (TEST ONLY): lets the host
+logic of the sharded rollout run under gloo without a GPU."""
+import numpy as np
+
+from oracle import pyoracle
+from ofighters_amd import _native as nat
+
+
+class OracleBatch:
+    def __init__(self, n_arenas, n_ships=8, arena_base=0):
+        self.N, self.M, self.base = n_arenas, n_ships, arena_base
+        self.arenas = [pyoracle.Arena(n_ships=n_ships) for _ in range(n_arenas)]
+        self.episode = 0
+        self._acts = None
+        self._sums = np.zeros(n_ships + 1, np.int64)
+
+    def spawn_random(self, seed):
+        for g, a in enumerate(self.arenas):
+            a.spawn(pyoracle.reset_draws(a.cfg, seed, self.base + g, 0))
+
+    def restart_random(self, seed):
+        self.episode += 1
+        self._sums[:] = 0
+        for g, a in enumerate(self.arenas):
+            self._sums[:self.M] += a.ships()["score"]
+            self._sums[self.M] += 1
+            a.restart(pyoracle.reset_draws(a.cfg, seed, self.base + g, self.episode))
+
+    def bot_actions(self, behaviours, seed, tick=None):
+        beh = np.array([nat.BEHAVIOURS[b] for b in behaviours], np.int32)
+        self._acts = [a.bot_actions(beh, seed, self.base + g, tick) for g, a in enumerate(self.arenas)]
+
+    def step(self):
+        for a, act in zip(self.arenas, self._acts):
+            a.step(act)
+
+    def rasterise(self):
+        pass
+
+    def episode_scores(self):
+        return self._sums.copy()
