@@ -292,3 +292,20 @@ class ArenaBatch:
         if want_heat:
             out["heat"] = dh.download(np.float32, (self.N, self.M, self.W, self.H))
         return out
+
+    # ------------------------------------------------------------------ facade support
+    def step_packed(self, packed):
+        """packed int32 [N,M,5] = valid, shoot, thrust, px, py (the facade's Action.packed())."""
+        p = np.asarray(packed, np.int32).reshape(self.N, self.M, 5)
+        self.step(pack_actions(p[..., 0], p[..., 1], p[..., 2], p[..., 3], p[..., 4]))
+
+    def snapshot(self):
+        g = self.get
+        return dict(x=g(nat.F_SHIP_X), y=g(nat.F_SHIP_Y), px=g(nat.F_SHIP_PX), py=g(nat.F_SHIP_PY),
+                    alive=g(nat.F_SHIP_ALIVE), hull=g(nat.F_HULL), reward=g(nat.F_REWARD), score=g(nat.F_SCORE),
+                    n_lasers=g(nat.F_N_LASERS), lx=g(nat.F_LASER_X), ly=g(nat.F_LASER_Y),
+                    lowner=g(nat.F_LASER_OWNER), ldead=g(nat.F_LASER_DEAD))
+
+    def maps_f64(self):
+        sm, lm = self.maps_host(nat.MAP_U8)
+        return sm.astype(np.float64), lm.astype(np.float64)

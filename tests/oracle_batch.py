@@ -39,3 +39,32 @@ class OracleBatch:
 
     def episode_scores(self):
         return self._sums.copy()
+
+
+class OracleEngine:
+    """Single-arena engine with the interface the facade (lib/battleground.py) needs, on the CPU oracle."""
+
+    def __init__(self, n_ships, width=400, height=400):
+        self.N, self.M, self.W, self.H = 1, n_ships, width, height
+        self.a = pyoracle.Arena(cfg=pyoracle.default_cfg(n_ships, width=width, height=height))
+
+    def spawn(self, draws):
+        self.a.spawn(np.asarray(draws, np.int32).reshape(self.M, 2))
+
+    def restart(self, draws):
+        self.a.restart(np.asarray(draws, np.int32).reshape(self.M, 2))
+
+    def step_packed(self, packed):
+        self.a.step(np.asarray(packed, np.int32).reshape(self.M, 5))
+
+    def snapshot(self):
+        s, l = self.a.ships(), self.a.lasers()
+        n = len(l["x"])
+        one = lambda v: np.asarray(v)[None]
+        return dict(x=one(s["xy"][:, 0]), y=one(s["xy"][:, 1]), px=one(s["pt"][:, 0]), py=one(s["pt"][:, 1]),
+                    alive=one(s["alive"]), hull=one(s["hull"]), reward=one(s["reward"]), score=one(s["score"]),
+                    n_lasers=np.array([n]), lx=one(l["x"]), ly=one(l["y"]), lowner=one(l["owner"]), ldead=one(l["destroyed"]))
+
+    def maps_f64(self):
+        sm, lm = self.a.rasterise()
+        return sm[None].astype(np.float64), lm[None].astype(np.float64)
