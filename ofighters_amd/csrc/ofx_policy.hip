@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
   __shared__ float hb2[4][HT_LB2], vb2[4][HT_LB2];  // U2[0|199][x'] , U2[y'][0|199]  (border tiles)
   __shared__ float hb4[4][HT_LB4], vb4[4][HT_LB4];  // U3 lines of the current channel half
   __shared__ float facc[2][2 * HT_T];               // zero-padding corrections of the heat-map frame pixels
-  __shared__ __align__(8) unsigned short otab[512]; // quad -> (2qi-1)*U3P + (2qj-1) + 64, edge flags in bits 12-15
+  __shared__ __align__(16) unsigned otab[512];      // quad -> (2qi-1)*U3P + (2qj-1) + 64 | flags << 12 (see below)
   __shared__ unsigned short atab[512];              // quad -> qi*L2 + qj (A-operand gather base)
   constexpr int tiles_x = HT_S3 / HT_T, tiles = tiles_x * tiles_x;
   const int s = blockIdx.x / tiles, t = blockIdx.x - s * tiles;
@@ -591,9 +591,12 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
     if (tid < 32) (&w4s[0][0])[256 + tid] = wb;
     for (int m = tid; m < 512; m += 256) {
       const int mq = min(m, HT_NQ - 1), qi = mq / HT_Q, qj = mq - qi * HT_Q;
-      unsigned f = (qi == 0 ? 1u : 0u) | (qi == HT_Q - 1 ? 2u : 0u) | (qj == 0 ? 4u : 0u) | (qj == HT_Q - 1 ? 8u : 0u);
+      // bits 0-3: quad on the tile's outer ring (one of its phases falls outside the 42x42 tile);
+      // bits 4-7: quad one step inside (in an image-border tile one of its phases is a FRAME cell of the plane)
+      unsigned f = (qi == 0 ? 1u : 0u) | (qi == HT_Q - 1 ? 2u : 0u) | (qj == 0 ? 4u : 0u) | (qj == HT_Q - 1 ? 8u : 0u) |
+                   (qi == 1 ? 16u : 0u) | (qi == HT_Q - 2 ? 32u : 0u) | (qj == 1 ? 64u : 0u) | (qj == HT_Q - 2 ? 128u : 0u);
       if (m >= HT_NQ) f = 15u;
-      otab[m] = (unsigned short)(((2 * qi - 1) * HT_U3P + (2 * qj - 1) + 64) | (f << 12));
+      otab[m] = (unsigned)((2 * qi - 1) * HT_U3P + (2 * qj - 1) + 64) | (f << 12);
       atab[m] = (unsigned short)(qi * HT_L2 + qj);
     }
     if (tid < 2 * 2 * HT_T) (&facc[0][0])[tid] = 0.f;
@@ -618,7 +621,10 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
   const int ph3 = n16 >> 2, cl3 = n16 & 3, pa3 = ph3 >> 1, pb3 = ph3 & 1;
   const unsigned badmask = ((pa3 ? 2u : 1u) | (pb3 ? 8u : 4u)) << 12;  // cell of this phase falls outside the tile
   const int cell_off = cl3 * HT_U3 * HT_U3P + pa3 * HT_U3P + pb3 - 64;
-  const float relu_floor = border ? -INFINITY : 0.f;  // border tiles apply the ReLU in their fix-up pass
+  // frame cells of the plane (y or x in {0,199}) keep G + bias WITHOUT ReLU: the border pass subtracts the
+  // zero-padding taps first.  y = 0 <=> top tile, quad row 1, phase row 0 ; y = 199 <=> bottom tile, row Q-2, phase row 1
+  const unsigned framemask = (((top && pa3 == 0) ? 16u : 0u) | ((bot && pa3 == 1) ? 32u : 0u) |
+                              ((lef && pb3 == 0) ? 64u : 0u) | ((rig && pb3 == 1) ? 128u : 0u)) << 12;
 
   // stage-C ownership: 2 x 4 uprelu3 pixels per thread (200 of 256 threads)
   const bool cthread = tid < (HT_T / 2) * (HT_T / 4);
@@ -649,48 +655,48 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
         for (int j = 0; j < 9; j++)  // tap j, channel kq
           d = __builtin_amdgcn_mfma_f32_16x16x4f32(abase[(j / 3) * HT_L2 + (j % 3)], bw[j], d, 0, 0, 0);
         // D: col = lane & 15, row = 4 (lane >> 4) + reg -> quads m0 + 4 kq .. + 3
-        const uint2 o2 = *reinterpret_cast<const uint2 *>(&otab[m0 + 4 * kq]);
-        const unsigned o[4] = {o2.x & 0xFFFFu, o2.x >> 16, o2.y & 0xFFFFu, o2.y >> 16};
+        const uint4 o4 = *reinterpret_cast<const uint4 *>(&otab[m0 + 4 * kq]);
+        const unsigned o[4] = {o4.x, o4.y, o4.z, o4.w};
 #pragma unroll
         for (int i = 0; i < 4; i++)
-          if (!(o[i] & badmask)) ubase[o[i] & 0xFFFu] = fmaxf(d[i] + bias3, relu_floor);
+          if (!(o[i] & badmask)) ubase[o[i] & 0xFFFu] = fmaxf(d[i] + bias3, (o[i] & framemask) ? -INFINITY : 0.f);
       }
     }
     __syncthreads();
     if (border) {
-      // The tile holds G + bias without ReLU.  Frame cells (row/col 0 or 199 of the plane) subtract the taps
-      // that fall into the conv's zero padding, sum w[tap][ci] U2[clamp], taken from the frame lines.
-      for (int e = tid; e < 4 * HT_U3 * HT_U3; e += 256) {
-        const int tx = e % HT_U3, ty = (e / HT_U3) % HT_U3, cl = e / (HT_U3 * HT_U3);
-        const int y = r0 - 1 + ty, x = c0 - 1 + tx;
-        if (y < 0 || y >= HT_S3 || x < 0 || x >= HT_S3) continue;  // clamp copies below
-        float v = u3[cl][ty][tx];
+      // Frame cells (row/col 0 or 199 of the plane) hold G + bias without ReLU: subtract the taps that fall
+      // into the conv's zero padding, sum w[tap][ci] U2[clamp] from the frame lines, then apply the ReLU.
+      for (int e = tid; e < 4 * 2 * HT_U3; e += 256) {
+        const int k = e % HT_U3, line = (e / HT_U3) & 1, cl = e / (2 * HT_U3);
+        int y, x;
+        if (line == 0) { if (!hline) continue; y = top ? 0 : HT_S3 - 1; x = c0 - 1 + k; }
+        else { if (!vline) continue; x = lef ? 0 : HT_S3 - 1; y = r0 - 1 + k; }
+        if (y < 0 || y >= HT_S3 || x < 0 || x >= HT_S3) continue;
         const bool fy = y == 0 || y == HT_S3 - 1, fx = x == 0 || x == HT_S3 - 1;
-        if (fy || fx) {
-          const float *w = p.w3raw + 4 * half + cl;
-          float corr = 0.f;
-          if (fy) {
-            const int trow = (y == 0) ? 0 : 2;
+        if (line == 1 && fy) continue;  // the corner cell belongs to the horizontal line
+        const float *w = p.w3raw + 4 * half + cl;
+        float corr = 0.f;
+        if (fy) {
+          const int trow = (y == 0) ? 0 : 2;
 #pragma unroll
-            for (int dx = -1; dx <= 1; dx++) {
-              const int xx = min(max(x + dx, 0), HT_S3 - 1) - (c0 - 2);
+          for (int dx = -1; dx <= 1; dx++) {
+            const int xx = min(max(x + dx, 0), HT_S3 - 1) - (c0 - 2);
 #pragma unroll
-              for (int ci = 0; ci < 4; ci++) corr += w[((trow * 3 + dx + 1) * 4 + ci) * 8] * hb2[ci][xx];
-            }
+            for (int ci = 0; ci < 4; ci++) corr += w[((trow * 3 + dx + 1) * 4 + ci) * 8] * hb2[ci][xx];
           }
-          if (fx) {
-            const int tcol = (x == 0) ? 0 : 2;
-#pragma unroll
-            for (int dy = -1; dy <= 1; dy++) {
-              const int uy = y + dy;
-              if (uy < 0 || uy >= HT_S3) continue;  // counted with the row
-#pragma unroll
-              for (int ci = 0; ci < 4; ci++) corr += w[(((dy + 1) * 3 + tcol) * 4 + ci) * 8] * vb2[ci][uy - (r0 - 2)];
-            }
-          }
-          v -= corr;
         }
-        u3[cl][ty][tx] = fmaxf(v, 0.f);
+        if (fx) {
+          const int tcol = (x == 0) ? 0 : 2;
+#pragma unroll
+          for (int dy = -1; dy <= 1; dy++) {
+            const int uy = y + dy;
+            if (uy < 0 || uy >= HT_S3) continue;  // counted with the row
+#pragma unroll
+            for (int ci = 0; ci < 4; ci++) corr += w[(((dy + 1) * 3 + tcol) * 4 + ci) * 8] * vb2[ci][uy - (r0 - 2)];
+          }
+        }
+        float *cell = &u3[cl][y - (r0 - 1)][x - (c0 - 1)];
+        *cell = fmaxf(*cell - corr, 0.f);
       }
       __syncthreads();
       // halo cells outside the image = clamp extension (their sources are inside the image)
