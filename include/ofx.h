@@ -262,6 +262,9 @@ int ofx_timer_stop(ofx_handle *h, float *ms_host); /* synchronises */
  * handle's stream (created on first use, idx in [0, 65536)), read the elapsed
  * time between two of them later (synchronises on the second).              */
 int ofx_event_record(ofx_handle *h, int32_t idx);
+/* When event_base >= 0 every following ofx_policy_forward records events event_base / event_base+1 around its
+ * dominant kernel (the fused head tail) and then advances event_base by 2; -1 switches it off.               */
+int ofx_policy_profile(ofx_handle *h, int32_t event_base);
 int ofx_event_elapsed(ofx_handle *h, int32_t idx_from, int32_t idx_to, float *ms_host);
 
 #ifdef __cplusplus

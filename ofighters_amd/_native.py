@@ -93,6 +93,7 @@ SIGNATURES = {
     "ofx_timer_start": (_i, [_vp]),
     "ofx_timer_stop": (_i, [_vp, C.POINTER(C.c_float)]),
     "ofx_event_record": (_i, [_vp, C.c_int32]),
+    "ofx_policy_profile": (_i, [_vp, C.c_int32]),
     "ofx_event_elapsed": (_i, [_vp, C.c_int32, C.c_int32, C.POINTER(C.c_float)]),
 }
 

@@ -141,6 +141,7 @@ extern "C" int ofx_create(const ofx_config *cfg, ofx_handle **out) {
   hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { ofx_set_error("hipStreamCreate: %s", hipGetErrorString(e)); ofx_destroy(h); return OFX_ERR_HIP; }
   h->own_stream = true;
+  h->prof_base = -1;
   *out = h;
   return OFX_OK;
 }
@@ -556,5 +557,11 @@ extern "C" int ofx_event_elapsed(ofx_handle *h, int32_t a, int32_t b, float *ms_
   }
   OFX_HIP(hipEventSynchronize(h->ring[b]));
   OFX_HIP(hipEventElapsedTime(ms_host, h->ring[a], h->ring[b]));
+  return OFX_OK;
+}
+
+extern "C" int ofx_policy_profile(ofx_handle *h, int32_t event_base) {
+  if (!h || event_base >= OFX_RING_MAX - 1) { ofx_set_error("ofx_policy_profile: bad event base %d", event_base); return OFX_ERR_INVALID; }
+  h->prof_base = event_base < 0 ? -1 : event_base;
   return OFX_OK;
 }

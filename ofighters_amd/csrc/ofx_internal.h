@@ -54,6 +54,7 @@ struct ofx_handle {
   bool events;
   hipEvent_t *ring;                // numbered events for ofx_event_record
   int ring_n;
+  int prof_base;                   // ofx_policy_profile: next event pair, -1 = off
 };
 
 // kernels / launchers implemented in the other translation units

@@ -270,6 +270,126 @@ __global__ __launch_bounds__(((TH / 2) * (TW / 2) + 63) / 64 * 64) void k_conv(C
   }
 }
 
+// ---- direct 3x3 convolution, wide register tile, VGPR-resident weights ---------------------------------
+// Same contract as k_conv for the COUT = 8 layers, tuned to what tools/ubench_fma.hip measured on gfx950:
+// v_fmac_f32 with an SGPR weight operand issues at HALF rate (75 TFLOP/s), with VGPR operands at 115.  Here each
+// thread owns 2 x 4 output pixels x 8 channels (64 accumulators), and the 72 weights of one input channel are
+// fetched from an LDS copy with broadcast ds_read_b128 into VGPRs, each feeding 8 FMAs.
+template <int CIN, int TH, int TW, int MODE, bool POOL, bool OUT_HWC>
+__global__ __launch_bounds__(((TH / 2) * (TW / 4) + 63) / 64 * 64) void k_conv8(ConvParams p) {
+  constexpr int COUT = 8;
+  constexpr int NT = (TH / 2) * (TW / 4);
+  constexpr int NTB = (NT + 63) / 64 * 64;
+  constexpr int TWP = TW + 4;  // halo 1 each side + 2 pad: row stride multiple of 4 floats (16-byte aligned reads)
+  __shared__ __align__(16) float tile[CIN][TH + 2][TWP];
+  __shared__ __align__(16) float wl[CIN][9 * COUT];  // [ci][tap][co]
+  const int img = blockIdx.x / p.tiles, t = blockIdx.x - img * p.tiles;
+  if (p.mask && !p.mask[img]) return;
+  const int ty0 = (t / p.tiles_x) * TH, tx0 = (t % p.tiles_x) * TW;
+  const int tid = threadIdx.x;
+  const int H = p.H, W = p.W;
+
+  for (int e = tid; e < CIN * 9 * COUT; e += NTB) {  // folded weights [tap][ci][co] -> [ci][tap][co]
+    const int co = e % COUT, tap = (e / COUT) % 9, ci = e / (9 * COUT);
+    wl[ci][tap * COUT + co] = p.w[(tap * CIN + ci) * COUT + co];
+  }
+  // stage the (TH+2) x (TW+2) x CIN input patch: tile column c <-> image column tx0 - 1 + c
+  constexpr int TOTAL = CIN * (TH + 2) * TWP;
+  constexpr int SU = 8;
+  for (int base = 0; base < TOTAL; base += NTB * SU) {
+    float vals[SU];
+#pragma unroll
+    for (int u = 0; u < SU; u++) {
+      const int e = base + u * NTB + tid;
+      float v = 0.f;
+      if (e < TOTAL) {
+        const int c = e % TWP, r = (e / TWP) % (TH + 2), ci = e / (TWP * (TH + 2));
+        const int gy = ty0 - 1 + r, gx = tx0 - 1 + c;
+        if (c < TW + 2 && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+          if (MODE == 0) {
+            v = p.in[(((size_t)img * CIN + ci) * H + gy) * W + gx];
+          } else {
+            const int cell = gy * W + gx;
+            v = (float)((p.bits[ci][(size_t)img * ((PS * PS) >> 5) + (cell >> 5)] >> (cell & 31)) & 1u);
+          }
+        }
+      }
+      vals[u] = v;
+    }
+#pragma unroll
+    for (int u = 0; u < SU; u++) {
+      const int e = base + u * NTB + tid;
+      if (e < TOTAL) (&tile[0][0][0])[e] = vals[u];
+    }
+  }
+  __syncthreads();
+  if (tid >= NT) return;
+  const int tr = tid / (TW / 4), tc = tid - tr * (TW / 4);
+
+  float acc[2][4][COUT];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int co = 0; co < COUT; co++) acc[i][j][co] = 0.f;
+
+#pragma unroll 1
+  for (int ci = 0; ci < CIN; ci++) {
+    float v[4][8];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {  // cols 4tc .. 4tc+5 of the tile: two aligned b128 reads (conflict free)
+      const float4 lo = *reinterpret_cast<const float4 *>(&tile[ci][2 * tr + r][4 * tc]);
+      const float4 hi = *reinterpret_cast<const float4 *>(&tile[ci][2 * tr + r][4 * tc + 4]);
+      v[r][0] = lo.x; v[r][1] = lo.y; v[r][2] = lo.z; v[r][3] = lo.w; v[r][4] = hi.x; v[r][5] = hi.y;
+    }
+#pragma unroll
+    for (int dy = 0; dy < 3; dy++) {
+      float wv[3 * COUT];  // one tap row: 24 weights, broadcast reads
+#pragma unroll
+      for (int q = 0; q < 6; q++) {
+        const float4 t4 = *reinterpret_cast<const float4 *>(&wl[ci][dy * 3 * COUT + 4 * q]);
+        wv[4 * q] = t4.x; wv[4 * q + 1] = t4.y; wv[4 * q + 2] = t4.z; wv[4 * q + 3] = t4.w;
+      }
+#pragma unroll
+      for (int dx = 0; dx < 3; dx++)
+#pragma unroll
+        for (int co = 0; co < COUT; co++)
+#pragma unroll
+          for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+              acc[i][j][co] = __builtin_fmaf(v[i + dy][j + dx], wv[dx * COUT + co], acc[i][j][co]);
+    }
+  }
+
+  const int oy = ty0 + 2 * tr, ox = tx0 + 4 * tc;
+#pragma unroll
+  for (int co = 0; co < COUT; co++) {
+    const float bias = p.b[co];
+    float o[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) o[i][j] = fmaxf(acc[i][j][co] + bias, 0.f);
+    if (POOL) {
+      const float m0 = fmaxf(fmaxf(o[0][0], o[0][1]), fmaxf(o[1][0], o[1][1]));
+      const float m1 = fmaxf(fmaxf(o[0][2], o[0][3]), fmaxf(o[1][2], o[1][3]));
+      const int Ho = H >> 1, Wo = W >> 1, py = oy >> 1, px = ox >> 1;
+      if (OUT_HWC) {
+        p.out[(((size_t)img * Ho + py) * Wo + px) * COUT + co] = m0;
+        p.out[(((size_t)img * Ho + py) * Wo + px + 1) * COUT + co] = m1;
+      } else {
+        *reinterpret_cast<float2 *>(&p.out[(((size_t)img * COUT + co) * Ho + py) * Wo + px]) = make_float2(m0, m1);
+      }
+    } else {
+      float *op = p.out + (((size_t)img * COUT + co) * H + oy) * W + ox;
+      *reinterpret_cast<float4 *>(op) = make_float4(o[0][0], o[0][1], o[0][2], o[0][3]);
+      *reinterpret_cast<float4 *>(op + W) = make_float4(o[1][0], o[1][1], o[1][2], o[1][3]);
+    }
+  }
+}
+
 // ---- fp32 MFMA GEMM for the dense layers -------------------------------------------
 // C[M][N] = act(A[M][K] (lda) x B[K][N] (ldb) + bias[N])   one wave per 32x32 tile,
 // v_mfma_f32_32x32x2_f32: lane l holds A[row l&31][k l>>5], B[k l>>5][col l&31];
@@ -889,6 +1009,18 @@ static int launch_conv(ofx_handle *h, ConvParams p, int images, int H) {
   return OFX_OK;
 }
 
+template <int CIN, int TH, int TW, int MODE, bool POOL, bool OUT_HWC>
+static int launch_conv8(ofx_handle *h, ConvParams p, int images, int H) {
+  p.H = H; p.W = H;
+  p.tiles_x = H / TW;
+  p.tiles = p.tiles_x * (H / TH);
+  constexpr int NTB = ((TH / 2) * (TW / 4) + 63) / 64 * 64;
+  hipLaunchKernelGGL((k_conv8<CIN, TH, TW, MODE, POOL, OUT_HWC>), dim3((unsigned)(images * p.tiles)), dim3(NTB), 0,
+                     h->stream, p);
+  OFX_HIP(hipGetLastError());
+  return OFX_OK;
+}
+
 static int launch_gemm(ofx_handle *h, const float *A, int lda, const float *B, int ldb, const float *bias, float *C,
                        int ldc, int M, int N, int K, int relu) {
   const int tiles = ((M + 31) / 32) * ((N + 31) / 32);
@@ -942,7 +1074,7 @@ extern "C" int ofx_policy_forward(ofx_handle *h, const float *weights, const uin
   cp.bits[0] = (const unsigned *)h->maps[OFX_MAP_BITS_LSB][0];
   cp.bits[1] = (const unsigned *)h->maps[OFX_MAP_BITS_LSB][1];
   cp.w = ws.prep + L.tw[0]; cp.b = ws.prep + L.tb[0]; cp.out = ws.p1;
-  if ((rc = launch_conv<2, 8, 16, 80, 1, true, false>(h, cp, N, 400))) return rc;
+  if ((rc = launch_conv8<2, 20, 100, 1, true, false>(h, cp, N, 400))) return rc;
   cp.in = ws.p1; cp.w = ws.prep + L.tw[1]; cp.b = ws.prep + L.tb[1]; cp.out = ws.p2;
   if ((rc = launch_conv<8, 8, 10, 100, 0, true, false>(h, cp, N, 200))) return rc;
   cp.in = ws.p2; cp.w = ws.prep + L.tw[2]; cp.b = ws.prep + L.tb[2]; cp.out = ws.p3;
@@ -980,8 +1112,14 @@ extern "C" int ofx_policy_forward(ofx_handle *h, const float *weights, const uin
     ht.w4eff = ws.prep + L.w4eff_c; ht.w4raw = ws.prep + L.w4raw; ht.b4 = ws.prep + L.b4;
     ht.mask = ship_mask; ht.best = ws.best; ht.heat = heatmap;
     constexpr int tiles = (HT_S3 / HT_T) * (HT_S3 / HT_T);
+    const int pb = h->prof_base;
+    if (pb >= 0 && (rc = ofx_event_record(h, pb))) return rc;
     hipLaunchKernelGGL(k_head_tail, dim3((unsigned)(S * tiles)), dim3(256), 0, h->stream, ht);
     OFX_HIP(hipGetLastError());
+    if (pb >= 0) {
+      if ((rc = ofx_event_record(h, pb + 1))) return rc;
+      h->prof_base = pb + 2;
+    }
   } else {
     up.in = ws.up2; up.w = ws.prep + L.uw[2]; up.b = ws.prep + L.ub[2]; up.out = ws.up3;
     if ((rc = launch_conv<4, 8, 10, 100, 2, false, false>(h, up, S, 200))) return rc;

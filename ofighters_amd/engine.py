@@ -309,3 +309,6 @@ class ArenaBatch:
     def maps_f64(self):
         sm, lm = self.maps_host(nat.MAP_U8)
         return sm.astype(np.float64), lm.astype(np.float64)
+
+    def policy_profile(self, event_base):
+        nat.check(nat.lib().ofx_policy_profile(self._h, event_base))
