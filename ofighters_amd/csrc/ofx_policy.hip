@@ -633,6 +633,7 @@ struct HeadTailParams {
   const uint8_t *mask;
   unsigned long long *best;
   float *heat;
+  int ablate;                  // diagnostics (OFX_HT_ABLATE): 1 no stage-A loads, 2 no stage B, 4 no stage C, 8 no border passes
 };
 
 constexpr int HT_T = 40;              // uprelu3 tile side
@@ -699,7 +700,7 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
       const int e = u * 256 + tid;
       const int c = e % HT_L2, r = (e / HT_L2) % HT_L2, ci = e / (HT_L2 * HT_L2);
       const int gi = min(max(ib + r, 0), HT_S2 - 1), gj = min(max(jb + c, 0), HT_S2 - 1);
-      vals[u] = p.up2[(((size_t)s * 4 + ci) * HT_S2 + gi) * HT_S2 + gj];
+      vals[u] = (p.ablate & 1) ? 0.f : p.up2[(((size_t)s * 4 + ci) * HT_S2 + gi) * HT_S2 + gj];
     }
     const float wa = p.w4eff[tid], wb = tid < 32 ? p.w4eff[256 + tid] : 0.f;
 #pragma unroll
@@ -746,44 +747,58 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
   const unsigned framemask = (((top && pa3 == 0) ? 16u : 0u) | ((bot && pa3 == 1) ? 32u : 0u) |
                               ((lef && pb3 == 0) ? 64u : 0u) | ((rig && pb3 == 1) ? 128u : 0u)) << 12;
 
-  // stage-C ownership: 2 x 4 uprelu3 pixels per thread (200 of 256 threads)
-  const bool cthread = tid < (HT_T / 2) * (HT_T / 4);
-  const int tr = 2 * (tid / (HT_T / 4)), tc = 4 * (tid % (HT_T / 4));
-  float acc[2][4][4];  // [row][col][phase]
+  // stage-C ownership: a lane owns 4 horizontally adjacent uprelu3 pixels (one aligned b128 LDS read serves four
+  // MFMA B operands); 400 such lane-tasks per tile = pass 0 (all 256 lanes) + pass 1 (lanes 0..143).
+  // cacc[pass][pixel] = the 4 output phases of that pixel's heat-map quad.
+  constexpr int CT = (HT_T * HT_T) / 4;          // 400 lane-tasks
+  int coff[2];                                   // LDS offset of the task's window origin inside a channel plane
+  f32x4 cacc[2][4];
 #pragma unroll
-  for (int i = 0; i < 2; i++)
+  for (int q = 0; q < 2; q++) {
+    const int task = min(q * 256 + tid, CT - 1);
+    coff[q] = (task / (HT_T / 4)) * HT_U3P + 4 * (task % (HT_T / 4));
 #pragma unroll
-    for (int j = 0; j < 4; j++)
-#pragma unroll
-      for (int ph = 0; ph < 4; ph++) acc[i][j][ph] = 0.f;
+    for (int g = 0; g < 4; g++) cacc[q][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const bool pass1 = wv * 64 < CT - 256;         // wave-uniform: waves 0..2 have lanes in pass 1
 
 #pragma unroll 1
   for (int half = 0; half < 2; half++) {
     // ---- stage B: 4 channels of the uprelu3 tile on the matrix cores ----
-    {
+    if (!(p.ablate & 2)) {
       float bw[9];
 #pragma unroll
       for (int j = 0; j < 9; j++) bw[j] = p.w3mf[(half * 36 + 4 * j + kq) * 16 + n16];
       const float bias3 = p.b3[4 * half + cl3];
       float *ubase = &u3[0][0][0] + cell_off;
+      // two M-tiles per iteration, their MFMA chains interleaved (16x16x4: 32-cycle issue, 40-cycle dependent
+      // latency -> two independent accumulators keep the matrix pipe full)
 #pragma unroll 1
-      for (int mt = wv; mt < HT_MT; mt += 4) {
-        const int m0 = mt * 16;
-        const float *abase = &l2[kq * HT_L2P] + atab[m0 + n16];  // A row = quad m0 + (lane & 15), k = 4 j + kq
-        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+      for (int mt = wv; mt < HT_MT; mt += 8) {
+        const int m0 = mt * 16, m1 = min(mt + 4, HT_MT - 1) * 16;
+        const bool two = mt + 4 < HT_MT;  // wave-uniform
+        const float *a0 = &l2[kq * HT_L2P] + atab[m0 + n16];  // A row = quad m + (lane & 15), k = 4 j + kq
+        const float *a1 = &l2[kq * HT_L2P] + atab[m1 + n16];
+        f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 9; j++)  // tap j, channel kq
-          d = __builtin_amdgcn_mfma_f32_16x16x4f32(abase[(j / 3) * HT_L2 + (j % 3)], bw[j], d, 0, 0, 0);
-        // D: col = lane & 15, row = 4 (lane >> 4) + reg -> quads m0 + 4 kq .. + 3
-        const uint4 o4 = *reinterpret_cast<const uint4 *>(&otab[m0 + 4 * kq]);
-        const unsigned o[4] = {o4.x, o4.y, o4.z, o4.w};
+        for (int j = 0; j < 9; j++) {  // tap j, channel kq
+          d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[(j / 3) * HT_L2 + (j % 3)], bw[j], d0, 0, 0, 0);
+          d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[(j / 3) * HT_L2 + (j % 3)], bw[j], d1, 0, 0, 0);
+        }
+        // D: col = lane & 15, row = 4 (lane >> 4) + reg -> quads m + 4 kq .. + 3
+        const uint4 oa = *reinterpret_cast<const uint4 *>(&otab[m0 + 4 * kq]);
+        const uint4 ob = *reinterpret_cast<const uint4 *>(&otab[m1 + 4 * kq]);
+        const unsigned o0[4] = {oa.x, oa.y, oa.z, oa.w}, o1[4] = {ob.x, ob.y, ob.z, ob.w};
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-          if (!(o[i] & badmask)) ubase[o[i] & 0xFFFu] = fmaxf(d[i] + bias3, (o[i] & framemask) ? -INFINITY : 0.f);
+        for (int i = 0; i < 4; i++) {
+          if (!(o0[i] & badmask)) ubase[o0[i] & 0xFFFu] = fmaxf(d0[i] + bias3, (o0[i] & framemask) ? -INFINITY : 0.f);
+          if (two && !(o1[i] & badmask))
+            ubase[o1[i] & 0xFFFu] = fmaxf(d1[i] + bias3, (o1[i] & framemask) ? -INFINITY : 0.f);
+        }
       }
     }
     __syncthreads();
-    if (border) {
+    if (border && !(p.ablate & 8)) {
       // Frame cells (row/col 0 or 199 of the plane) hold G + bias without ReLU: subtract the taps that fall
       // into the conv's zero padding, sum w[tap][ci] U2[clamp] from the frame lines, then apply the ReLU.
       for (int e = tid; e < 4 * 2 * HT_U3; e += 256) {
@@ -870,36 +885,33 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
       }
     }
 
-    // ---- stage C: 4 channels of the heat-map quads on the VALU ----
-    if (cthread) {
-#pragma unroll 1
-      for (int cl = 0; cl < 4; cl++) {
-        float v[4][8];
+    // ---- stage C: 4 channels of the heat-map quads, also on the matrix cores.  Per output pixel the layer is
+    // out[phase] = sum_k in[k] W[k][phase], k = (channel, tap): v_mfma_f32_4x4x1_16B_f32 with CBSZ = 4 broadcasts the
+    // A block of lanes 0-3 (the 4 phase weights of tap k) to all 16 blocks, B = one input value per lane (pixel):
+    // D[phase][pixel] += W[k][phase] * in[pixel][k] -- an M = 4, N = 64, K = 1 step at the full f32 MFMA rate, with
+    // N = 4 phases exactly (no padding).  36 steps per half and group.
+    if (!(p.ablate & 4)) {
+      float wa[36];  // A operands: lane i < 4 holds phase i
 #pragma unroll
-        for (int r = 0; r < 4; r++) {  // two aligned b128 reads per row: bank-conflict free across the wave
-          const float4 lo = *reinterpret_cast<const float4 *>(&u3[cl][tr + r][tc]);
-          const float4 hi = *reinterpret_cast<const float4 *>(&u3[cl][tr + r][tc + 4]);
-          v[r][0] = lo.x; v[r][1] = lo.y; v[r][2] = lo.z; v[r][3] = lo.w;
-          v[r][4] = hi.x; v[r][5] = hi.y;
-        }
-        float wv4[36];
+      for (int k = 0; k < 36; k++) wa[k] = w4s[4 * half + k / 9][(lane & 3) * 9 + k % 9];
+      const float *ub = &u3[0][0][0];
 #pragma unroll
-        for (int q = 0; q < 9; q++) {
-          const float4 t4 = *reinterpret_cast<const float4 *>(&w4s[4 * half + cl][4 * q]);
-          wv4[4 * q] = t4.x; wv4[4 * q + 1] = t4.y; wv4[4 * q + 2] = t4.z; wv4[4 * q + 3] = t4.w;
-        }
+      for (int q = 0; q < 2; q++) {
+        if (q == 1 && !pass1) break;
 #pragma unroll
-        for (int ph = 0; ph < 4; ph++)
+        for (int cl = 0; cl < 4; cl++)
 #pragma unroll
-          for (int a = 0; a < 3; a++)
+          for (int a = 0; a < 3; a++) {
+            const float *row = ub + coff[q] + cl * HT_U3 * HT_U3P + a * HT_U3P;
+            const float4 lo = *reinterpret_cast<const float4 *>(row);
+            const float4 hi = *reinterpret_cast<const float4 *>(row + 4);
+            const float v[6] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y};
 #pragma unroll
-            for (int b = 0; b < 3; b++) {
-              const float wv = wv4[ph * 9 + a * 3 + b];
+            for (int b = 0; b < 3; b++)
 #pragma unroll
-              for (int i = 0; i < 2; i++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) acc[i][j][ph] = __builtin_fmaf(v[i + a][j + b], wv, acc[i][j][ph]);
-            }
+              for (int g = 0; g < 4; g++)  // 4 independent accumulator chains
+                cacc[q][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[cl * 9 + a * 3 + b], v[g + b], cacc[q][g], 4, 0, 0);
+          }
       }
     }
     __syncthreads();  // the tile is overwritten by the next half
@@ -909,16 +921,17 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
   float bestv = -INFINITY;
   unsigned bestk = 0xFFFFFFFFu;
   const float bias4 = p.b4[0];
-  if (cthread) {
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+  for (int q = 0; q < 2; q++) {
+    const int task = q * 256 + tid;
+    if (task < CT) {
+      const int li = r0 + task / (HT_T / 4), lj0 = c0 + 4 * (task % (HT_T / 4));
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int li = r0 + tr + i, lj = c0 + tc + j;
+      for (int g = 0; g < 4; g++)
 #pragma unroll
         for (int ph = 0; ph < 4; ph++) {
-          const int y = 2 * li + (ph >> 1), x = 2 * lj + (ph & 1);
-          float val = acc[i][j][ph] + bias4;
+          const int y = 2 * li + (ph >> 1), x = 2 * (lj0 + g) + (ph & 1);
+          float val = cacc[q][g][ph] + bias4;
           if (border) {
             if (y == 0 || y == PS - 1) val -= facc[0][x - 2 * c0];
             if (x == 0 || x == PS - 1) val -= facc[1][y - 2 * r0];
@@ -927,7 +940,7 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
           if (p.heat) p.heat[(size_t)s * PS * PS + k] = val;
           if (val > bestv || (val == bestv && k < bestk)) { bestv = val; bestk = k; }
         }
-      }
+    }
   }
   unsigned long long key = ((unsigned long long)ordered_f32(bestv) << 32) | (unsigned long long)(~bestk);
   if (bestk == 0xFFFFFFFFu) key = 0ull;
@@ -1111,6 +1124,7 @@ extern "C" int ofx_policy_forward(ofx_handle *h, const float *weights, const uin
     ht.w3mf = ws.prep + L.w3mf; ht.w3raw = ws.prep + L.uw[2]; ht.b3 = ws.prep + L.ub[2];
     ht.w4eff = ws.prep + L.w4eff_c; ht.w4raw = ws.prep + L.w4raw; ht.b4 = ws.prep + L.b4;
     ht.mask = ship_mask; ht.best = ws.best; ht.heat = heatmap;
+    { const char *e = getenv("OFX_HT_ABLATE"); ht.ablate = e ? atoi(e) : 0; }
     constexpr int tiles = (HT_S3 / HT_T) * (HT_S3 / HT_T);
     const int pb = h->prof_base;
     if (pb >= 0 && (rc = ofx_event_record(h, pb))) return rc;
