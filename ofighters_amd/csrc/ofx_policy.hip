@@ -682,32 +682,15 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
   __shared__ float facc[2][2 * HT_T];               // zero-padding corrections of the heat-map frame pixels
   __shared__ __align__(16) unsigned otab[512];      // quad -> (2qi-1)*U3P + (2qj-1) + 64 | flags << 12 (see below)
   __shared__ unsigned short atab[512];              // quad -> qi*L2 + qj (A-operand gather base)
-  constexpr int tiles_x = HT_S3 / HT_T, tiles = tiles_x * tiles_x;
-  const int s = blockIdx.x / tiles, t = blockIdx.x - s * tiles;
+  // one workgroup walks the 5 tiles of one tile row of one ship: tables, weights and launch cost are paid once
+  constexpr int tiles_x = HT_S3 / HT_T;
+  const int s = blockIdx.x / tiles_x, trow = blockIdx.x - s * tiles_x;
   if (p.mask && !p.mask[s]) return;  // block-uniform
-  const int r0 = (t / tiles_x) * HT_T, c0 = (t % tiles_x) * HT_T;  // uprelu3 coords of the tile
-  const int ib = r0 / 2 - 2, jb = c0 / 2 - 2;                      // uprelu2 coords of the patch origin
-  const bool top = r0 == 0, bot = r0 + HT_T == HT_S3, lef = c0 == 0, rig = c0 + HT_T == HT_S3;
-  const bool hline = top || bot, vline = lef || rig, border = hline || vline;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-
-  // ---- stage A: patch + tables + stage-C weights; all global loads in flight before the first LDS store ----
+  const int r0 = trow * HT_T, ib = r0 / 2 - 2;   // uprelu3 row of the tiles, uprelu2 row of the patch origin
+  const bool top = r0 == 0, bot = r0 + HT_T == HT_S3, hline = top || bot;
   {
-    constexpr int TOTAL = 4 * HT_L2 * HT_L2;  // 2304 = 9 x 256
-    float vals[TOTAL / 256];
-#pragma unroll
-    for (int u = 0; u < TOTAL / 256; u++) {
-      const int e = u * 256 + tid;
-      const int c = e % HT_L2, r = (e / HT_L2) % HT_L2, ci = e / (HT_L2 * HT_L2);
-      const int gi = min(max(ib + r, 0), HT_S2 - 1), gj = min(max(jb + c, 0), HT_S2 - 1);
-      vals[u] = (p.ablate & 1) ? 0.f : p.up2[(((size_t)s * 4 + ci) * HT_S2 + gi) * HT_S2 + gj];
-    }
     const float wa = p.w4eff[tid], wb = tid < 32 ? p.w4eff[256 + tid] : 0.f;
-#pragma unroll
-    for (int u = 0; u < TOTAL / 256; u++) {
-      const int e = u * 256 + tid;
-      l2[e + (e / (HT_L2 * HT_L2)) * 16] = vals[u];
-    }
     (&w4s[0][0])[tid] = wa;
     if (tid < 32) (&w4s[0][0])[256 + tid] = wb;
     for (int m = tid; m < 512; m += 256) {
@@ -720,7 +703,43 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
       otab[m] = (unsigned)((2 * qi - 1) * HT_U3P + (2 * qj - 1) + 64) | (f << 12);
       atab[m] = (unsigned short)(qi * HT_L2 + qj);
     }
+  }
+  float bestv = -INFINITY;
+  unsigned bestk = 0xFFFFFFFFu;
+  const float bias4 = p.b4[0];
+
+  // software pipeline over the row: the patch of tile t+1 is fetched from HBM while tile t computes
+  constexpr int PATCH = 4 * HT_L2 * HT_L2;  // 2304 = 9 x 256
+  int poff[PATCH / 256], prow[PATCH / 256], pcol[PATCH / 256];  // tile-independent part of the patch addressing
+#pragma unroll
+  for (int u = 0; u < PATCH / 256; u++) {
+    const int e = u * 256 + tid;
+    const int c = e % HT_L2, r = (e / HT_L2) % HT_L2, ci = e / (HT_L2 * HT_L2);
+    poff[u] = e + ci * 16;
+    prow[u] = (ci * HT_S2 + min(max(ib + r, 0), HT_S2 - 1)) * HT_S2;
+    pcol[u] = c;
+  }
+  const float *up2s = p.up2 + (size_t)s * 4 * HT_S2 * HT_S2;
+  float vals[PATCH / 256];
+#pragma unroll
+  for (int u = 0; u < PATCH / 256; u++) vals[u] = up2s[prow[u] + min(max(pcol[u] - 2, 0), HT_S2 - 1)];
+
+#pragma unroll 1
+  for (int tcol = 0; tcol < tiles_x; tcol++) {
+  const int c0 = tcol * HT_T, jb = c0 / 2 - 2;
+  const bool lef = c0 == 0, rig = c0 + HT_T == HT_S3;
+  const bool vline = lef || rig, border = hline || vline;
+
+  // ---- stage A: the prefetched uprelu2 patch goes to LDS; the next tile's loads are issued right away ----
+  {
+#pragma unroll
+    for (int u = 0; u < PATCH / 256; u++) l2[poff[u]] = vals[u];
     if (tid < 2 * 2 * HT_T) (&facc[0][0])[tid] = 0.f;
+    if (tcol + 1 < tiles_x) {
+      const int jn = (c0 + HT_T) / 2 - 2;
+#pragma unroll
+      for (int u = 0; u < PATCH / 256; u++) vals[u] = up2s[prow[u] + min(max(jn + pcol[u], 0), HT_S2 - 1)];
+    }
   }
   __syncthreads();
   if (border) {  // frame lines of the upsampled uprelu2 plane (block-uniform)
@@ -918,9 +937,6 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
   }
 
   // ---- outputs + arg-max (first maximum in C order) ----
-  float bestv = -INFINITY;
-  unsigned bestk = 0xFFFFFFFFu;
-  const float bias4 = p.b4[0];
 #pragma unroll
   for (int q = 0; q < 2; q++) {
     const int task = q * 256 + tid;
@@ -942,6 +958,9 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
         }
     }
   }
+  __syncthreads();  // facc / l2 are rewritten by the next tile
+  }  // tile loop
+
   unsigned long long key = ((unsigned long long)ordered_f32(bestv) << 32) | (unsigned long long)(~bestk);
   if (bestk == 0xFFFFFFFFu) key = 0ull;
 #pragma unroll
@@ -1125,10 +1144,9 @@ extern "C" int ofx_policy_forward(ofx_handle *h, const float *weights, const uin
     ht.w4eff = ws.prep + L.w4eff_c; ht.w4raw = ws.prep + L.w4raw; ht.b4 = ws.prep + L.b4;
     ht.mask = ship_mask; ht.best = ws.best; ht.heat = heatmap;
     { const char *e = getenv("OFX_HT_ABLATE"); ht.ablate = e ? atoi(e) : 0; }
-    constexpr int tiles = (HT_S3 / HT_T) * (HT_S3 / HT_T);
     const int pb = h->prof_base;
     if (pb >= 0 && (rc = ofx_event_record(h, pb))) return rc;
-    hipLaunchKernelGGL(k_head_tail, dim3((unsigned)(S * tiles)), dim3(256), 0, h->stream, ht);
+    hipLaunchKernelGGL(k_head_tail, dim3((unsigned)(S * (HT_S3 / HT_T))), dim3(256), 0, h->stream, ht);
     OFX_HIP(hipGetLastError());
     if (pb >= 0) {
       if ((rc = ofx_event_record(h, pb + 1))) return rc;
