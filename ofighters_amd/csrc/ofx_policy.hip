@@ -61,6 +61,8 @@ extern "C" int ofx_policy_layout(const ofx_handle *h, ofx_policy_desc *desc) {
 struct PrepLayout {
   int tw[4], tb[4];   // trunk folded kernels [9][cin][8], biases [8]
   int uw[3], ub[3];   // upconv1..3 folded
+  int bg[4];          // background response after trunk layer i ([8] each): the value every output channel takes
+                      // where the whole receptive window shows empty space
   int w3eff;          // [4 ci][4 phases][9 low-res taps][8 co]  (BN folded; VALU variant)
   int w3mf;           // [half 2][k = tap*4 + ci (36)][n = phase*4 + co_local (16)]  MFMA B operand
   int w4eff;          // [4 phases][9 low-res taps][8 ci] (v1 kernel)
@@ -75,12 +77,14 @@ static PrepLayout prep_layout() {
   int off = 0;
   for (int i = 0; i < 4; i++) { L.tw[i] = off; off += 9 * kTrunkCin[i] * 8; L.tb[i] = off; off += 8; }
   for (int i = 0; i < 3; i++) { L.uw[i] = off; off += 9 * kUpCin[i] * kUpCout[i]; L.ub[i] = off; off += kUpCout[i]; }
+  for (int i = 0; i < 4; i++) { L.bg[i] = off; off += 8; }
   L.w3eff = off; off += 4 * 9 * 4 * 8;
   L.w3mf = off; off += 36 * 32;
   L.w4eff = off; off += 4 * 9 * 8;
   L.w4eff_c = off; off += 8 * 4 * 9;
   L.w4raw = off; off += 72;
   L.b4 = off; off += 1;
+  off += 8;                      // 8 zeros: the background of conv1's binary input
   L.total = (off + 63) & ~63;
   return L;
 }
@@ -91,6 +95,7 @@ struct PrepParams {
   int src_k[7], src_b[7], src_g[7], cin[7], cout[7], dst_w[7], dst_b[7];
   int src_k4, src_b4, dst_w4eff, dst_w4raw, dst_b4;
   int dst_w3eff, dst_w4eff_c, dst_w3mf;
+  int dst_bg[4];
 };
 
 // interpolation coefficients of the x2 half-pixel bilinear: output row 2i+a, conv
@@ -130,6 +135,23 @@ __global__ void k_policy_prepare(PrepParams p) {
     p.prep[p.dst_w4eff_c + (ci * 4 + ph) * 9 + tap] = acc;
   }
   for (int e = tid; e < 72; e += blockDim.x) p.prep[p.dst_w4raw + e] = p.w[p.src_k4 + e];
+  // background chain of the trunk: an all-empty window (input 0) gives relu(b1') after layer 1, a window of that
+  // constant gives a constant after layer 2, ... -- same fma order (ci outer, tap inner) as the conv kernels, so
+  // the skipped waves write bit-identical values
+  __syncthreads();
+  if (tid < 8) {
+    float bgv[8];
+    for (int ci = 0; ci < 8; ci++) bgv[ci] = 0.f;
+    for (int l = 0; l < 4; l++) {
+      const int cin = p.cin[l];
+      float acc = 0.f;
+      for (int ci = 0; ci < cin; ci++)
+        for (int tap = 0; tap < 9; tap++) acc = __builtin_fmaf(bgv[ci], p.prep[p.dst_w[l] + (tap * cin + ci) * 8 + tid], acc);
+      const float o = fmaxf(acc + p.prep[p.dst_b[l] + tid], 0.f);
+      p.prep[p.dst_bg[l] + tid] = o;
+      for (int ci = 0; ci < 8; ci++) bgv[ci] = __shfl(o, ci, 8);
+    }
+  }
   // upconv3 (layer index 6): phase weights from the BN-folded kernel (folded in place, same thread order
   // would race with the fold above: recompute the fold here)
   {
@@ -157,6 +179,7 @@ struct ConvParams {
   const float *w, *b;              // folded [9][CIN][COUT], [COUT]
   float *out;                      // planar [img][COUT][Ho][Wo] or HWC [img][Ho][Wo][COUT]
   const uint8_t *mask;             // per image, may be null
+  const float *bg_in, *bg_out;     // background value per input / output channel (null = no background skip)
   int H, W;                        // conv domain (input after any upsampling) = conv output size
   int tiles_x, tiles;              // tiles per row / per image
 };
@@ -227,6 +250,23 @@ __global__ __launch_bounds__(((TH / 2) * (TW / 2) + 63) / 64 * 64) void k_conv(C
 #pragma unroll
       for (int co = 0; co < COUT; co++) acc[i][j][co] = 0.f;
 
+  // Background skip (wave-uniform): when every window of this wave lies inside the image and shows only the
+  // background value of each input channel, the outputs are the precomputed background response.
+  bool skip = false;
+  if (p.bg_in != nullptr) {
+    bool flat = ty0 + 2 * tr >= 1 && ty0 + 2 * tr + 2 < H && tx0 + 2 * tc >= 1 && tx0 + 2 * tc + 2 < W;
+    for (int ci = 0; ci < CIN && flat; ci++) {
+      const float bgv = p.bg_in[ci];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const float2 lo = *reinterpret_cast<const float2 *>(&tile[ci][2 * tr + r][2 * tc]);
+        const float2 hi = *reinterpret_cast<const float2 *>(&tile[ci][2 * tr + r][2 * tc + 2]);
+        flat = flat && lo.x == bgv && lo.y == bgv && hi.x == bgv && hi.y == bgv;
+      }
+    }
+    skip = __all(flat);
+  }
+  if (!skip) {
 #pragma unroll
   for (int ci = 0; ci < CIN; ci++) {
     float v[4][4];
@@ -249,6 +289,7 @@ __global__ __launch_bounds__(((TH / 2) * (TW / 2) + 63) / 64 * 64) void k_conv(C
             for (int j = 0; j < 2; j++) acc[i][j][co] = __builtin_fmaf(v[i + dy][j + dx], wv, acc[i][j][co]);
         }
   }
+  }
 
   // ---- epilogue: folded bias, ReLU, optional 2x2 max-pool ----
   const int oy = ty0 + 2 * tr, ox = tx0 + 2 * tc;
@@ -257,6 +298,7 @@ __global__ __launch_bounds__(((TH / 2) * (TW / 2) + 63) / 64 * 64) void k_conv(C
     const float bias = p.b[co];
     float o00 = fmaxf(acc[0][0][co] + bias, 0.f), o01 = fmaxf(acc[0][1][co] + bias, 0.f);
     float o10 = fmaxf(acc[1][0][co] + bias, 0.f), o11 = fmaxf(acc[1][1][co] + bias, 0.f);
+    if (skip) o00 = o01 = o10 = o11 = p.bg_out[co];
     if (POOL) {
       const float m = fmaxf(fmaxf(o00, o01), fmaxf(o10, o11));
       const int Ho = H >> 1, Wo = W >> 1, py = oy >> 1, px = ox >> 1;
@@ -334,8 +376,22 @@ __global__ __launch_bounds__(((TH / 2) * (TW / 4) + 63) / 64 * 64) void k_conv8(
 #pragma unroll
       for (int co = 0; co < COUT; co++) acc[i][j][co] = 0.f;
 
+  bool skip = false;  // background skip, see k_conv
+  if (p.bg_in != nullptr) {
+    bool flat = ty0 + 2 * tr >= 1 && ty0 + 2 * tr + 2 < H && tx0 + 4 * tc >= 1 && tx0 + 4 * tc + 4 < W;
+    for (int ci = 0; ci < CIN && flat; ci++) {
+      const float bgv = p.bg_in[ci];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const float4 lo = *reinterpret_cast<const float4 *>(&tile[ci][2 * tr + r][4 * tc]);
+        const float4 hi = *reinterpret_cast<const float4 *>(&tile[ci][2 * tr + r][4 * tc + 4]);
+        flat = flat && lo.x == bgv && lo.y == bgv && lo.z == bgv && lo.w == bgv && hi.x == bgv && hi.y == bgv;
+      }
+    }
+    skip = __all(flat);
+  }
 #pragma unroll 1
-  for (int ci = 0; ci < CIN; ci++) {
+  for (int ci = 0; ci < (skip ? 0 : CIN); ci++) {
     float v[4][8];
 #pragma unroll
     for (int r = 0; r < 4; r++) {  // cols 4tc .. 4tc+5 of the tile: two aligned b128 reads (conflict free)
@@ -371,7 +427,7 @@ __global__ __launch_bounds__(((TH / 2) * (TW / 4) + 63) / 64 * 64) void k_conv8(
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
-      for (int j = 0; j < 4; j++) o[i][j] = fmaxf(acc[i][j][co] + bias, 0.f);
+      for (int j = 0; j < 4; j++) o[i][j] = skip ? p.bg_out[co] : fmaxf(acc[i][j][co] + bias, 0.f);
     if (POOL) {
       const float m0 = fmaxf(fmaxf(o[0][0], o[0][1]), fmaxf(o[1][0], o[1][1]));
       const float m1 = fmaxf(fmaxf(o[0][2], o[0][3]), fmaxf(o[1][2], o[1][3]));
@@ -671,14 +727,12 @@ __device__ __forceinline__ float up1d(const float *line, int stride, int base, i
 constexpr int HT_L2P = HT_L2 * HT_L2 + 16;  // plane stride of the patch: +16 floats so the 4 channel planes of
                                             // the MFMA A-gather land on different LDS banks
 constexpr int HT_LB2 = HT_T + 4;            // frame-line length of stage B (x' in [c0-2, c0+T+1])
-constexpr int HT_LB4 = 2 * HT_T + 2;        // frame-line length of stage C (x' in [2c0-1, 2c0+2T])
 
 __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
   __shared__ __align__(16) float l2[4 * HT_L2P];
   __shared__ __align__(16) float u3[4][HT_U3][HT_U3P];
   __shared__ __align__(16) float w4s[8][36];
   __shared__ float hb2[4][HT_LB2], vb2[4][HT_LB2];  // U2[0|199][x'] , U2[y'][0|199]  (border tiles)
-  __shared__ float hb4[4][HT_LB4], vb4[4][HT_LB4];  // U3 lines of the current channel half
   __shared__ float facc[2][2 * HT_T];               // zero-padding corrections of the heat-map frame pixels
   __shared__ __align__(16) unsigned otab[512];      // quad -> (2qi-1)*U3P + (2qj-1) + 64 | flags << 12 (see below)
   __shared__ unsigned short atab[512];              // quad -> qi*L2 + qj (A-operand gather base)
@@ -849,55 +903,40 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
             for (int ci = 0; ci < 4; ci++) corr += w[(((dy + 1) * 3 + tcol) * 4 + ci) * 8] * vb2[ci][uy - (r0 - 2)];
           }
         }
-        float *cell = &u3[cl][y - (r0 - 1)][x - (c0 - 1)];
-        *cell = fmaxf(*cell - corr, 0.f);
+        const int ty = y - (r0 - 1), tx = x - (c0 - 1);
+        const float v = fmaxf(u3[cl][ty][tx] - corr, 0.f);
+        u3[cl][ty][tx] = v;
+        // the halo cells outside the image are clamp copies of exactly these frame cells
+        const int oy = (y == 0) ? -1 : (y == HT_S3 - 1) ? 1 : 0, ox = (x == 0) ? -1 : (x == HT_S3 - 1) ? 1 : 0;
+        if (oy) u3[cl][ty + oy][tx] = v;
+        if (ox) u3[cl][ty][tx + ox] = v;
+        if (oy && ox) u3[cl][ty + oy][tx + ox] = v;
       }
       __syncthreads();
-      // halo cells outside the image = clamp extension (their sources are inside the image)
-      for (int e = tid; e < 4 * 4 * HT_U3; e += 256) {
-        const int k = e % HT_U3, side = (e / HT_U3) & 3, cl = e / (4 * HT_U3);
-        const int ty = side == 0 ? 0 : side == 1 ? HT_U3 - 1 : k, tx = side == 2 ? 0 : side == 3 ? HT_U3 - 1 : k;
-        const int y = r0 - 1 + ty, x = c0 - 1 + tx;
-        if (y < 0 || y >= HT_S3 || x < 0 || x >= HT_S3) {
-          const int cy = min(max(y, 0), HT_S3 - 1), cx = min(max(x, 0), HT_S3 - 1);
-          u3[cl][ty][tx] = u3[cl][cy - (r0 - 1)][cx - (c0 - 1)];
-        }
-      }
-      __syncthreads();
-      // frame lines of the upsampled uprelu3 plane for these 4 channels
-      for (int e = tid; e < 2 * 4 * HT_LB4; e += 256) {
-        const int k = e % HT_LB4, cl = (e / HT_LB4) & 3, line = e / (4 * HT_LB4);
-        if (line == 0 && hline) {
-          const int R = top ? 0 : HT_S3 - 1, xc = min(max(2 * c0 - 1 + k, 0), PS - 1);
-          hb4[cl][k] = up1d(&u3[cl][R - (r0 - 1)][0], 1, c0 - 1, xc);
-        } else if (line == 1 && vline) {
-          const int Cc = lef ? 0 : HT_S3 - 1, yc = min(max(2 * r0 - 1 + k, 0), PS - 1);
-          vb4[cl][k] = up1d(&u3[cl][0][Cc - (c0 - 1)], HT_U3P, r0 - 1, yc);
-        }
-      }
-      __syncthreads();
-      // corrections of the heat-map frame pixels of this tile, accumulated over the two halves:
-      // facc[0][k] for (y in {0,399}, x = 2c0 + k) ; facc[1][k] for (y = 2r0 + k, x in {0,399}), rows counted once
+      // zero-padding corrections of the heat-map frame pixels of this tile, accumulated over the two halves:
+      // facc[0][k] for (y in {0,399}, x = 2c0 + k) ; facc[1][k] for (y = 2r0 + k, x in {0,399}), rows counted once.
+      // U3[row 0|399][x'] is an x-lerp of the (clamp-extended) tile row 0|199, U3[y'][col 0|399] a y-lerp.
       for (int e = tid; e < 2 * 2 * HT_T; e += 256) {
         const int k = e % (2 * HT_T), line = e / (2 * HT_T);
         const float *w = p.w4raw + 4 * half;
         float corr = 0.f;
         if (line == 0 && hline) {
-          const int trow = top ? 0 : 2, x = 2 * c0 + k;
+          const int trow = top ? 0 : 2, x = 2 * c0 + k, R = (top ? 0 : HT_S3 - 1) - (r0 - 1);
 #pragma unroll
           for (int dx = -1; dx <= 1; dx++) {
-            const int xx = min(max(x + dx, 0), PS - 1) - (2 * c0 - 1);
+            const int xc = min(max(x + dx, 0), PS - 1);
 #pragma unroll
-            for (int cl = 0; cl < 4; cl++) corr += w[(trow * 3 + dx + 1) * 8 + cl] * hb4[cl][xx];
+            for (int cl = 0; cl < 4; cl++) corr += w[(trow * 3 + dx + 1) * 8 + cl] * up1d(&u3[cl][R][0], 1, c0 - 1, xc);
           }
         } else if (line == 1 && vline) {
-          const int tcol = lef ? 0 : 2, y = 2 * r0 + k;
+          const int tcol = lef ? 0 : 2, y = 2 * r0 + k, Cc = (lef ? 0 : HT_S3 - 1) - (c0 - 1);
 #pragma unroll
           for (int dy = -1; dy <= 1; dy++) {
             const int uy = y + dy;
             if (uy < 0 || uy >= PS) continue;
 #pragma unroll
-            for (int cl = 0; cl < 4; cl++) corr += w[((dy + 1) * 3 + tcol) * 8 + cl] * vb4[cl][uy - (2 * r0 - 1)];
+            for (int cl = 0; cl < 4; cl++)
+              corr += w[((dy + 1) * 3 + tcol) * 8 + cl] * up1d(&u3[cl][0][Cc], HT_U3P, r0 - 1, uy);
           }
         }
         facc[line][k] += corr;
@@ -1085,6 +1124,7 @@ extern "C" int ofx_policy_forward(ofx_handle *h, const float *weights, const uin
   if ((rc = ofx_launch_raster(h, OFX_MAP_BITS_LSB, nullptr, nullptr))) return rc;
   PrepParams pp;
   pp.w = weights; pp.prep = ws.prep;
+  OFX_HIP(hipMemsetAsync(ws.prep + L.total - 64, 0, 64 * sizeof(float), h->stream));
   for (int i = 0; i < 4; i++) {
     pp.src_k[i] = off[6 * i]; pp.src_b[i] = off[6 * i + 1]; pp.src_g[i] = off[6 * i + 2];
     pp.cin[i] = kTrunkCin[i]; pp.cout[i] = 8; pp.dst_w[i] = L.tw[i]; pp.dst_b[i] = L.tb[i];
@@ -1097,6 +1137,7 @@ extern "C" int ofx_policy_forward(ofx_handle *h, const float *weights, const uin
   pp.src_k4 = off[t_u4]; pp.src_b4 = off[t_u4 + 1];
   pp.dst_w4eff = L.w4eff; pp.dst_w4raw = L.w4raw; pp.dst_b4 = L.b4;
   pp.dst_w3eff = L.w3eff; pp.dst_w4eff_c = L.w4eff_c; pp.dst_w3mf = L.w3mf;
+  for (int i = 0; i < 4; i++) pp.dst_bg[i] = L.bg[i];
   hipLaunchKernelGGL(k_policy_prepare, dim3(1), dim3(256), 0, h->stream, pp);
   OFX_HIP(hipGetLastError());
 
@@ -1105,13 +1146,20 @@ extern "C" int ofx_policy_forward(ofx_handle *h, const float *weights, const uin
   memset(&cp, 0, sizeof(cp));
   cp.bits[0] = (const unsigned *)h->maps[OFX_MAP_BITS_LSB][0];
   cp.bits[1] = (const unsigned *)h->maps[OFX_MAP_BITS_LSB][1];
+  // opt-in: pays off on sparse scenes only (measured: with policy-driven play the maps are full of lasers
+  // and the window checks cost more than they save)
+  const bool bgskip = getenv("OFX_POLICY_BG_SKIP") != nullptr;
   cp.w = ws.prep + L.tw[0]; cp.b = ws.prep + L.tb[0]; cp.out = ws.p1;
+  if (bgskip) { cp.bg_in = ws.prep + L.total - 8; cp.bg_out = ws.prep + L.bg[0]; }  // the 8 pad floats are zero
   if ((rc = launch_conv8<2, 20, 100, 1, true, false>(h, cp, N, 400))) return rc;
   cp.in = ws.p1; cp.w = ws.prep + L.tw[1]; cp.b = ws.prep + L.tb[1]; cp.out = ws.p2;
+  if (bgskip) { cp.bg_in = ws.prep + L.bg[0]; cp.bg_out = ws.prep + L.bg[1]; }
   if ((rc = launch_conv<8, 8, 10, 100, 0, true, false>(h, cp, N, 200))) return rc;
   cp.in = ws.p2; cp.w = ws.prep + L.tw[2]; cp.b = ws.prep + L.tb[2]; cp.out = ws.p3;
+  if (bgskip) { cp.bg_in = ws.prep + L.bg[1]; cp.bg_out = ws.prep + L.bg[2]; }
   if ((rc = launch_conv<8, 8, 10, 100, 0, true, false>(h, cp, N, 100))) return rc;
   cp.in = ws.p3; cp.w = ws.prep + L.tw[3]; cp.b = ws.prep + L.tb[3]; cp.out = ws.p4;
+  cp.bg_in = nullptr; cp.bg_out = nullptr;
   if ((rc = launch_conv<8, 8, 10, 50, 0, true, true>(h, cp, N, 50))) return rc;  // (h,w,c) = Flatten order
 
   // 2. dense1: trunk features on MFMA once per arena; head + head-1 per ship

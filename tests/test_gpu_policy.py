@@ -94,3 +94,21 @@ def test_policy_determinism_and_trunk_sharing():
     for k in a1:
         assert np.array_equal(a1[k], a2[k])
     b.close()
+
+
+def test_background_skip_is_bit_identical():
+    """Waves whose receptive windows show only empty space write the precomputed background response instead of
+    running the FMAs; the prepare kernel uses the conv kernels' fma order, so both paths agree bit for bit."""
+    import os
+    from oracle import pyoracle
+    b = _rollout(4, 8, seed=8, ticks=30)
+    w, _ = pyoracle.policy_init(6, trained_like=True)
+    slow = b.policy_forward_host(w, want_heat=True)
+    os.environ["OFX_POLICY_BG_SKIP"] = "1"     # opt-in (only pays off on sparse scenes)
+    try:
+        fast = b.policy_forward_host(w, want_heat=True)
+    finally:
+        del os.environ["OFX_POLICY_BG_SKIP"]
+    for k in fast:
+        assert np.array_equal(fast[k], slow[k]), k
+    b.close()
