@@ -91,13 +91,14 @@ def main():
     import torch
 
     dist = None
-    if world > 1:
+    local_rank %= max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local_rank)
+    if world > 1 or "RANK" in os.environ:
+        # launched by torch.distributed.run: one process per GPU, RCCL ("nccl") over xGMI
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
 
     from ofighters_amd import ArenaBatch, _native as nat
 
