@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--ships", type=int, default=8)
     ap.add_argument("--workload", default="step+obs+policy", choices=["step", "step+obs", "step+obs+policy"])
     ap.add_argument("--policy-ships", type=int, default=-1, help="ships per arena driven by the bi-head policy (-1 = all)")
+    ap.add_argument("--policy-alive-only", action="store_true",
+                    help="skip the forward of destroyed ships (QlearnIA.play returns None once done, "
+                         "agents/qlearnIA_V2.py:372-377); NOT the headline configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -119,6 +122,12 @@ def main():
             mk = np.zeros((N, M), np.uint8)
             mk[:, :n_pol] = 1
             mask_dev = torch.from_numpy(mk).cuda()
+        if args.policy_alive_only:
+            # the engine's own alive flags [N][M] uint8 serve as the ship mask: zero extra work
+            class _AliveMask:
+                def data_ptr(self_inner):
+                    return b.device_ptr(nat.F_SHIP_ALIVE)
+            mask_dev = _AliveMask()
     scores = torch.zeros(M + 1, dtype=torch.int64, device="cuda")
     torch.cuda.synchronize()  # the handle's stream is non-blocking w.r.t. torch's
     score_log = []
@@ -197,8 +206,11 @@ def main():
         # dominant kernel: k_head_tail = [x2 bilinear + conv 4->8 + BN + ReLU] + [x2 bilinear + conv 8->1] + arg-max
         # per policy ship: 200*200*4*9*8 + 400*400*8*9*1 = 23.04 MMAC, dense, no sparsity credit
         kernel = "k_head_tail"
-        alg_flops = N * n_pol * 2.0 * 23.04e6
-        whole_forward_flops = N * 2.0 * (53.28e6 + n_pol * 24.37e6)
+        n_eff = n_pol
+        if args.policy_alive_only:   # forwards actually run ~ mean number of playable ships (sampled at the end)
+            n_eff = float(b.get(nat.F_SHIP_ALIVE).mean()) * M
+        alg_flops = N * n_eff * 2.0 * 23.04e6
+        whole_forward_flops = N * 2.0 * (53.28e6 + n_eff * 24.37e6)
         achieved = alg_flops / (k_avg_ms * 1e-3) / 1e12
         roof_unit, roof_peak, roof_bound = "TFLOP/s", 157.3, "mfma"
         roof_note = ("fp32 (exact f32-input MFMA + fp32 VALU, both 157.3 TFLOP/s peak); whole tick = %.0f GFLOP dense "
@@ -231,7 +243,8 @@ def main():
             "workload": ("%d arenas x %d ships per GPU, random-bot actions + step" % (N, M))
                         + (" + 2D obs rasterise (u8 maps)" if do_obs else "")
                         + ((" + bi-head policy forward for %d ship(s)/arena, trunk shared per arena (BASELINE configs[3])"
-                            % n_pol) if do_policy else "; no policy forward (BASELINE configs[%d])" % (2 if do_obs else 1)),
+                            % n_pol) + (" (destroyed ships skipped)" if do_policy and args.policy_alive_only else "")
+                           if do_policy else "; no policy forward (BASELINE configs[%d])" % (2 if do_obs else 1)),
             "arenas_per_gpu": N, "ships": M, "laser_cap": b.L, "episode_ticks": ep_ticks,
             "parallelism": "arena-sharded x%d, RCCL all-reduce of episodic scores only" % world,
             "laser_overflow": overflow,
