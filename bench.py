@@ -25,35 +25,6 @@ SEED = 0x0F160001
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def synth_policy_weights(b, seed):
-    """he_uniform convs, glorot_uniform dense, zero bias, BN gamma=1 beta=0 mean=0 var=1: the state of
-    the reference's model right after construction (agents/qlearnIA_V2.py:129-186)."""
-    import numpy as np
-    off, cnt, total = b.policy_layout()
-    rs = np.random.RandomState(seed & 0x7FFFFFFF)
-    w = np.zeros(total, np.float32)
-    cin = [2, 8, 8, 8]
-    t = 0
-
-    def uni(n, lim):
-        return rs.uniform(-lim, lim, n).astype(np.float32)
-    for i in range(4):
-        w[off[t]:off[t] + cnt[t]] = uni(cnt[t], np.sqrt(6.0 / (9 * cin[i])))
-        w[off[t + 2]:off[t + 2] + 8] = 1.0
-        w[off[t + 5]:off[t + 5] + 8] = 1.0
-        t += 6
-    for fi, fo in ((5008, 100), (100, 50), (50, 2), (100, 625)):
-        w[off[t]:off[t] + cnt[t]] = uni(cnt[t], np.sqrt(6.0 / (fi + fo)))
-        t += 2
-    for ci, co in ((1, 2), (2, 4), (4, 8)):
-        w[off[t]:off[t] + cnt[t]] = uni(cnt[t], np.sqrt(6.0 / (9 * ci)))
-        w[off[t + 2]:off[t + 2] + co] = 1.0
-        w[off[t + 5]:off[t + 5] + co] = 1.0
-        t += 6
-    w[off[t]:off[t] + cnt[t]] = uni(cnt[t], np.sqrt(6.0 / 72))
-    return w
-
-
 def cpu_policy_sample(pyoracle, cfg, w, n_arenas, ticks, n_pol, seed):
     """CPU-oracle leg of the full workload: per tick and arena, n_pol policy forwards (the oracle has no
     trunk sharing: one full forward per ship, like the reference), step, rasterise."""
@@ -115,7 +86,8 @@ def main():
     if do_policy:
         # synthetic he_uniform / glorot_uniform weights of the pointer_model architecture (no checkpoint
         # ships with the reference); seed 0x0F160002
-        w_host = synth_policy_weights(b, 0x0F160002)
+        from ofighters_amd.agents.policy_weights import synthetic
+        w_host = synthetic(0x0F160002)
         w_dev = torch.from_numpy(w_host).cuda()
         mask_dev = None
         if n_pol < M:

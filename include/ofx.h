@@ -250,6 +250,13 @@ int ofx_policy_layout(const ofx_handle *h, ofx_policy_desc *desc_host);
 int ofx_policy_forward(ofx_handle *h, const float *weights, const uint8_t *ship_mask,
                        float *act_values, int32_t *iaction, int32_t *ipointer,
                        float *heatmap);
+/* Exploration of the bi-head action space (Trainer.get_best_action epsilon branch, agents/qlearnIA_V2.py:199-204,
+ * and the collecting phase :393-395): for every selected ship, with probability `epsilon` - or always when
+ * `collecting` != 0 - replace (iaction, ipointer) by random_play() (:317-321): iaction = randint(0, 1),
+ * ipointer = (randint(0, W-1), randint(0, H-1)).  Draws: Philox4x32-10 keyed by `seed`, counter
+ * (global arena, ship, tick, stream 2).  NULL iaction / ipointer = the handle's workspace results.             */
+int ofx_policy_explore(ofx_handle *h, double epsilon, uint64_t seed, uint32_t tick, int32_t collecting,
+                       const uint8_t *ship_mask, int32_t *iaction, int32_t *ipointer);
 /* QlearnIA.play action packing (qlearnIA_V2.py:447-454): exactly one of
  * shoot/thrust set, pointer always set.                                      */
 int ofx_policy_actions(ofx_handle *h, const int32_t *iaction, const int32_t *ipointer,

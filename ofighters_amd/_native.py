@@ -90,6 +90,7 @@ SIGNATURES = {
     "ofx_policy_layout": (_i, [_vp, C.POINTER(OfxPolicyDesc)]),
     "ofx_policy_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ofx_policy_actions": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "ofx_policy_explore": (_i, [_vp, C.c_double, _u64, _u32, C.c_int32, _vp, _vp, _vp]),
     "ofx_timer_start": (_i, [_vp]),
     "ofx_timer_stop": (_i, [_vp, C.POINTER(C.c_float)]),
     "ofx_event_record": (_i, [_vp, C.c_int32]),

@@ -1378,6 +1378,43 @@ extern "C" int ofx_policy_forward(ofx_handle *h, const float *weights, const uin
   return OFX_OK;
 }
 
+#define OFX_STREAM_EXPLORE 2u
+__global__ void k_policy_explore(int N, int M, int W, int H, int arena_base, double eps, uint32_t k0, uint32_t k1,
+                                 uint32_t tick, int collecting, const uint8_t *mask, int32_t *iaction, int32_t *ipointer) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= N * M || (mask && !mask[s])) return;
+  const int a = s / M, i = s - a * M;
+  uint32_t r[4];
+  ofx_philox4x32_10((uint32_t)(arena_base + a), (uint32_t)i, tick, OFX_STREAM_EXPLORE, k0, k1, r);
+  const double u = (double)r[0] * (1.0 / 4294967296.0);
+  if (collecting || u <= eps) {  // np.random.rand() <= epsilon (qlearnIA_V2.py:201)
+    iaction[s] = ofx_draw_int(r[1], 1);
+    ipointer[2 * s] = ofx_draw_int(r[2], W - 1);
+    ipointer[2 * s + 1] = ofx_draw_int(r[3], H - 1);
+  }
+}
+
+extern "C" int ofx_policy_explore(ofx_handle *h, double epsilon, uint64_t seed, uint32_t tick, int32_t collecting,
+                                  const uint8_t *ship_mask, int32_t *iaction, int32_t *ipointer) {
+  if (!h) { ofx_set_error("ofx_policy_explore: null handle"); return OFX_ERR_INVALID; }
+  if (!h->spawned) { ofx_set_error("ofx_policy_explore before ofx_spawn"); return OFX_ERR_STATE; }
+  if (epsilon < 0.0 || epsilon > 1.0) { ofx_set_error("Value must me in range [0,1]"); return OFX_ERR_INVALID; }  // epsilon.py:56
+  OFX_HIP(hipSetDevice(h->cfg.device));
+  if (!iaction || !ipointer) {
+    PolicyWs ws;
+    int rc = policy_workspace(h, &ws);
+    if (rc) return rc;
+    if (!iaction) iaction = ws.iaction;
+    if (!ipointer) ipointer = ws.ipointer;
+  }
+  const int S = h->cfg.n_arenas * h->cfg.n_ships;
+  hipLaunchKernelGGL(k_policy_explore, dim3((S + 255) / 256), dim3(256), 0, h->stream, h->cfg.n_arenas, h->cfg.n_ships,
+                     h->cfg.width, h->cfg.height, h->cfg.arena_base, epsilon, (uint32_t)seed, (uint32_t)(seed >> 32), tick,
+                     collecting, ship_mask, iaction, ipointer);
+  OFX_HIP(hipGetLastError());
+  return OFX_OK;
+}
+
 extern "C" int ofx_policy_actions(ofx_handle *h, const int32_t *iaction, const int32_t *ipointer,
                                   const uint8_t *ship_mask, ofx_action *actions) {
   if (!h || !actions) { ofx_set_error("ofx_policy_actions: null argument"); return OFX_ERR_INVALID; }

@@ -312,3 +312,9 @@ class ArenaBatch:
 
     def policy_profile(self, event_base):
         nat.check(nat.lib().ofx_policy_profile(self._h, event_base))
+
+    def policy_explore(self, epsilon, seed, tick=None, collecting=False, ship_mask_ptr=None, iaction_ptr=None,
+                       ipointer_ptr=None):
+        """epsilon-greedy / collecting-phase random play over the last forward's results."""
+        nat.check(nat.lib().ofx_policy_explore(self._h, float(epsilon), seed, self.tick if tick is None else tick,
+                                               int(bool(collecting)), ship_mask_ptr, iaction_ptr, ipointer_ptr))

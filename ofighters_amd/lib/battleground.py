@@ -51,7 +51,11 @@ class Ship:
         self.can_shoot = 1
         self.player = None
         self.laser_speed = 10
-        self.agent = Agent(behavior, bot=bot)
+        if behavior == "QlearnIA":          # lib/ship.py:69-74
+            from ..agents.qlearn import QlearnIA
+            self.agent = QlearnIA()
+        else:
+            self.agent = Agent(behavior, bot=bot)
 
     def is_playable(self):
         return self.state not in ["destroyed", "wreckage"]
@@ -141,6 +145,15 @@ class Battleground:
         self.lasers = [Laser(float(st["lx"][0, j]), float(st["ly"][0, j]), self.ships[int(st["lowner"][0, j])],
                              bool(st["ldead"][0, j])) for j in range(n)]
         self._maps_cache = None
+
+    def _policy_forward(self, ship, weights):
+        """One bi-head forward for `ship` (batch of one, like model.predict in qlearnIA_V2.py:210)."""
+        M = len(self.ships)
+        mask = np.zeros((1, M), np.uint8)
+        i = self.ships.index(ship)
+        mask[0, i] = 1
+        out = self._e.policy_forward_host(weights, ship_mask=mask)
+        return dict(act=out["act"][0, i], iaction=out["iaction"][0, i], ipointer=out["ipointer"][0, i])
 
     # ------------------------------------------------------------------ reference API
     def outside(self, x, y):

@@ -36,6 +36,7 @@ class Observation:
         self.pointing = None
         self.pos = None
         self.done = None
+        self._ship = None
         battleground = kwargs.get("battleground")
         ship = kwargs.get("ship")
         if battleground:
@@ -51,6 +52,7 @@ class Observation:
 
     def analyse_ship(self, ship):
         """Must be executed after analyse_battleground"""
+        self._ship = ship
         self.reward = ship.agent.reward
         self.can_shoot = 0 if ship.can_shoot == 0 else 1
         self.pointing = ship.pointing

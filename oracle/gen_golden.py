@@ -13,6 +13,7 @@ input/output fixtures for the hot path into tests/golden/*.npz:
   geometry.npz      Ship.thrust / Circle.edge / enemy_aimed / enemy_on_trajectory
                     on random integer configurations          (ship.py:134-222)
   scratch_nn.npz    Neural_network.feed                       (neural_network.py:396-420)
+  epsilon.npz       Epsilon_cos / Epsilon_decay sequences     (lib/epsilon.py:36-86)
 
 keras / tensorflow are absent from every interpreter in this image and are not
 on the recorded path (scripted bots only); they are replaced by inert
@@ -425,6 +426,25 @@ def scratch_nn_cases():
     print("scratch_nn:", {k: v.shape for k, v in out.items() if k.startswith("y_")})
 
 
+def epsilon_cases():
+    """Exploration schedules (lib/epsilon.py:36-86): value sequences incl. the period wrap and set()."""
+    with contextlib.redirect_stdout(_sink):
+        from ofighters.lib.epsilon import Epsilon_cos, Epsilon_decay
+        out = {}
+        e = Epsilon_cos(period=110 * 400)                    # the reference's TRAINER setting, qlearnIA_V2.py:308
+        out["cos_44000_first"] = np.array([e.get()] + [e.next() for _ in range(600)])
+        e = Epsilon_cos(period=50)
+        out["cos_50"] = np.array([e.get()] + [e.next() for _ in range(130)])
+        e.set(0.25)
+        out["cos_50_after_set"] = np.array([e.t, e.get()] + [e.next() for _ in range(5)])
+        d = Epsilon_decay()
+        out["decay"] = np.array([d.get()] + [d.next() for _ in range(3000)])
+        d.set(0.0105)
+        out["decay_after_set"] = np.array([d.next() for _ in range(800)])
+    np.savez_compressed(os.path.join(OUT, "epsilon.npz"), **out)
+    print("epsilon:", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     random_traces()
     brawl_traces()
@@ -432,3 +452,4 @@ if __name__ == "__main__":
     raster_cases()
     geometry_cases()
     scratch_nn_cases()
+    epsilon_cases()

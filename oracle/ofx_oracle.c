@@ -483,6 +483,21 @@ void orc_bot_actions(const orc_arena *a, const int32_t *behaviours, uint64_t see
   }
 }
 
+#define ORC_STREAM_EXPLORE 2u
+/* epsilon branch of Trainer.get_best_action + random_play (agents/qlearnIA_V2.py:199-204,317-321) on the
+ * counter RNG: returns 1 and fills (iaction, px, py) when the ship explores this tick, else 0.               */
+int orc_policy_explore(const orc_cfg *c, double eps, uint64_t seed, uint32_t global_arena, uint32_t ship,
+                       uint32_t tick, int collecting, int32_t *out3) {
+  uint32_t r[4];
+  philox4x32_10(global_arena, ship, tick, ORC_STREAM_EXPLORE, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+  double u = (double)r[0] * (1.0 / 4294967296.0);
+  if (!(collecting || u <= eps)) return 0;
+  out3[0] = draw_int(r[1], 1);
+  out3[1] = draw_int(r[2], c->width - 1);
+  out3[2] = draw_int(r[3], c->height - 1);
+  return 1;
+}
+
 void orc_reset_draws(const orc_cfg *c, uint64_t seed, uint32_t global_arena, uint32_t episode, int32_t *draws) {
   for (int i = 0; i < c->n_ships; i++) {
     uint32_t r[4];

@@ -260,3 +260,13 @@ def policy_forward(ship_map, laser_map, vec8, weights, want_heat=True):
     ip = np.zeros(2, np.int32)
     L.orc_policy_forward(_p(sm), _p(lm), _p(v), _p(w), _p(act), _p(heat), _p(ia), _p(ip))
     return act, heat, int(ia[0]), (int(ip[0]), int(ip[1]))
+
+
+def policy_explore(cfg, eps, seed, global_arena, ship, tick, collecting=False):
+    L = lib()
+    L.orc_policy_explore.argtypes = [C.POINTER(OrcCfg), C.c_double, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                     C.c_int, C.c_void_p]
+    L.orc_policy_explore.restype = C.c_int
+    out = np.zeros(3, np.int32)
+    hit = L.orc_policy_explore(C.byref(cfg), float(eps), C.c_uint64(seed), global_arena, ship, tick, int(collecting), _p(out))
+    return (int(out[0]), int(out[1]), int(out[2])) if hit else None

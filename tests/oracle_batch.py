@@ -68,3 +68,16 @@ class OracleEngine:
     def maps_f64(self):
         sm, lm = self.a.rasterise()
         return sm[None].astype(np.float64), lm[None].astype(np.float64)
+
+    def policy_forward_host(self, weights, ship_mask=None, want_heat=False):
+        sm, lm = self.a.rasterise()
+        head, _ = self.a.obs_head()
+        M = self.M
+        out = dict(act=np.zeros((1, M, 2), np.float32), iaction=np.zeros((1, M), np.int32),
+                   ipointer=np.zeros((1, M, 2), np.int32))
+        for i in range(M):
+            if ship_mask is not None and not np.asarray(ship_mask).reshape(M)[i]:
+                continue
+            act, _, ia, ip = pyoracle.policy_forward(sm, lm, head[i].astype(np.float32), weights, want_heat=False)
+            out["act"][0, i], out["iaction"][0, i], out["ipointer"][0, i] = act, ia, ip
+        return out
