@@ -66,7 +66,6 @@ struct PrepLayout {
   int uw[3], ub[3];   // upconv1..3 folded
   int bg[4];          // background response after trunk layer i ([8] each): the value every output channel takes
                       // where the whole receptive window shows empty space
-  int w3eff;          // [4 ci][4 phases][9 low-res taps][8 co]  (BN folded; VALU variant)
   int w3mf;           // [half 2][k = tap*4 + ci (36)][n = phase*4 + co_local (16)]  MFMA B operand
   int w4eff;          // [4 phases][9 low-res taps][8 ci] (v1 kernel)
   int w4eff_c;        // [8 ci][4 phases][9 taps] (fused kernel: one contiguous slice per input channel)
@@ -81,7 +80,6 @@ static PrepLayout prep_layout() {
   for (int i = 0; i < 4; i++) { L.tw[i] = off; off += 9 * kTrunkCin[i] * 8; L.tb[i] = off; off += 8; }
   for (int i = 0; i < 3; i++) { L.uw[i] = off; off += 9 * kUpCin[i] * kUpCout[i]; L.ub[i] = off; off += kUpCout[i]; }
   for (int i = 0; i < 4; i++) { L.bg[i] = off; off += 8; }
-  L.w3eff = off; off += 4 * 9 * 4 * 8;
   L.w3mf = off; off += 36 * 32;
   L.w4eff = off; off += 4 * 9 * 8;
   L.w4eff_c = off; off += 8 * 4 * 9;
@@ -97,7 +95,7 @@ struct PrepParams {
   float *prep;
   int src_k[7], src_b[7], src_g[7], cin[7], cout[7], dst_w[7], dst_b[7];
   int src_k4, src_b4, dst_w4eff, dst_w4raw, dst_b4;
-  int dst_w3eff, dst_w4eff_c, dst_w3mf;
+  int dst_w4eff_c, dst_w3mf;
   int dst_bg[4];
 };
 
@@ -168,7 +166,6 @@ __global__ void k_policy_prepare(PrepParams p) {
       for (int dy = 0; dy < 3; dy++)
         for (int dx = 0; dx < 3; dx++)
           acc += (p.w[p.src_k[6] + ((dy * 3 + dx) * cin + ci) * cout + co] * inv) * (up_coef(a, dy, ty) * up_coef(b, dx, tx));
-      p.prep[p.dst_w3eff + ((ci * 4 + ph) * 9 + tap) * cout + co] = acc;
       p.prep[p.dst_w3mf + ((co >> 2) * 36 + tap * 4 + ci) * 16 + ph * 4 + (co & 3)] = acc;
     }
   }
@@ -422,155 +419,6 @@ __global__ __launch_bounds__(((TH / 2) * (TW / 4) + 63) / 64 * 64) void k_conv8(
     }
   }
 
-  const int oy = ty0 + 2 * tr, ox = tx0 + 4 * tc;
-#pragma unroll
-  for (int co = 0; co < COUT; co++) {
-    const float bias = p.b[co];
-    float o[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-      for (int j = 0; j < 4; j++) o[i][j] = skip ? p.bg_out[co] : fmaxf(acc[i][j][co] + bias, 0.f);
-    if (POOL) {
-      const float m0 = fmaxf(fmaxf(o[0][0], o[0][1]), fmaxf(o[1][0], o[1][1]));
-      const float m1 = fmaxf(fmaxf(o[0][2], o[0][3]), fmaxf(o[1][2], o[1][3]));
-      const int Ho = H >> 1, Wo = W >> 1, py = oy >> 1, px = ox >> 1;
-      if (OUT_HWC) {
-        p.out[(((size_t)img * Ho + py) * Wo + px) * COUT + co] = m0;
-        p.out[(((size_t)img * Ho + py) * Wo + px + 1) * COUT + co] = m1;
-      } else {
-        *reinterpret_cast<float2 *>(&p.out[(((size_t)img * COUT + co) * Ho + py) * Wo + px]) = make_float2(m0, m1);
-      }
-    } else {
-      float *op = p.out + (((size_t)img * COUT + co) * H + oy) * W + ox;
-      *reinterpret_cast<float4 *>(op) = make_float4(o[0][0], o[0][1], o[0][2], o[0][3]);
-      *reinterpret_cast<float4 *>(op + W) = make_float4(o[1][0], o[1][1], o[1][2], o[1][3]);
-    }
-  }
-}
-
-// ---- the same on the matrix cores ----
-template <int CIN, int TH, int TW, int MODE, bool POOL, bool OUT_HWC>
-__global__ __launch_bounds__(((TH / 2) * (TW / 4) + 63) / 64 * 64) void k_conv8m(ConvParams p) {
-  constexpr int COUT = 8;
-  constexpr int NT = (TH / 2) * (TW / 4);
-  constexpr int NTB = (NT + 63) / 64 * 64;
-  constexpr int TWP = TW + 4;  // halo 1 each side + 2 pad: row stride multiple of 4 floats (16-byte aligned reads)
-  __shared__ __align__(16) float tile[CIN][TH + 2][TWP];
-  __shared__ __align__(16) float wl[CIN][9 * COUT];  // [ci][tap][co]
-  const int img = blockIdx.x / p.tiles, t = blockIdx.x - img * p.tiles;
-  if (p.mask && !p.mask[img]) return;
-  const int ty0 = (t / p.tiles_x) * TH, tx0 = (t % p.tiles_x) * TW;
-  const int tid = threadIdx.x;
-  const int H = p.H, W = p.W;
-
-  for (int e = tid; e < CIN * 9 * COUT; e += NTB) {  // folded weights [tap][ci][co] -> [ci][tap][co]
-    const int co = e % COUT, tap = (e / COUT) % 9, ci = e / (9 * COUT);
-    wl[ci][tap * COUT + co] = p.w[(tap * CIN + ci) * COUT + co];
-  }
-  // stage the (TH+2) x (TW+2) x CIN input patch: tile column c <-> image column tx0 - 1 + c.
-  // 2-D thread mapping (32 column lanes x NTB/32 row lanes) with running indices: no div/mod per element,
-  // each group of loads is in flight before the first LDS store.
-  {
-    constexpr int CL = 32, RL = NTB / CL;
-    const int cl0 = tid % CL, rl0 = tid / CL;
-    constexpr int NCH = (TWP + CL - 1) / CL;  // column steps per row
-    for (int ci = 0; ci < CIN; ci++) {
-      for (int r = rl0; r < TH + 2; r += RL) {
-        const int gy = ty0 - 1 + r;
-        const bool rowok = gy >= 0 && gy < H;
-        float vals[NCH];
-#pragma unroll
-        for (int q = 0; q < NCH; q++) {
-          const int c = cl0 + q * CL, gx = tx0 - 1 + c;
-          float v = 0.f;
-          if (rowok && c < TW + 2 && gx >= 0 && gx < W) {
-            if (MODE == 0) {
-              v = p.in[(((size_t)img * CIN + ci) * H + gy) * W + gx];
-            } else {
-              const int cell = gy * W + gx;
-              v = (float)((p.bits[ci][(size_t)img * ((PS * PS) >> 5) + (cell >> 5)] >> (cell & 31)) & 1u);
-            }
-          }
-          vals[q] = v;
-        }
-#pragma unroll
-        for (int q = 0; q < NCH; q++) {
-          const int c = cl0 + q * CL;
-          if (c < TWP) tile[ci][r][c] = vals[q];
-        }
-      }
-    }
-  }
-  __syncthreads();
-  const bool live = tid < NT;           // idle lanes still run the MFMAs (on a clamped window) but store nothing
-  const int tcl = live ? tid : NT - 1;
-  const int tr = tcl / (TW / 4), tc = tcl - tr * (TW / 4);
-
-  float acc[2][4][COUT];
-#pragma unroll
-  for (int i = 0; i < 2; i++)
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-#pragma unroll
-      for (int co = 0; co < COUT; co++) acc[i][j][co] = 0.f;
-
-  bool skip = false;  // background skip, see k_conv
-  if (p.bg_in != nullptr) {
-    bool flat = ty0 + 2 * tr >= 1 && ty0 + 2 * tr + 2 < H && tx0 + 4 * tc >= 1 && tx0 + 4 * tc + 4 < W;
-    for (int ci = 0; ci < CIN && flat; ci++) {
-      const float bgv = p.bg_in[ci];
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const float4 lo = *reinterpret_cast<const float4 *>(&tile[ci][2 * tr + r][4 * tc]);
-        const float4 hi = *reinterpret_cast<const float4 *>(&tile[ci][2 * tr + r][4 * tc + 4]);
-        flat = flat && lo.x == bgv && lo.y == bgv && lo.z == bgv && lo.w == bgv && hi.x == bgv && hi.y == bgv;
-      }
-    }
-    skip = __all(flat);
-  }
-  // Matrix-core form: per input value the layer is out[co] += W[k][co] * in[k].  v_mfma_f32_4x4x1_16B_f32 with
-  // CBSZ = 4 broadcasts one 4-lane block of the A register to all 16 blocks: A lanes 0-3 = W[k][co 0..3] (ABID 0),
-  // lanes 4-7 = W[k][co 4..7] (ABID 1), B = one input value per lane (pixel): an M = 4, N = 64, K = 1 step at the
-  // full f32 MFMA rate (133-140 TFLOP/s measured vs 75 / 115 for v_fmac with an SGPR / VGPR weight) with no padded
-  // dimension.  One b128 LDS read serves 4 pixels x 3 taps x 2 channel halves = 24 MFMAs.
-  f32x4 alo[2][4], ahi[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; i++)
-#pragma unroll
-    for (int j = 0; j < 4; j++) { alo[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; ahi[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll 1
-  for (int ci = 0; ci < (skip ? 0 : CIN); ci++) {
-    float v[4][8];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const float4 lo = *reinterpret_cast<const float4 *>(&tile[ci][2 * tr + r][4 * tc]);
-      const float4 hi = *reinterpret_cast<const float4 *>(&tile[ci][2 * tr + r][4 * tc + 4]);
-      v[r][0] = lo.x; v[r][1] = lo.y; v[r][2] = lo.z; v[r][3] = lo.w; v[r][4] = hi.x; v[r][5] = hi.y;
-    }
-    float wa[9];  // lane l < 8 holds W[tap][ci][co = l]
-#pragma unroll
-    for (int tap = 0; tap < 9; tap++) wa[tap] = wl[ci][tap * COUT + (tid & 7)];
-#pragma unroll
-    for (int dy = 0; dy < 3; dy++)
-#pragma unroll
-      for (int dx = 0; dx < 3; dx++)
-#pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            alo[i][j] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[dy * 3 + dx], v[i + dy][j + dx], alo[i][j], 4, 0, 0);
-            ahi[i][j] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[dy * 3 + dx], v[i + dy][j + dx], ahi[i][j], 4, 1, 0);
-          }
-  }
-#pragma unroll
-  for (int i = 0; i < 2; i++)
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-#pragma unroll
-      for (int co = 0; co < 4; co++) { acc[i][j][co] = alo[i][j][co]; acc[i][j][co + 4] = ahi[i][j][co]; }
-
-  if (!live) return;
   const int oy = ty0 + 2 * tr, ox = tx0 + 4 * tc;
 #pragma unroll
   for (int co = 0; co < COUT; co++) {
@@ -1242,18 +1090,6 @@ static int launch_conv8(ofx_handle *h, ConvParams p, int images, int H) {
   return OFX_OK;
 }
 
-template <int CIN, int TH, int TW, int MODE, bool POOL, bool OUT_HWC>
-static int launch_conv8m(ofx_handle *h, ConvParams p, int images, int H) {
-  p.H = H; p.W = H;
-  p.tiles_x = H / TW;
-  p.tiles = p.tiles_x * (H / TH);
-  constexpr int NTB = ((TH / 2) * (TW / 4) + 63) / 64 * 64;
-  hipLaunchKernelGGL((k_conv8m<CIN, TH, TW, MODE, POOL, OUT_HWC>), dim3((unsigned)(images * p.tiles)), dim3(NTB), 0,
-                     h->stream, p);
-  OFX_HIP(hipGetLastError());
-  return OFX_OK;
-}
-
 static int launch_gemm(ofx_handle *h, const float *A, int lda, const float *B, int ldb, const float *bias, float *C,
                        int ldc, int M, int N, int K, int relu) {
   const int tiles = ((M + 31) / 32) * ((N + 31) / 32);
@@ -1298,7 +1134,7 @@ extern "C" int ofx_policy_forward(ofx_handle *h, const float *weights, const uin
   }
   pp.src_k4 = off[t_u4]; pp.src_b4 = off[t_u4 + 1];
   pp.dst_w4eff = L.w4eff; pp.dst_w4raw = L.w4raw; pp.dst_b4 = L.b4;
-  pp.dst_w3eff = L.w3eff; pp.dst_w4eff_c = L.w4eff_c; pp.dst_w3mf = L.w3mf;
+  pp.dst_w4eff_c = L.w4eff_c; pp.dst_w3mf = L.w3mf;
   for (int i = 0; i < 4; i++) pp.dst_bg[i] = L.bg[i];
   hipLaunchKernelGGL(k_policy_prepare, dim3(1), dim3(256), 0, h->stream, pp);
   OFX_HIP(hipGetLastError());
