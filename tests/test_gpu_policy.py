@@ -133,3 +133,42 @@ def test_layer_by_layer_tail_agrees_with_fused():
     np.testing.assert_allclose(fused["heat"], plain["heat"], rtol=0, atol=TOL * hs)
     np.testing.assert_allclose(fused["act"], plain["act"], rtol=0, atol=1e-6)
     b.close()
+
+
+def test_policy_full_size_properties():
+    """BASELINE configs[3] size (4096 x 8): determinism, mask consistency (a masked forward equals the same ships of
+    a full forward), pointer range, and a sample of ships against the CPU restatement."""
+    from ofighters_amd import DeviceBuffer, _native as nat
+    from ofighters_amd.agents.policy_weights import synthetic
+    from oracle import pyoracle
+    N, M = 4096, 8
+    b = _rollout(N, M, seed=0x0F160001, ticks=12)
+    w = synthetic()
+    S = N * M
+    dw = DeviceBuffer(w.nbytes).upload(w)
+    da, di, dp = DeviceBuffer(8 * S), DeviceBuffer(4 * S), DeviceBuffer(8 * S)
+
+    def run(mask_ptr=None):
+        b.policy_forward(dw.ptr, mask_ptr, da.ptr, di.ptr, dp.ptr, None)
+        b.sync()
+        return (da.download(np.float32, (N, M, 2)), di.download(np.int32, (N, M)), dp.download(np.int32, (N, M, 2)))
+
+    a1, i1, p1 = run()
+    a2, i2, p2 = run()
+    assert np.array_equal(a1, a2) and np.array_equal(i1, i2) and np.array_equal(p1, p2)     # bitwise reproducible
+    assert p1.min() >= 0 and p1.max() <= 399 and set(np.unique(i1)) <= {0, 1}
+    mask = np.zeros((N, M), np.uint8)
+    mask[:, 3] = 1
+    dm = DeviceBuffer(S).upload(mask)
+    a3, i3, p3 = run(dm.ptr)
+    assert np.array_equal(a3[:, 3], a1[:, 3]) and np.array_equal(p3[:, 3], p1[:, 3])
+    head, _ = b.observe_head()
+    sm, lm = b.maps_host(nat.MAP_U8)
+    rs = np.random.RandomState(2)
+    for g in rs.choice(N, 3, replace=False):
+        i = int(rs.randint(M))
+        act, heat, ia, ip = pyoracle.policy_forward(sm[g], lm[g], head[g, i].astype(np.float32), w)
+        np.testing.assert_allclose(a1[g, i], act, rtol=0, atol=TOL * max(1.0, float(np.abs(act).max())))
+        gx, gy = p1[g, i]
+        assert heat[gy, gx] >= heat.max() - 2 * TOL * float(np.abs(heat).max())
+    b.close()
