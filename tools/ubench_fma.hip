@@ -47,6 +47,23 @@ __global__ __launch_bounds__(256) void k(float *out, const float *w, int iters) 
     float sum = 0;
     for (int i = 0; i < 8; i++) sum += a[i].x + a[i].y;
     out[blockIdx.x * blockDim.x + threadIdx.x] = sum;
+  } else if (MODE == 4 || MODE == 5) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 a[8];
+    for (int i = 0; i < 8; i++) a[i] = (f32x4){x, x + i, x - i, x};
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          if (MODE == 4) a[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(x, s2 + x, a[i], 0, 0, 0);
+          else a[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(x, s3 + x, a[i], 4, 0, 0);
+        }
+      }
+    }
+    float sum = 0;
+    for (int i = 0; i < 8; i++) sum += a[i][0] + a[i][1] + a[i][2] + a[i][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = sum;
   } else {
     f32x16 a0, a1;
     for (int i = 0; i < 16; i++) { a0[i] = x; a1[i] = x + 1; }
@@ -91,6 +108,8 @@ int main() {
     run<3>("v_fmac_f32 (VGPR weight)", b, 4000, 64 * 2.0);
     run<1>("v_pk_fma_f32", b, 4000, 32 * 4.0);
     run<2>("v_mfma_f32_32x32x2_f32", b, 1000, 4 * 32.0 * 32 * 2 * 2 / 64);
+    run<4>("v_mfma_f32_16x16x4_f32", b, 1000, 16 * 16.0 * 16 * 4 * 2 / 64);
+    run<5>("v_mfma_f32_4x4x1_16B_f32", b, 1000, 16 * 16.0 * 4 * 4 * 1 * 2 / 64);
   }
   return 0;
 }
