@@ -283,3 +283,29 @@ def test_error_behaviour():
         b.spawn_random(1)
         b.bot_actions(["kamikaze"] * 4, 1)
     b.close()
+
+
+@pytest.mark.parametrize("M,W,H,L", [(1, 400, 400, 64), (64, 96, 96, 1024), (5, 64, 128, 256), (7, 160, 96, 256)])
+def test_shapes_and_non_square_maps_vs_oracle(M, W, H, L):
+    """Edge shapes: a lone ship, a full wave of 64 ships (4096 shooter/enemy pairs), and NON-SQUARE arenas where the
+    reference's map is np.zeros((dim.x, dim.y)) indexed [y][x] (observation.py:86, form.py:226): the quirk
+    (rows bounded by the width) is reproduced, not fixed."""
+    from ofighters_amd import _native as nat
+    from oracle import pyoracle
+    N, seed = 16, 1234 + M
+    b = _batch(N, M, laser_cap=L, width=W, height=H)
+    b.spawn_random(seed)
+    oracles = []
+    for g in range(N):
+        o = pyoracle.Arena(cfg=pyoracle.default_cfg(M, width=W, height=H))
+        o.spawn(pyoracle.reset_draws(o.cfg, seed, g, 0))
+        oracles.append(o)
+    beh = (["turret", "random", "runner", "shoot", "thrust", "idle"] * 11)[:M]
+    _oracle_rollout(b, oracles, beh, seed, ticks=90, episode_ticks=40, check_every=3)
+    sm, lm = b.maps_host(nat.MAP_U8)
+    assert sm.shape == (N, W, H)
+    for g, o in enumerate(oracles):
+        osm, olm = o.rasterise()
+        assert np.array_equal(sm[g], osm) and np.array_equal(lm[g], olm), g
+    assert b.overflow_count() == 0
+    b.close()
