@@ -88,6 +88,8 @@ static double sqrt_le_threshold(double r) {
 template <typename T>
 static int dev_alloc_zero(T **p, size_t count) {
   OFX_HIP(hipMalloc((void **)p, count * sizeof(T) ? count * sizeof(T) : 1));
+  // hipMemset on the null stream returns before the fill has run and is NOT ordered with the handle's
+  // non-blocking stream: ofx_create synchronises the device once after all allocations (see there)
   OFX_HIP(hipMemset(*p, 0, count * sizeof(T)));
   return OFX_OK;
 }
@@ -142,6 +144,10 @@ extern "C" int ofx_create(const ofx_config *cfg, ofx_handle **out) {
   if (e != hipSuccess) { ofx_set_error("hipStreamCreate: %s", hipGetErrorString(e)); ofx_destroy(h); return OFX_ERR_HIP; }
   h->own_stream = true;
   h->prof_base = -1;
+  // the zero fills above ran on the null stream; the handle's stream is non-blocking, so without this a kernel
+  // enqueued right after ofx_create (k_spawn) could be overtaken by a late memset (seen with two handles in a row)
+  e = hipDeviceSynchronize();
+  if (e != hipSuccess) { ofx_set_error("hipDeviceSynchronize: %s", hipGetErrorString(e)); ofx_destroy(h); return OFX_ERR_HIP; }
   *out = h;
   return OFX_OK;
 }

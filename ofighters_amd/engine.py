@@ -213,8 +213,7 @@ class ArenaBatch:
         nbytes = nat.lib().ofx_field_bytes(self._h, field)
         a = np.empty(nbytes // dt.itemsize, dtype=dt)
         nat.check(nat.lib().ofx_get_host(self._h, field, a.ctypes.data_as(C.c_void_p), nbytes))
-        n = self.N
-        return a.reshape(n, -1) if a.size != n else a
+        return a if field in (nat.F_N_LASERS, nat.F_TIME) else a.reshape(self.N, -1)
 
     def device_ptr(self, field):
         return nat.lib().ofx_device_ptr(self._h, field)
