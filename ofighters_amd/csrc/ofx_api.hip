@@ -69,6 +69,9 @@ extern "C" int ofx_free(void *dev_ptr) {
 }
 extern "C" int ofx_memcpy_h2d(void *dst, const void *src, size_t bytes) {
   OFX_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+  // a copy from pageable memory may still be in flight when hipMemcpy returns, and handles run on
+  // non-blocking streams: make the bytes visible to every stream before returning (host-convenience path only)
+  OFX_HIP(hipDeviceSynchronize());
   return OFX_OK;
 }
 extern "C" int ofx_memcpy_d2h(void *dst, const void *src, size_t bytes) {
