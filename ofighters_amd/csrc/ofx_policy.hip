@@ -179,6 +179,7 @@ struct ConvParams {
   const float *w, *b;              // folded [9][CIN][COUT], [COUT]
   float *out;                      // planar [img][COUT][Ho][Wo] or HWC [img][Ho][Wo][COUT]
   const uint8_t *mask;             // per image, may be null
+  int ablate;                      // diagnostics (OFX_CONV_ABLATE): 1 no global loads, 2 no FMAs, 4 no stores
   const float *bg_in, *bg_out;     // background value per input / output channel (null = no background skip)
   int H, W;                        // conv domain (input after any upsampling) = conv output size
   int tiles_x, tiles;              // tiles per row / per image
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(((TH / 2) * (TW / 2) + 63) / 64 * 64) void k_conv(C
         const int gy = ty0 - 1 + r, gx = tx0 - 1 + c;
         if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
           if (MODE == 0) {
-            v = p.in[(((size_t)img * CIN + ci) * H + gy) * W + gx];
+            v = (p.ablate & 1) ? 1.f : p.in[(((size_t)img * CIN + ci) * H + gy) * W + gx];
           } else if (MODE == 1) {
             const int cell = gy * W + gx;
             v = (float)((p.bits[ci][(size_t)img * ((PS * PS) >> 5) + (cell >> 5)] >> (cell & 31)) & 1u);
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(((TH / 2) * (TW / 2) + 63) / 64 * 64) void k_conv(C
     }
     skip = __all(flat);
   }
-  if (!skip) {
+  if (!skip && !(p.ablate & 2)) {
 #pragma unroll
   for (int ci = 0; ci < CIN; ci++) {
     float v[4][4];
@@ -299,6 +300,7 @@ __global__ __launch_bounds__(((TH / 2) * (TW / 2) + 63) / 64 * 64) void k_conv(C
     float o00 = fmaxf(acc[0][0][co] + bias, 0.f), o01 = fmaxf(acc[0][1][co] + bias, 0.f);
     float o10 = fmaxf(acc[1][0][co] + bias, 0.f), o11 = fmaxf(acc[1][1][co] + bias, 0.f);
     if (skip) o00 = o01 = o10 = o11 = p.bg_out[co];
+    if ((p.ablate & 4) && o00 != 12345.f) continue;
     if (POOL) {
       const float m = fmaxf(fmaxf(o00, o01), fmaxf(o10, o11));
       const int Ho = H >> 1, Wo = W >> 1, py = oy >> 1, px = ox >> 1;
@@ -1415,6 +1417,7 @@ extern "C" int ofx_policy_forward(ofx_handle *h, const float *weights, const uin
   // 1. trunk, once per arena
   ConvParams cp;
   memset(&cp, 0, sizeof(cp));
+  { const char *e = getenv("OFX_CONV_ABLATE"); cp.ablate = e ? atoi(e) : 0; }
   cp.bits[0] = (const unsigned *)h->maps[OFX_MAP_BITS_LSB][0];
   cp.bits[1] = (const unsigned *)h->maps[OFX_MAP_BITS_LSB][1];
   // opt-in: pays off on sparse scenes only (measured: with policy-driven play the maps are full of lasers
