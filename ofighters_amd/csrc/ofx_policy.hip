@@ -339,6 +339,34 @@ __global__ __launch_bounds__(((TH / 2) * (TW / 4) + 63) / 64 * 64) void k_conv8(
   }
   // stage the (TH+2) x (TW+2) x CIN input patch: tile column c <-> image column tx0 - 1 + c
   constexpr int TOTAL = CIN * (TH + 2) * TWP;
+  if (MODE == 1) {
+    // 1-bit input: one thread per 32-bit WORD of a tile row (a row of TW+2 cells touches at most WPR words) instead
+    // of one global load per cell: 2 x (TH+2) x WPR word loads, each expanded into up to 32 LDS floats.
+    // (stage ablation: per-cell loads were 1.8 of the kernel's 5.0 ms)
+    constexpr int WPR = (TW + 2 + 31) / 32 + 1;
+    for (int e = tid; e < CIN * (TH + 2) * WPR; e += NTB) {
+      const int k = e % WPR, r = (e / WPR) % (TH + 2), ci = e / (WPR * (TH + 2));
+      const int gy = ty0 - 1 + r;
+      float *trow = &tile[ci][r][0];
+      if (gy < 0 || gy >= H) {
+        for (int c = k; c < TWP; c += WPR) trow[c] = 0.f;  // padding row: zeros (strided split of the row)
+        continue;
+      }
+      const int cell0 = gy * W + tx0 - 1;            // cell index of tile column 0 (may be -1 at the left image edge)
+      const int w0 = (cell0 >= 0 ? cell0 : 0) >> 5;  // first word of the row segment
+      const int wi = w0 + k;
+      const unsigned word = (wi < (PS * PS) >> 5) ? p.bits[ci][(size_t)img * ((PS * PS) >> 5) + wi] : 0u;
+      // cells of this word: wi*32 .. wi*32+31 -> tile columns c = cell - cell0
+      const int cbeg = max(wi * 32 - cell0, 0), cend = min(wi * 32 + 32 - cell0, TWP);
+      if (k == 0)
+        for (int c = 0; c < cbeg; c++) trow[c] = 0.f;  // cell0 = -1 at the left image edge: column 0 is padding
+      for (int c = cbeg; c < cend; c++) {
+        const int gx = tx0 - 1 + c;
+        const unsigned bit = (word >> ((cell0 + c) & 31)) & 1u;
+        trow[c] = (c < TW + 2 && gx >= 0 && gx < W && bit) ? 1.f : 0.f;
+      }
+    }
+  } else {
   constexpr int SU = 8;
   for (int base = 0; base < TOTAL; base += NTB * SU) {
     float vals[SU];
@@ -349,14 +377,8 @@ __global__ __launch_bounds__(((TH / 2) * (TW / 4) + 63) / 64 * 64) void k_conv8(
       if (e < TOTAL) {
         const int c = e % TWP, r = (e / TWP) % (TH + 2), ci = e / (TWP * (TH + 2));
         const int gy = ty0 - 1 + r, gx = tx0 - 1 + c;
-        if (c < TW + 2 && gy >= 0 && gy < H && gx >= 0 && gx < W) {
-          if (MODE == 0) {
-            v = p.in[(((size_t)img * CIN + ci) * H + gy) * W + gx];
-          } else {
-            const int cell = gy * W + gx;
-            v = (float)((p.bits[ci][(size_t)img * ((PS * PS) >> 5) + (cell >> 5)] >> (cell & 31)) & 1u);
-          }
-        }
+        if (c < TW + 2 && gy >= 0 && gy < H && gx >= 0 && gx < W)
+          v = p.in[(((size_t)img * CIN + ci) * H + gy) * W + gx];
       }
       vals[u] = v;
     }
@@ -365,6 +387,7 @@ __global__ __launch_bounds__(((TH / 2) * (TW / 4) + 63) / 64 * 64) void k_conv8(
       const int e = base + u * NTB + tid;
       if (e < TOTAL) (&tile[0][0][0])[e] = vals[u];
     }
+  }
   }
   __syncthreads();
   if (tid >= NT) return;
@@ -393,7 +416,7 @@ __global__ __launch_bounds__(((TH / 2) * (TW / 4) + 63) / 64 * 64) void k_conv8(
     skip = __all(flat);
   }
 #pragma unroll 1
-  for (int ci = 0; ci < (skip ? 0 : CIN); ci++) {
+  for (int ci = 0; ci < ((skip || (p.ablate & 2)) ? 0 : CIN); ci++) {
     float v[4][8];
 #pragma unroll
     for (int r = 0; r < 4; r++) {  // cols 4tc .. 4tc+5 of the tile: two aligned b128 reads (conflict free)
@@ -430,6 +453,7 @@ __global__ __launch_bounds__(((TH / 2) * (TW / 4) + 63) / 64 * 64) void k_conv8(
     for (int i = 0; i < 2; i++)
 #pragma unroll
       for (int j = 0; j < 4; j++) o[i][j] = skip ? p.bg_out[co] : fmaxf(acc[i][j][co] + bias, 0.f);
+    if ((p.ablate & 4) && o[0][0] != 12345.f) continue;
     if (POOL) {
       const float m0 = fmaxf(fmaxf(o[0][0], o[0][1]), fmaxf(o[1][0], o[1][1]));
       const float m1 = fmaxf(fmaxf(o[0][2], o[0][3]), fmaxf(o[1][2], o[1][3]));
@@ -1425,7 +1449,7 @@ extern "C" int ofx_policy_forward(ofx_handle *h, const float *weights, const uin
   const bool bgskip = getenv("OFX_POLICY_BG_SKIP") != nullptr;
   cp.w = ws.prep + L.tw[0]; cp.b = ws.prep + L.tb[0]; cp.out = ws.p1;
   if (bgskip) { cp.bg_in = ws.prep + L.total - 8; cp.bg_out = ws.prep + L.bg[0]; }  // the 8 pad floats are zero
-  if ((rc = launch_conv8<2, 20, 100, 1, true, false>(h, cp, N, 400))) return rc;
+  if ((rc = launch_conv8<2, 40, 100, 1, true, false>(h, cp, N, 400))) return rc;
   cp.in = ws.p1; cp.w = ws.prep + L.tw[1]; cp.b = ws.prep + L.tb[1]; cp.out = ws.p2;
   if (bgskip) { cp.bg_in = ws.prep + L.bg[0]; cp.bg_out = ws.prep + L.bg[1]; }
   if ((rc = launch_conv<8, 8, 10, 100, 0, true, false>(h, cp, N, 200))) return rc;
@@ -1453,6 +1477,7 @@ extern "C" int ofx_policy_forward(ofx_handle *h, const float *weights, const uin
     return rc;
   ConvParams up;
   memset(&up, 0, sizeof(up));
+  up.ablate = cp.ablate;
   up.mask = ship_mask;
   up.in = ws.u0; up.w = ws.prep + L.uw[0]; up.b = ws.prep + L.ub[0]; up.out = ws.up1;
   if ((rc = launch_conv<1, 2, 10, 50, 2, false, false>(h, up, S, 50))) return rc;
