@@ -262,6 +262,67 @@ int ofx_policy_explore(ofx_handle *h, double epsilon, uint64_t seed, uint32_t ti
 int ofx_policy_actions(ofx_handle *h, const int32_t *iaction, const int32_t *ipointer,
                        const uint8_t *ship_mask, ofx_action *actions);
 
+/* ---- transition capture: the replay memory -----------------------------
+ * Trainer.memory = deque(maxlen=memory_size) + Trainer.remember
+ * (agents/qlearnIA_V2.py:58,237-238), fed by the bookkeeping of QlearnIA.play
+ * (:370-403: nothing once the agent's `done` latch is set; the losing frame is
+ * still remembered; previous_obs/action/pointer) and cleared per episode by
+ * QlearnIA.reset (:360-368) - ofx_spawn* / ofx_restart* do that here.  Every
+ * arena owns one memory; rows are appended in (lock-step, ship index) order,
+ * the order of request_actions (lib/battleground.py:146-150).
+ * One row = [state, iaction, ipointer, reward, next_state, done]; the two
+ * observations are kept as the lock-step numbers of their 1-bit maps in the
+ * frame ring plus the ship's own toVector head.  (In the reference every ship
+ * of a tick shares ONE mutated Observation object, battleground.py:150, so the
+ * head found in its memory is the LAST analysed ship's; the per-ship head is
+ * stored here and that aliasing is not reproduced.)                          */
+typedef struct ofx_transition {
+  int32_t tick_prev, tick_next;   /* lock-steps of state / next_state         */
+  int32_t frame_prev, frame_next; /* their slots in the arena's frame ring     */
+  int32_t ship;                   /* -1 in padding rows of a gathered batch    */
+  int32_t iaction, px, py;        /* previous_action, previous_pointer (x, y) */
+  int32_t reward;                 /* obs.reward of next_state                  */
+  int32_t done;                   /* obs.done of next_state                    */
+  float head_prev[8], head_next[8];
+} ofx_transition;                 /* 104 bytes                                 */
+/* capacity = memory_size (400 in the reference); frames = length of every
+ * arena's ring of stored observation maps (0 = capacity + capacity/4 + 2).  An
+ * arena stores a frame only on lock-steps where one of its agents plays, and
+ * C rows made of runs of consecutive plays reference C + #runs frames (with K
+ * capturing ships per arena about C / K); a row whose `state` frame has been
+ * overwritten is no longer eligible for sampling.  A frame costs 2 * W*H/8
+ * bytes per arena (40 KB at 400x400).                                         */
+int ofx_replay_create(ofx_handle *h, int32_t capacity, int32_t frames);
+int ofx_replay_destroy(ofx_handle *h); /* also done by ofx_destroy            */
+/* Call once per lock-step after the action choice and BEFORE ofx_step: stores
+ * the current observation maps as frame `tick` of every arena with a playing
+ * agent and runs the play() bookkeeping for every ship selected by ship_mask
+ * (NULL = all) with its chosen (iaction, ipointer) (NULL = the workspace
+ * results of ofx_policy_forward / ofx_policy_explore).  `tick` must increase by
+ * one per call and not restart at episode boundaries.                         */
+int ofx_replay_capture(ofx_handle *h, uint32_t tick, const uint8_t *ship_mask, const int32_t *iaction,
+                       const int32_t *ipointer);
+/* len(memory) per arena [N] and the number of rows ever appended [N]; either
+ * may be NULL.  Synchronises.                                                 */
+int ofx_replay_count(ofx_handle *h, int32_t *count_host, int64_t *appended_host);
+/* list(memory) of one arena, oldest first; rows_host holds `capacity` rows.  */
+int ofx_replay_rows_host(ofx_handle *h, int32_t arena, ofx_transition *rows_host, int32_t *n_host);
+/* 1-bit maps of a stored lock-step of one arena, W*H/8 bytes each: pixel
+ * p = y*W + x -> bit (p & 7) of byte p >> 3 (numpy.unpackbits bitorder=
+ * 'little').  OFX_ERR_STATE when the arena's ring does not hold that frame.   */
+int ofx_replay_frame_host(ofx_handle *h, int32_t arena, int32_t tick, void *ship_bits_host, void *laser_bits_host);
+/* random.sample(memory, min(batch, len(memory))) for every arena
+ * (qlearnIA_V2.py:241-243): slot[N][batch] (device) receives row indices
+ * (oldest first, -1 pads), n_sampled[N] (device, may be NULL) the number drawn.
+ * Uniform without replacement (Floyd), Philox counter (global arena, j, draw,
+ * stream 3).                                                                  */
+int ofx_replay_sample(ofx_handle *h, uint64_t seed, uint32_t draw, int32_t batch, int32_t *slot, int32_t *n_sampled);
+/* Materialise sampled rows (device pointers): rows[N][batch] and, when not
+ * NULL, the 1-bit maps of state / next_state [N][batch][2 (ship, laser)]
+ * [W*H/32] uint32 in the layout ofx_policy_forward's trunk reads.             */
+int ofx_replay_gather(ofx_handle *h, const int32_t *slot, int32_t batch, ofx_transition *rows, void *bits_prev,
+                      void *bits_next);
+
 /* ---- timing helpers (HIP events on the handle's stream) ---------------- */
 int ofx_timer_start(ofx_handle *h);
 int ofx_timer_stop(ofx_handle *h, float *ms_host); /* synchronises */

@@ -49,6 +49,14 @@ class OfxAction(C.Structure):
                 ("valid", C.c_uint8), ("_pad", C.c_uint8)]
 
 
+class OfxTransition(C.Structure):
+    """include/ofx.h: struct ofx_transition - one row of Trainer.memory (qlearnIA_V2.py:237-238)."""
+    _fields_ = [("tick_prev", C.c_int32), ("tick_next", C.c_int32), ("frame_prev", C.c_int32),
+                ("frame_next", C.c_int32), ("ship", C.c_int32), ("iaction", C.c_int32),
+                ("px", C.c_int32), ("py", C.c_int32), ("reward", C.c_int32), ("done", C.c_int32),
+                ("head_prev", C.c_float * 8), ("head_next", C.c_float * 8)]
+
+
 class OfxPolicyDesc(C.Structure):
     _fields_ = [("n_floats", C.c_int32), ("offset", C.c_int32 * 64), ("count", C.c_int32 * 64),
                 ("n_tensors", C.c_int32)]
@@ -91,6 +99,14 @@ SIGNATURES = {
     "ofx_policy_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ofx_policy_actions": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "ofx_policy_explore": (_i, [_vp, C.c_double, _u64, _u32, C.c_int32, _vp, _vp, _vp]),
+    "ofx_replay_create": (_i, [_vp, C.c_int32, C.c_int32]),
+    "ofx_replay_destroy": (_i, [_vp]),
+    "ofx_replay_capture": (_i, [_vp, _u32, _vp, _vp, _vp]),
+    "ofx_replay_count": (_i, [_vp, _vp, _vp]),
+    "ofx_replay_rows_host": (_i, [_vp, C.c_int32, _vp, _vp]),
+    "ofx_replay_frame_host": (_i, [_vp, C.c_int32, C.c_int32, _vp, _vp]),
+    "ofx_replay_sample": (_i, [_vp, _u64, _u32, C.c_int32, _vp, _vp]),
+    "ofx_replay_gather": (_i, [_vp, _vp, C.c_int32, _vp, _vp, _vp]),
     "ofx_timer_start": (_i, [_vp]),
     "ofx_timer_stop": (_i, [_vp, C.POINTER(C.c_float)]),
     "ofx_event_record": (_i, [_vp, C.c_int32]),

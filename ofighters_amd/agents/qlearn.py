@@ -1,5 +1,6 @@
 """QlearnIA - the bi-head policy agent, forward only (API mirror of the reference's agents/qlearnIA_V2.py:324-456
-control flow; the DQN replay / fit / save of :240-298 is out of scope).
+control flow incl. Trainer.remember / the memory deque; the DQN replay / fit / save of :240-298 is out of scope,
+SURVEY section 8f rank 3).  The batched, device-resident form of the memory is ofx_replay_* (include/ofx.h).
 
 `play(obs)`: nothing once done; the first `collecting_steps` (20) total steps are `random_play()`; afterwards
 epsilon-greedy over the device forward (`Trainer.get_best_action`, :199-235): `iaction = argmax(act_values)`,
@@ -7,6 +8,7 @@ epsilon-greedy over the device forward (`Trainer.get_best_action`, :199-235): `i
 pointer set (:447-454).
 """
 import random
+from collections import deque
 
 import numpy as np
 
@@ -28,7 +30,8 @@ class Trainer:
     """Holds what the forward needs: the weight blob and the exploration schedule shared by every QlearnIA
     (the reference's module-level TRAINER singleton, qlearnIA_V2.py:308-310)."""
 
-    def __init__(self, weights=None, epsilon=None):
+    def __init__(self, weights=None, epsilon=None, memory_size=400):
+        self.memory = deque(maxlen=memory_size)      # qlearnIA_V2.py:58
         self.weights = synthetic() if weights is None else np.ascontiguousarray(weights, np.float32)
         self.epsilon = epsilon if epsilon is not None else Epsilon_cos(period=110 * 400)
         self.act_values = None
@@ -36,6 +39,10 @@ class Trainer:
 
     def decay_epsilon(self):
         self.epsilon.next()
+
+    def remember(self, state, iaction, ipointer, reward, next_state, done):
+        """qlearnIA_V2.py:237-238"""
+        self.memory.append([state, iaction, ipointer, reward, next_state, done])
 
     def get_best_action(self, obs, rand=True):
         if rand and np.random.rand() <= self.epsilon.get():
@@ -81,6 +88,9 @@ class QlearnIA(Agent):
             return None
         if obs.done:
             self.done = True
+        if self.previous_obs is not None and self.previous_action is not None and self.previous_pointer is not None:
+            self.trainer.remember(self.previous_obs, self.previous_action, self.previous_pointer, obs.reward, obs,
+                                  obs.done)
         if self.total_steps < self.collecting_steps:
             iaction, ipointer = random_play()
         else:

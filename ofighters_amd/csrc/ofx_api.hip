@@ -159,6 +159,7 @@ extern "C" int ofx_destroy(ofx_handle *h) {
   if (!h) return OFX_OK;
   (void)hipSetDevice(h->cfg.device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  ofx_replay_free(h);
   ofx_state &s = h->st;
   void *ptrs[] = {s.ship_x, s.ship_y, s.ship_px, s.ship_py, s.hull, s.reward, s.score, s.obs_reward, s.last_score,
                   s.alive, s.killer, s.time, s.n_lasers, s.laser_x, s.laser_y, s.laser_dx, s.laser_dy,
@@ -290,7 +291,7 @@ static int do_spawn(ofx_handle *h, const int32_t *draws, uint64_t seed) {
   hipLaunchKernelGGL(k_spawn, dim3((T + 255) / 256), dim3(256), 0, h->stream, p);
   OFX_HIP(hipGetLastError());
   h->spawned = true;
-  return OFX_OK;
+  return ofx_replay_episode_reset(h, nullptr);  // fresh agents: previous_* = None
 }
 
 static int do_restart(ofx_handle *h, const int32_t *draws, const uint8_t *mask, uint64_t seed, uint32_t episode) {
@@ -302,7 +303,7 @@ static int do_restart(ofx_handle *h, const int32_t *draws, const uint8_t *mask, 
   OFX_HIP(hipMemsetAsync(h->st.episode_sums, 0, sizeof(long long) * (p.M + 1), h->stream));
   hipLaunchKernelGGL(k_restart, dim3((T + 255) / 256), dim3(256), 0, h->stream, p);
   OFX_HIP(hipGetLastError());
-  return OFX_OK;
+  return ofx_replay_episode_reset(h, mask);  // QlearnIA.reset (qlearnIA_V2.py:360-368)
 }
 
 extern "C" int ofx_spawn(ofx_handle *h, const int32_t *draws) {

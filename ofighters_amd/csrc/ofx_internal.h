@@ -37,6 +37,8 @@ struct ofx_state {
   long long *episode_sums;         // [M+1]
 };
 
+struct ofx_replay;  // ofx_replay.hip
+
 struct ofx_handle {
   ofx_config cfg;
   hipStream_t stream;
@@ -55,12 +57,15 @@ struct ofx_handle {
   hipEvent_t *ring;                // numbered events for ofx_event_record
   int ring_n;
   int prof_base;                   // ofx_policy_profile: next event pair, -1 = off
+  ofx_replay *replay;              // transition memory (ofx_replay_create), null = none
 };
 
 // kernels / launchers implemented in the other translation units
 int ofx_launch_step(ofx_handle *h, const ofx_action *actions);
 int ofx_launch_raster(ofx_handle *h, int map_type, void *ship_map, void *laser_map);
 int ofx_ensure_scratch(ofx_handle *h, size_t bytes);
+void ofx_replay_free(ofx_handle *h);
+int ofx_replay_episode_reset(ofx_handle *h, const uint8_t *arena_mask);
 
 #define OFX_MAP_BITS_LSB 4 /* internal: 1 bit / cell, pixel p -> bit (p & 31) of word p >> 5 */
 

@@ -23,6 +23,7 @@
 // weights by k_policy_prepare.
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 #include "ofx_internal.h"
 
@@ -719,13 +720,22 @@ struct HeadTailParams {
 
 constexpr int HT_T = 40;              // uprelu3 tile side
 constexpr int HT_Q = HT_T / 2 + 2;    // quads per side (22)
-constexpr int HT_NQ = HT_Q * HT_Q;    // 484
-constexpr int HT_MT = (HT_NQ + 15) / 16;  // 16-quad M-tiles (31)
+constexpr int HT_QW = 24;             // padded quad row: 22 real quads + 2 duplicates of the last one, so that the
+                                      // 4 accumulator registers of a lane are 4 consecutive quads of ONE row
+constexpr int HT_NQP = HT_Q * HT_QW;  // 528
+constexpr int HT_MT = HT_NQP / 16;    // 16-quad M-tiles (33)
 constexpr int HT_L2 = HT_T / 2 + 4;   // uprelu2 patch side (24)
 constexpr int HT_U3 = HT_T + 2;       // uprelu3 tile side incl. halo (42)
-constexpr int HT_U3P = HT_U3 + 2;     // row stride (even -> 8-byte aligned pair reads)
+constexpr int HT_U3S = 48;            // storage row stride: halo columns 0..41, then the landing zone of the cells that
+                                      // stage B computes but nobody reads (column 42 and the padded quads 43..46)
+constexpr int HT_U3PL = (HT_U3 + 2) * HT_U3S + 4;  // plane: halo rows -1..42 (the outer rows are a landing zone too)
+                                                   // + 4 floats in front for cell (-1, -1); multiple of 4 floats
 constexpr int HT_S2 = 100, HT_S3 = 200;
 
+// offset of the uprelu3 cell (channel, halo row, halo column) inside the LDS tile; halo (0, 0) = pixel (r0-1, c0-1)
+__device__ __forceinline__ constexpr int u3o(int cl, int row, int col) {
+  return cl * HT_U3PL + 4 + (row + 1) * HT_U3S + col;
+}
 
 // bilinear x2 (half-pixel) sample at up-res (uy, ux) of a clamp-extended low-res LDS plane whose element
 // [0][0] has low-res coordinates (o_r, o_c)
@@ -748,38 +758,51 @@ __device__ __forceinline__ float up1d(const float *line, int stride, int base, i
   return l0 + (l1 - l0) * w;
 }
 
+// max without the canonicalising v_max(x, x) the compiler puts in front of fmaxf() in IEEE mode (x is an MFMA
+// result here, never a signalling NaN)
+__device__ __forceinline__ float max_raw(float x, float floor) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(floor), "v"(x));
+  return r;
+}
+
 constexpr int HT_L2P = HT_L2 * HT_L2 + 16;  // plane stride of the patch: +16 floats so the 4 channel planes of
                                             // the MFMA A-gather land on different LDS banks
 constexpr int HT_LB2 = HT_T + 4;            // frame-line length of stage B (x' in [c0-2, c0+T+1])
 
+// The f32 MFMAs and the VALU share the SIMD's issue slots on gfx950 (tools/ubench_mix.hip: their rates do not add
+// up), so every VALU instruction costs matrix throughput.  The kernel is written to keep the VALU count per tile
+// low: stage B writes its accumulators with one address computation per M-tile (immediate offsets for the 4
+// registers, bias pre-loaded into the accumulator, no per-cell predicates), stage C has no VALU at all, and the
+// arg-max is a 3-instruction compare/select per value on a compile-time slot id.
 __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
   __shared__ __align__(16) float l2[4 * HT_L2P];
-  __shared__ __align__(16) float u3[4][HT_U3][HT_U3P];
+  __shared__ __align__(16) float u3f[4 * HT_U3PL];
   __shared__ __align__(16) float w4s[8][36];
   __shared__ float hb2[4][HT_LB2], vb2[4][HT_LB2];  // U2[0|199][x'] , U2[y'][0|199]  (border tiles)
   __shared__ float facc[2][2 * HT_T];               // zero-padding corrections of the heat-map frame pixels
-  __shared__ __align__(16) unsigned otab[512];      // quad -> (2qi-1)*U3P + (2qj-1) + 64 | flags << 12 (see below)
-  __shared__ unsigned short atab[512];              // quad -> qi*L2 + qj (A-operand gather base)
+  __shared__ unsigned gtab[HT_NQP / 4];             // quad group g = 4i -> byte offset of its first cell | qi << 16 | qj0 << 24
+  __shared__ unsigned short atab[HT_NQP];           // padded quad -> qi*L2 + qj (A-operand gather base)
   // one workgroup walks the 5 tiles of one tile row of one ship: tables, weights and launch cost are paid once
   constexpr int tiles_x = HT_S3 / HT_T;
   const int s = blockIdx.x / tiles_x, trow = blockIdx.x - s * tiles_x;
   if (p.mask && !p.mask[s]) return;  // block-uniform
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform by construction: keep it in an SGPR
   const int r0 = trow * HT_T, ib = r0 / 2 - 2;   // uprelu3 row of the tiles, uprelu2 row of the patch origin
   const bool top = r0 == 0, bot = r0 + HT_T == HT_S3, hline = top || bot;
   {
     const float wa = p.w4eff[tid], wb = tid < 32 ? p.w4eff[256 + tid] : 0.f;
     (&w4s[0][0])[tid] = wa;
     if (tid < 32) (&w4s[0][0])[256 + tid] = wb;
-    for (int m = tid; m < 512; m += 256) {
-      const int mq = min(m, HT_NQ - 1), qi = mq / HT_Q, qj = mq - qi * HT_Q;
-      // bits 0-3: quad on the tile's outer ring (one of its phases falls outside the 42x42 tile);
-      // bits 4-7: quad one step inside (in an image-border tile one of its phases is a FRAME cell of the plane)
-      unsigned f = (qi == 0 ? 1u : 0u) | (qi == HT_Q - 1 ? 2u : 0u) | (qj == 0 ? 4u : 0u) | (qj == HT_Q - 1 ? 8u : 0u) |
-                   (qi == 1 ? 16u : 0u) | (qi == HT_Q - 2 ? 32u : 0u) | (qj == 1 ? 64u : 0u) | (qj == HT_Q - 2 ? 128u : 0u);
-      if (m >= HT_NQ) f = 15u;
-      otab[m] = (unsigned)((2 * qi - 1) * HT_U3P + (2 * qj - 1) + 64) | (f << 12);
+    for (int m = tid; m < HT_NQP; m += 256) {
+      const int qi = m / HT_QW, qj = min(m - qi * HT_QW, HT_Q - 1);
       atab[m] = (unsigned short)(qi * HT_L2 + qj);
+    }
+    if (tid < HT_NQP / 4) {
+      const int g = 4 * tid, qi = g / HT_QW, qj0 = g - qi * HT_QW;
+      // quad (qi, qj), phase (pa, pb) -> halo cell (2 qi - 1 + pa, 2 qj - 1 + pb); the lane adds its (pa, pb, channel)
+      gtab[tid] = (unsigned)(((2 * qi) * HT_U3S + 2 * qj0) * 4) | ((unsigned)qi << 16) | ((unsigned)qj0 << 24);
     }
   }
   float bestv = -INFINITY;
@@ -802,11 +825,27 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
 #pragma unroll
   for (int u = 0; u < PATCH / 256; u++) vals[u] = up2s[prow[u] + min(max(pcol[u] - 2, 0), HT_S2 - 1)];
 
+  // per-lane constants of the MFMA stage: n = lane & 15 -> (phase, local channel); kq = lane >> 4 -> input channel
+  const int n16 = lane & 15, kq = lane >> 4;
+  const int ph3 = n16 >> 2, cl3 = n16 & 3, pa3 = ph3 >> 1, pb3 = ph3 & 1;
+  // stage-B output address: lane part (channel plane, phase row / column) + gtab part (quad group)
+  char *const wbase = (char *)u3f + (cl3 * HT_U3PL + 4 + pa3 * HT_U3S + pb3 - 1) * 4;
+  const float *const arow = &l2[kq * HT_L2P];
+  // frame cells of the plane (y or x in {0,199}) keep G + bias WITHOUT ReLU: the border pass subtracts the
+  // zero-padding taps first.  y = 0 <=> top tile, quad row 1, phase row 0 ; y = 199 <=> bottom tile, row Q-2, phase row 1;
+  // x = 0 <=> left tile, quad column 1 (register 1 of group 0), phase column 0 ; x = 199 <=> right tile, quad column
+  // Q-2 (register 0 of group 20), phase column 1
+  const int fr_qi = (top && pa3 == 0) ? 1 : (bot && pa3 == 1) ? HT_Q - 2 : -1;
+
 #pragma unroll 1
   for (int tcol = 0; tcol < tiles_x; tcol++) {
   const int c0 = tcol * HT_T, jb = c0 / 2 - 2;
   const bool lef = c0 == 0, rig = c0 + HT_T == HT_S3;
   const bool vline = lef || rig, border = hline || vline;
+  const int fc_q0 = (lef && pb3 == 0) ? 0 : (rig && pb3 == 1) ? HT_Q - 2 : -1, fc_i = lef ? 1 : 0;
+  // 400 stage-C lane-tasks = 6.25 waves: three waves run two passes, one runs a single pass and takes the 33rd
+  // M-tile of stage B instead; the light wave rotates so that the four SIMDs of the CU see the same load
+  const int light = (tcol + (int)blockIdx.x) & 3;
 
   // ---- stage A: the prefetched uprelu2 patch goes to LDS; the next tile's loads are issued right away ----
   {
@@ -834,30 +873,21 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
     __syncthreads();
   }
 
-  // per-lane constants of the MFMA stage: n = lane & 15 -> (phase, local channel); kq = lane >> 4 -> input channel
-  const int n16 = lane & 15, kq = lane >> 4;
-  const int ph3 = n16 >> 2, cl3 = n16 & 3, pa3 = ph3 >> 1, pb3 = ph3 & 1;
-  const unsigned badmask = ((pa3 ? 2u : 1u) | (pb3 ? 8u : 4u)) << 12;  // cell of this phase falls outside the tile
-  const int cell_off = cl3 * HT_U3 * HT_U3P + pa3 * HT_U3P + pb3 - 64;
-  // frame cells of the plane (y or x in {0,199}) keep G + bias WITHOUT ReLU: the border pass subtracts the
-  // zero-padding taps first.  y = 0 <=> top tile, quad row 1, phase row 0 ; y = 199 <=> bottom tile, row Q-2, phase row 1
-  const unsigned framemask = (((top && pa3 == 0) ? 16u : 0u) | ((bot && pa3 == 1) ? 32u : 0u) |
-                              ((lef && pb3 == 0) ? 64u : 0u) | ((rig && pb3 == 1) ? 128u : 0u)) << 12;
-
   // stage-C ownership: a lane owns 4 horizontally adjacent uprelu3 pixels (one aligned b128 LDS read serves four
-  // MFMA B operands); 400 such lane-tasks per tile = pass 0 (all 256 lanes) + pass 1 (lanes 0..143).
-  // cacc[pass][pixel] = the 4 output phases of that pixel's heat-map quad.
+  // MFMA B operands); 400 such lane-tasks per tile = pass 0 (all 256 lanes) + pass 1 (144 lanes of the three
+  // non-light waves).  cacc[pass][pixel] = the 4 output phases of that pixel's heat-map quad, bias pre-loaded.
   constexpr int CT = (HT_T * HT_T) / 4;          // 400 lane-tasks
-  int coff[2];                                   // LDS offset of the task's window origin inside a channel plane
+  const bool pass1 = wv != light;                // wave-uniform
+  int ctask[2], coff[2];                         // task, LDS offset of its window origin inside a channel plane
   f32x4 cacc[2][4];
+  ctask[0] = tid;
+  ctask[1] = min(256 + (wv - (wv > light ? 1 : 0)) * 64 + lane, CT - 1);
 #pragma unroll
   for (int q = 0; q < 2; q++) {
-    const int task = min(q * 256 + tid, CT - 1);
-    coff[q] = (task / (HT_T / 4)) * HT_U3P + 4 * (task % (HT_T / 4));
+    coff[q] = u3o(0, ctask[q] / (HT_T / 4), 4 * (ctask[q] % (HT_T / 4)));
 #pragma unroll
-    for (int g = 0; g < 4; g++) cacc[q][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < 4; g++) cacc[q][g] = (f32x4){bias4, bias4, bias4, bias4};
   }
-  const bool pass1 = wv * 64 < CT - 256;         // wave-uniform: waves 0..2 have lanes in pass 1
 
 #pragma unroll 1
   for (int half = 0; half < 2; half++) {
@@ -867,32 +897,46 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
 #pragma unroll
       for (int j = 0; j < 9; j++) bw[j] = p.w3mf[(half * 36 + 4 * j + kq) * 16 + n16];
       const float bias3 = p.b3[4 * half + cl3];
-      float *ubase = &u3[0][0][0] + cell_off;
+      const f32x4 binit = {bias3, bias3, bias3, bias3};
       // two M-tiles per iteration, their MFMA chains interleaved (16x16x4: 32-cycle issue, 40-cycle dependent
       // latency -> two independent accumulators keep the matrix pipe full)
+      auto run = [&](auto BT) {
+        constexpr bool BORDER = decltype(BT)::value;
 #pragma unroll 1
-      for (int mt = wv; mt < HT_MT; mt += 8) {
-        const int m0 = mt * 16, m1 = min(mt + 4, HT_MT - 1) * 16;
-        const bool two = mt + 4 < HT_MT;  // wave-uniform
-        const float *a0 = &l2[kq * HT_L2P] + atab[m0 + n16];  // A row = quad m + (lane & 15), k = 4 j + kq
-        const float *a1 = &l2[kq * HT_L2P] + atab[m1 + n16];
-        f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+        for (int it = 0; it < 5; it++) {
+          int mt0, mt1;
+          bool two = true;  // wave-uniform
+          if (it < 4) { mt0 = wv + 8 * it; mt1 = mt0 + 4; }
+          else { if (wv != light) break; mt0 = mt1 = HT_MT - 1; two = false; }
+          const float *a0 = arow + atab[mt0 * 16 + n16];  // A row = quad m + (lane & 15), k = 4 j + kq
+          const float *a1 = arow + atab[mt1 * 16 + n16];
+          f32x4 d0 = binit, d1 = binit;
 #pragma unroll
-        for (int j = 0; j < 9; j++) {  // tap j, channel kq
-          d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[(j / 3) * HT_L2 + (j % 3)], bw[j], d0, 0, 0, 0);
-          d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[(j / 3) * HT_L2 + (j % 3)], bw[j], d1, 0, 0, 0);
-        }
-        // D: col = lane & 15, row = 4 (lane >> 4) + reg -> quads m + 4 kq .. + 3
-        const uint4 oa = *reinterpret_cast<const uint4 *>(&otab[m0 + 4 * kq]);
-        const uint4 ob = *reinterpret_cast<const uint4 *>(&otab[m1 + 4 * kq]);
-        const unsigned o0[4] = {oa.x, oa.y, oa.z, oa.w}, o1[4] = {ob.x, ob.y, ob.z, ob.w};
+          for (int j = 0; j < 9; j++) {  // tap j, channel kq
+            d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[(j / 3) * HT_L2 + (j % 3)], bw[j], d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[(j / 3) * HT_L2 + (j % 3)], bw[j], d1, 0, 0, 0);
+          }
+          // D: col = lane & 15, row = 4 (lane >> 4) + reg -> the 4 consecutive quads of group mt * 4 + kq
+          const unsigned g0 = gtab[mt0 * 4 + kq], g1 = gtab[mt1 * 4 + kq];
+          float f0[4] = {0.f, 0.f, 0.f, 0.f}, f1[4] = {0.f, 0.f, 0.f, 0.f};  // ReLU floor; -inf keeps a frame cell raw
+          if (BORDER) {
+            const float r0f = (int)((g0 >> 16) & 0xFFu) == fr_qi ? -INFINITY : 0.f;
+            const float r1f = (int)((g1 >> 16) & 0xFFu) == fr_qi ? -INFINITY : 0.f;
+            const bool c0f = (int)(g0 >> 24) == fc_q0, c1f = (int)(g1 >> 24) == fc_q0;
+            f0[0] = (c0f && fc_i == 0) ? -INFINITY : r0f; f0[1] = (c0f && fc_i == 1) ? -INFINITY : r0f; f0[2] = f0[3] = r0f;
+            f1[0] = (c1f && fc_i == 0) ? -INFINITY : r1f; f1[1] = (c1f && fc_i == 1) ? -INFINITY : r1f; f1[2] = f1[3] = r1f;
+          }
+          float *w0 = (float *)(wbase + (g0 & 0xFFFFu));
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-          if (!(o0[i] & badmask)) ubase[o0[i] & 0xFFFu] = fmaxf(d0[i] + bias3, (o0[i] & framemask) ? -INFINITY : 0.f);
-          if (two && !(o1[i] & badmask))
-            ubase[o1[i] & 0xFFFu] = fmaxf(d1[i] + bias3, (o1[i] & framemask) ? -INFINITY : 0.f);
+          for (int i = 0; i < 4; i++) w0[2 * i] = max_raw(d0[i], f0[i]);
+          if (two) {
+            float *w1 = (float *)(wbase + (g1 & 0xFFFFu));
+#pragma unroll
+            for (int i = 0; i < 4; i++) w1[2 * i] = max_raw(d1[i], f1[i]);
+          }
         }
-      }
+      };
+      if (border) run(std::true_type{}); else run(std::false_type{});
     }
     __syncthreads();
     if (border && !(p.ablate & 8)) {
@@ -928,13 +972,13 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
           }
         }
         const int ty = y - (r0 - 1), tx = x - (c0 - 1);
-        const float v = fmaxf(u3[cl][ty][tx] - corr, 0.f);
-        u3[cl][ty][tx] = v;
+        const float v = fmaxf(u3f[u3o(cl, ty, tx)] - corr, 0.f);
+        u3f[u3o(cl, ty, tx)] = v;
         // the halo cells outside the image are clamp copies of exactly these frame cells
         const int oy = (y == 0) ? -1 : (y == HT_S3 - 1) ? 1 : 0, ox = (x == 0) ? -1 : (x == HT_S3 - 1) ? 1 : 0;
-        if (oy) u3[cl][ty + oy][tx] = v;
-        if (ox) u3[cl][ty][tx + ox] = v;
-        if (oy && ox) u3[cl][ty + oy][tx + ox] = v;
+        if (oy) u3f[u3o(cl, ty + oy, tx)] = v;
+        if (ox) u3f[u3o(cl, ty, tx + ox)] = v;
+        if (oy && ox) u3f[u3o(cl, ty + oy, tx + ox)] = v;
       }
       __syncthreads();
       // zero-padding corrections of the heat-map frame pixels of this tile, accumulated over the two halves:
@@ -950,7 +994,8 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
           for (int dx = -1; dx <= 1; dx++) {
             const int xc = min(max(x + dx, 0), PS - 1);
 #pragma unroll
-            for (int cl = 0; cl < 4; cl++) corr += w[(trow * 3 + dx + 1) * 8 + cl] * up1d(&u3[cl][R][0], 1, c0 - 1, xc);
+            for (int cl = 0; cl < 4; cl++)
+              corr += w[(trow * 3 + dx + 1) * 8 + cl] * up1d(&u3f[u3o(cl, R, 0)], 1, c0 - 1, xc);
           }
         } else if (line == 1 && vline) {
           const int tcol = lef ? 0 : 2, y = 2 * r0 + k, Cc = (lef ? 0 : HT_S3 - 1) - (c0 - 1);
@@ -960,7 +1005,7 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
             if (uy < 0 || uy >= PS) continue;
 #pragma unroll
             for (int cl = 0; cl < 4; cl++)
-              corr += w[((dy + 1) * 3 + tcol) * 8 + cl] * up1d(&u3[cl][0][Cc], HT_U3P, r0 - 1, uy);
+              corr += w[((dy + 1) * 3 + tcol) * 8 + cl] * up1d(&u3f[u3o(cl, 0, Cc)], HT_U3S, r0 - 1, uy);
           }
         }
         facc[line][k] += corr;
@@ -970,13 +1015,12 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
     // ---- stage C: 4 channels of the heat-map quads, also on the matrix cores.  Per output pixel the layer is
     // out[phase] = sum_k in[k] W[k][phase], k = (channel, tap): v_mfma_f32_4x4x1_16B_f32 with CBSZ = 4 broadcasts the
     // A block of lanes 0-3 (the 4 phase weights of tap k) to all 16 blocks, B = one input value per lane (pixel):
-    // D[phase][pixel] += W[k][phase] * in[pixel][k] -- an M = 4, N = 64, K = 1 step at the full f32 MFMA rate, with
-    // N = 4 phases exactly (no padding).  36 steps per half and group.
+    // D[phase][pixel] += W[k][phase] * in[pixel][k] -- an M = 4, N = 64, K = 1 step with N = 4 phases exactly (no
+    // padding) and not a single VALU instruction.  36 steps per half and group.
     if (!(p.ablate & 4)) {
       float wa[36];  // A operands: lane i < 4 holds phase i
 #pragma unroll
       for (int k = 0; k < 36; k++) wa[k] = w4s[4 * half + k / 9][(lane & 3) * 9 + k % 9];
-      const float *ub = &u3[0][0][0];
 #pragma unroll
       for (int q = 0; q < 2; q++) {
         if (q == 1 && !pass1) break;
@@ -984,7 +1028,7 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
         for (int cl = 0; cl < 4; cl++)
 #pragma unroll
           for (int a = 0; a < 3; a++) {
-            const float *row = ub + coff[q] + cl * HT_U3 * HT_U3P + a * HT_U3P;
+            const float *row = u3f + coff[q] + cl * HT_U3PL + a * HT_U3S;
             const float4 lo = *reinterpret_cast<const float4 *>(row);
             const float4 hi = *reinterpret_cast<const float4 *>(row + 4);
             const float v[6] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y};
@@ -1000,26 +1044,68 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
   }
 
   // ---- outputs + arg-max (first maximum in C order) ----
+  if (border) {  // zero-padding corrections of the frame pixels: only the lanes that own them
 #pragma unroll
-  for (int q = 0; q < 2; q++) {
-    const int task = q * 256 + tid;
-    if (task < CT) {
-      const int li = r0 + task / (HT_T / 4), lj0 = c0 + 4 * (task % (HT_T / 4));
+    for (int q = 0; q < 2; q++) {
+      const int lt = ctask[q] / (HT_T / 4), c4 = ctask[q] - lt * (HT_T / 4);
+      if (hline && lt == (top ? 0 : HT_T - 1)) {  // y = 0 (phase row 0) or y = 399 (phase row 1)
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+#pragma unroll
+          for (int b = 0; b < 2; b++) {
+            const float c = facc[0][2 * (4 * c4 + g) + b];
+            if (top) cacc[q][g][b] -= c; else cacc[q][g][2 + b] -= c;
+          }
+      }
+      if (vline && c4 == (lef ? 0 : HT_T / 4 - 1)) {  // x = 0 (pixel 0, phase column 0) or x = 399
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+          const float c = facc[1][2 * lt + r];
+          if (lef) cacc[q][0][2 * r] -= c; else cacc[q][3][2 * r + 1] -= c;
+        }
+      }
+    }
+  }
+  if (p.heat) {
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int task = q * 256 + tid;  // a light wave's q = 1 registers hold nothing
+      const bool mine = q == 0 ? true : (pass1 && 256 + (wv - (wv > light ? 1 : 0)) * 64 + lane < CT);
+      if (!mine) continue;
+      (void)task;
+      const int li = r0 + ctask[q] / (HT_T / 4), lj0 = c0 + 4 * (ctask[q] % (HT_T / 4));
 #pragma unroll
       for (int g = 0; g < 4; g++)
 #pragma unroll
-        for (int ph = 0; ph < 4; ph++) {
-          const int y = 2 * li + (ph >> 1), x = 2 * (lj0 + g) + (ph & 1);
-          float val = cacc[q][g][ph] + bias4;
-          if (border) {
-            if (y == 0 || y == PS - 1) val -= facc[0][x - 2 * c0];
-            if (x == 0 || x == PS - 1) val -= facc[1][y - 2 * r0];
-          }
-          const unsigned k = (unsigned)(y * PS + x);
-          if (p.heat) p.heat[(size_t)s * PS * PS + k] = val;
-          if (val > bestv || (val == bestv && k < bestk)) { bestv = val; bestk = k; }
-        }
+        for (int ph = 0; ph < 4; ph++)
+          p.heat[(size_t)s * PS * PS + (size_t)(2 * li + (ph >> 1)) * PS + 2 * (lj0 + g) + (ph & 1)] = cacc[q][g][ph];
     }
+  }
+  {
+    // per thread the 32 values are visited in increasing flat index, so a strict > keeps the first maximum; the slot
+    // is a compile-time constant (3 VALU instructions per value); lanes past the 400th task hold copies of task 399
+    float tv = -INFINITY;
+    int ts = 0;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      if (q == 1 && !pass1) break;
+#pragma unroll
+      for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+#pragma unroll
+          for (int b = 0; b < 2; b++) {
+            const float val = cacc[q][g][2 * r + b];
+            const bool gt = val > tv;
+            tv = gt ? val : tv;
+            ts = gt ? (q * 16 + r * 8 + g * 2 + b) : ts;
+          }
+    }
+    const int task = (ts & 16) ? ctask[1] : ctask[0];
+    const int lt = task / (HT_T / 4), c4 = task - lt * (HT_T / 4);
+    const int y = 2 * (r0 + lt) + ((ts >> 3) & 1), x = 2 * (c0 + 4 * c4 + ((ts >> 1) & 3)) + (ts & 1);
+    const unsigned k = (unsigned)(y * PS + x);
+    if (tv > bestv || (tv == bestv && k < bestk)) { bestv = tv; bestk = k; }
   }
   __syncthreads();  // facc / l2 are rewritten by the next tile
   }  // tile loop
@@ -1515,6 +1601,16 @@ extern "C" int ofx_policy_forward(ofx_handle *h, const float *weights, const uin
   hipLaunchKernelGGL(k_policy_finish, dim3((S + 255) / 256), dim3(256), 0, h->stream, S, ship_mask, ws.best,
                      ipointer ? ipointer : ws.ipointer);
   OFX_HIP(hipGetLastError());
+  return OFX_OK;
+}
+
+// (iaction, ipointer) of the last forward / explore, for the other translation units (ofx_replay.hip)
+int ofx_policy_results(ofx_handle *h, int32_t **iaction, int32_t **ipointer) {
+  PolicyWs ws;
+  int rc = policy_workspace(h, &ws);
+  if (rc) return rc;
+  *iaction = ws.iaction;
+  *ipointer = ws.ipointer;
   return OFX_OK;
 }
 

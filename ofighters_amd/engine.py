@@ -312,6 +312,63 @@ class ArenaBatch:
     def policy_profile(self, event_base):
         nat.check(nat.lib().ofx_policy_profile(self._h, event_base))
 
+    # ------------------------------------------------------------ replay memory
+    TRANSITION_DTYPE = np.dtype([("tick_prev", np.int32), ("tick_next", np.int32), ("frame_prev", np.int32),
+                                 ("frame_next", np.int32), ("ship", np.int32),
+                                 ("iaction", np.int32), ("px", np.int32), ("py", np.int32), ("reward", np.int32),
+                                 ("done", np.int32), ("head_prev", np.float32, 8), ("head_next", np.float32, 8)])
+
+    def replay_create(self, capacity=400, frames=0):
+        """Trainer.memory = deque(maxlen=memory_size) per arena (qlearnIA_V2.py:58)."""
+        nat.check(nat.lib().ofx_replay_create(self._h, int(capacity), int(frames)))
+        self.replay_capacity = int(capacity)
+
+    def replay_capture(self, tick, ship_mask_ptr=None, iaction_ptr=None, ipointer_ptr=None):
+        """QlearnIA.play bookkeeping + Trainer.remember for this lock-step; call before step()."""
+        nat.check(nat.lib().ofx_replay_capture(self._h, int(tick), ship_mask_ptr, iaction_ptr, ipointer_ptr))
+
+    def replay_count(self):
+        cnt = np.empty(self.N, np.int32)
+        app = np.empty(self.N, np.int64)
+        nat.check(nat.lib().ofx_replay_count(self._h, cnt.ctypes.data_as(C.c_void_p), app.ctypes.data_as(C.c_void_p)))
+        return cnt, app
+
+    def replay_rows(self, arena):
+        """list(memory) of one arena, oldest first, as a structured array."""
+        rows = np.zeros(self.replay_capacity, self.TRANSITION_DTYPE)
+        n = C.c_int32()
+        nat.check(nat.lib().ofx_replay_rows_host(self._h, int(arena), rows.ctypes.data_as(C.c_void_p), C.byref(n)))
+        return rows[:n.value]
+
+    def replay_frame(self, arena, tick):
+        """(ship_map, laser_map) uint8 [H][W] of a stored lock-step."""
+        nb = self.W * self.H // 8
+        a, b = np.empty(nb, np.uint8), np.empty(nb, np.uint8)
+        nat.check(nat.lib().ofx_replay_frame_host(self._h, int(arena), int(tick), a.ctypes.data_as(C.c_void_p),
+                                                   b.ctypes.data_as(C.c_void_p)))
+        un = lambda x: np.unpackbits(x, bitorder="little").reshape(self.H, self.W)
+        return un(a), un(b)
+
+    def replay_sample(self, seed, draw, batch):
+        """random.sample(memory, min(batch, len)) per arena -> (slot DeviceBuffer [N][batch], n DeviceBuffer [N])."""
+        slot, n = DeviceBuffer(4 * self.N * batch), DeviceBuffer(4 * self.N)
+        nat.check(nat.lib().ofx_replay_sample(self._h, seed, int(draw), int(batch), slot.ptr, n.ptr))
+        return slot, n
+
+    def replay_gather(self, slot, batch, with_maps=True):
+        """Materialise sampled rows: (rows [N][batch], bits_prev, bits_next uint32 [N][batch][2][W*H/32]) on the host."""
+        rows = DeviceBuffer(self.N * batch * self.TRANSITION_DTYPE.itemsize)
+        words = self.W * self.H // 32
+        bp = DeviceBuffer(4 * self.N * batch * 2 * words) if with_maps else None
+        bn = DeviceBuffer(4 * self.N * batch * 2 * words) if with_maps else None
+        nat.check(nat.lib().ofx_replay_gather(self._h, slot.ptr, int(batch), rows.ptr, bp.ptr if bp else None,
+                                               bn.ptr if bn else None))
+        self.sync()
+        out = [rows.download(self.TRANSITION_DTYPE, (self.N, batch))]
+        if with_maps:
+            out += [bp.download(np.uint32, (self.N, batch, 2, words)), bn.download(np.uint32, (self.N, batch, 2, words))]
+        return out
+
     def policy_explore(self, epsilon, seed, tick=None, collecting=False, ship_mask_ptr=None, iaction_ptr=None,
                        ipointer_ptr=None):
         """epsilon-greedy / collecting-phase random play over the last forward's results."""

@@ -120,7 +120,7 @@ def pack(m):
 
 
 def run_trace(name, ships, seed, episodes, ticks=EPISODE_TICKS, map_every=1,
-              init=None, scripts=None, box=None, lmax=None):
+              init=None, scripts=None, box=None, lmax=None, setup=None, clock=None, extra=None):
     """Drive the reference exactly as the GUI does and dump a trace."""
     random.seed(seed)
     TAP.log = []
@@ -140,6 +140,8 @@ def run_trace(name, ships, seed, episodes, ticks=EPISODE_TICKS, map_every=1,
     if scripts is not None:
         for s, sc in zip(bg.ships, scripts):
             s.agent = Agent(bot=ScriptBot(sc))
+    if setup is not None:
+        setup(bg)
     seen = [[] for _ in range(M)]
     for s, st in zip(bg.ships, seen):
         tap_agent(s, st)
@@ -171,6 +173,8 @@ def run_trace(name, ships, seed, episodes, ticks=EPISODE_TICKS, map_every=1,
                 # GUI clean-up happens at the start of the next GUI tick,
                 # before Battleground.frame (ofighters.py:663-667)
                 bg.lasers = [l for l in bg.lasers if l.state != "destroyed"]
+                if clock is not None:
+                    clock(t)
                 bg.frame()
                 for i, s in enumerate(bg.ships):
                     a = bg.actions[i]
@@ -220,7 +224,8 @@ def run_trace(name, ships, seed, episodes, ticks=EPISODE_TICKS, map_every=1,
         laser_x=lx, laser_y=ly, laser_owner=lo, laser_destroyed=ld,
         map_ticks=np.array(map_ticks, dtype=np.int32),
         ship_maps=np.array(ship_maps), laser_maps=np.array(laser_maps),
-        reset_draws=reset_draws, reset_state=reset_state, ep_scores=ep_scores)
+        reset_draws=reset_draws, reset_state=reset_state, ep_scores=ep_scores,
+        **(extra() if extra is not None else {}))
     kills = int((ship_alive[ticks - 1::ticks] == 0).sum())
     print("step_%-22s M=%d T=%d maxL=%d deaths=%d reward_sum=%d" % (
         name, M, T, L, kills, int(ep_scores.sum())))
@@ -426,6 +431,62 @@ def scratch_nn_cases():
     print("scratch_nn:", {k: v.shape for k, v in out.items() if k.startswith("y_")})
 
 
+def replay_traces():
+    """Trainer.remember / QlearnIA.play bookkeeping (qlearnIA_V2.py:58,237-238,360-403): QlearnIA ships kept in
+    their collecting phase (random_play, :393-395 - the Keras model is a mock and is never called) next to random
+    bots; every remember() call is recorded in order together with the lock-step and ship it came from."""
+    import ofighters.agents.qlearnIA_V2 as ql
+
+    for name, ships, seed, box in (("replay_open", {"QlearnIA": 3, "random": 2}, 11, None),
+                                   ("replay_brawl", {"random": 1, "QlearnIA": 4}, 12, (150, 250))):
+        ctx = {"t": 0, "ship": -1}
+        rows = []
+        ql.TRAINER.memory.clear()
+
+        def remember(state, iaction, ipointer, reward, next_state, done, _orig=ql.TRAINER.remember.__func__):
+            rows.append((ctx["t"], ctx["ship"], int(iaction), int(ipointer[0]), int(ipointer[1]), int(reward),
+                         int(bool(done)), np.array(next_state.vector[:8, 0], dtype=np.float64)))
+            _orig(ql.TRAINER, state, iaction, ipointer, reward, next_state, done)
+
+        ql.TRAINER.remember = remember
+        chosen = []  # (tick, ship, iaction, px, py) for every play() that chose an action
+
+        def setup(bg):
+            for i, s in enumerate(bg.ships):
+                if s.agent.behavior != "QlearnIA":
+                    continue
+                s.agent.collecting_steps = 10 ** 9   # harness: stay in the collecting phase
+                s.agent.is_learning = False          # harness: no replay()/fit on the mock model
+
+                def play(obs, _i=i, _a=s.agent, _orig=s.agent.play):
+                    ctx["ship"] = _i
+                    was_done = _a.done
+                    out = _orig(obs)
+                    if not was_done:
+                        chosen.append((ctx["t"], _i, int(_a.previous_action), int(_a.previous_pointer[0]),
+                                       int(_a.previous_pointer[1])))
+                    return out
+
+                s.agent.bot_play = play
+
+        def clock(t):
+            ctx["t"] = t
+
+        def extra():
+            mem = list(ql.TRAINER.memory)
+            tail = rows[-len(mem):]
+            for m, r in zip(mem, tail):   # the deque holds exactly the last maxlen remembered rows, in order
+                assert (m[1], m[2][0], m[2][1], m[3], bool(m[5])) == (r[2], r[3], r[4], r[5], bool(r[6]))
+            return dict(
+                replay_rows=np.array([r[:7] for r in rows], dtype=np.int32),   # tick_next, ship, iaction, px, py, reward, done
+                replay_head_next=np.array([r[7] for r in rows], dtype=np.float64),
+                replay_chosen=np.array(chosen, dtype=np.int32),
+                replay_maxlen=np.int32(ql.TRAINER.memory.maxlen), replay_len=np.int32(len(mem)))
+
+        run_trace(name, ships, seed, 3, map_every=50, box=box, setup=setup, clock=clock, extra=extra)
+        del ql.TRAINER.remember
+
+
 def epsilon_cases():
     """Exploration schedules (lib/epsilon.py:36-86): value sequences incl. the period wrap and set()."""
     with contextlib.redirect_stdout(_sink):
@@ -453,3 +514,4 @@ if __name__ == "__main__":
     geometry_cases()
     scratch_nn_cases()
     epsilon_cases()
+    replay_traces()

@@ -270,3 +270,66 @@ def policy_explore(cfg, eps, seed, global_arena, ship, tick, collecting=False):
     out = np.zeros(3, np.int32)
     hit = L.orc_policy_explore(C.byref(cfg), float(eps), C.c_uint64(seed), global_arena, ship, tick, int(collecting), _p(out))
     return (int(out[0]), int(out[1]), int(out[2])) if hit else None
+
+
+# ---- replay memory (test infrastructure; small cases only - pure Python) -------------------------------------------
+class ReplayMemory:
+    """CPU restatement of Trainer.memory = deque(maxlen=memory_size) (agents/qlearnIA_V2.py:58), Trainer.remember
+    (:237-238) and the bookkeeping QlearnIA.play does around the action choice (:370-403) for the capturing ships of
+    ONE arena.  Pinned by tests/golden/step_replay_*.npz (every remember() call of the live reference, in order).
+
+    A row is (tick_prev, tick_next, ship, iaction, px, py, reward, done, head_prev, head_next).  The reference stores
+    references to Observation objects that every ship of a tick shares and mutates (lib/battleground.py:150), so the
+    `vector` found in its memory is the LAST analysed ship's; this restatement (like the device code) keeps the
+    capturing ship's own head instead - the value `next_state.vector[:8]` has at the moment remember() is called."""
+
+    def __init__(self, n_ships, capacity=400):
+        from collections import deque
+        self.memory = deque(maxlen=capacity)
+        self.appended = 0
+        self.M = n_ships
+        self.reset()
+
+    def reset(self, ships=None):
+        """QlearnIA.reset (:360-368): done = False, previous_obs = previous_action = previous_pointer = None."""
+        if ships is None:
+            self.latched = [False] * self.M
+            self.prev = [None] * self.M
+        else:
+            for i in ships:
+                self.latched[i], self.prev[i] = False, None
+
+    def play(self, tick, ship, head8, obs_done, chosen):
+        """One QlearnIA.play(obs) call.  `chosen` = (iaction, (px, py)) is what the action choice returns when it is
+        reached (it is not reached once the agent is done).  Returns True when an action was chosen."""
+        if self.latched[ship]:                      # :373-374
+            return False
+        if obs_done:                                # :376-383 (replay()/fit is out of scope)
+            self.latched[ship] = True
+        reward = int(head8[0])                      # obs.reward (observation.py:103)
+        if self.prev[ship] is not None:             # :385-387
+            pt, ph, ia, (px, py) = self.prev[ship]
+            self.memory.append((pt, tick, ship, ia, px, py, reward, int(bool(obs_done)),
+                                np.asarray(ph, np.float32), np.asarray(head8, np.float32)))
+            self.appended += 1
+        ia, ip = chosen                             # :389-396
+        self.prev[ship] = (tick, np.array(head8, np.float64), int(ia), (int(ip[0]), int(ip[1])))   # :397-399
+        return True
+
+    def rows(self):
+        return list(self.memory)
+
+
+def replay_sample(capacity_count, batch, seed, global_arena, draw):
+    """random.sample(memory, min(batch, len(memory))) (qlearnIA_V2.py:241-243) on the counter RNG: Floyd's subset
+    sampling, draw j from Philox counter (global arena, j, draw, stream 3).  Returns row indices, oldest first."""
+    n = min(batch, capacity_count)
+    out = []
+    for j in range(n):
+        top = capacity_count - n + j
+        r = philox(global_arena, j, draw, 3, seed)
+        t = (int(r[0]) * (top + 1)) >> 32
+        if t in out:
+            t = top
+        out.append(t)
+    return out

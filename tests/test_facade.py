@@ -20,12 +20,14 @@ SEEDED = {"random4_s1": (1, {"random": 4}), "random8_s42": (42, {"random": 8}),
           "turret8_s9": (9, {"turret": 8})}
 
 
-def replay_seeded(name, engine_factory):
+def replay_seeded(name, engine_factory, setup=None):
     seed, ships = SEEDED[name]
     z = load_trace(name)
     M = z["init_state"].shape[0]
     random.seed(seed)
     bg = Battleground(ships=ships, engine=engine_factory(M))
+    if setup is not None:
+        setup(bg)
     assert [(s.body.x, s.body.y) for s in bg.ships] == [tuple(r) for r in z["spawn_draws"]]
     ticks, episodes = int(z["ticks"]), int(z["episodes"])
     map_idx = {int(t): k for k, t in enumerate(z["map_ticks"])}
@@ -59,6 +61,42 @@ def replay_seeded(name, engine_factory):
 def test_facade_reproduces_reference_from_seed_cpu(name):
     from tests.oracle_batch import OracleEngine
     replay_seeded(name, lambda M: OracleEngine(M))
+
+
+def _qlearnia_collecting_run(engine_factory):
+    """The reference's own QlearnIA ships (collecting phase: random_play) next to random bots, from the seed alone;
+    afterwards the shared Trainer.memory holds exactly the reference's last 400 remembered rows."""
+    from ofighters_amd.agents import qlearn
+    qlearn.TRAINER = None
+    qlearn.QlearnIA.max_id = 1
+    SEEDED["replay_open"] = (11, {"QlearnIA": 3, "random": 2})
+
+    def setup(bg):
+        for s in bg.ships:
+            if s.agent.behavior == "QlearnIA":
+                s.agent.collecting_steps = 10 ** 9       # same harness setting as oracle/gen_golden.py
+    try:
+        replay_seeded("replay_open", engine_factory, setup)
+        z = load_trace("replay_open")
+        mem = list(qlearn.TRAINER.memory)
+        ref = z["replay_rows"][-len(mem):]
+        assert len(mem) == int(z["replay_len"]) == qlearn.TRAINER.memory.maxlen
+        got = [[m[1], m[2][0], m[2][1], m[3], int(bool(m[5]))] for m in mem]
+        assert got == ref[:, 2:].tolist()
+    finally:
+        del SEEDED["replay_open"]
+        qlearn.TRAINER = None
+
+
+def test_facade_qlearnia_memory_reproduces_reference_cpu():
+    from tests.oracle_batch import OracleEngine
+    _qlearnia_collecting_run(lambda M: OracleEngine(M))
+
+
+@pytest.mark.gpu
+def test_facade_qlearnia_memory_reproduces_reference_gpu():
+    from ofighters_amd import ArenaBatch
+    _qlearnia_collecting_run(lambda M: ArenaBatch(1, M))
 
 
 @pytest.mark.gpu
