@@ -71,6 +71,8 @@ struct PrepLayout {
   int w4eff;          // [4 phases][9 low-res taps][8 ci] (v1 kernel)
   int w4eff_c;        // [8 ci][4 phases][9 taps] (fused kernel: one contiguous slice per input channel)
   int w4raw;          // [9][8]
+  int efr;            // [line h|v][side first|last][parity 2][low-res offset 3][ci 8]: phase weights of the taps of
+                      // upconv4 that fall into the zero padding of a frame pixel (k_head_tail border pass)
   int b4;             // [1]
   int total;
 };
@@ -85,6 +87,7 @@ static PrepLayout prep_layout() {
   L.w4eff = off; off += 4 * 9 * 8;
   L.w4eff_c = off; off += 8 * 4 * 9;
   L.w4raw = off; off += 72;
+  L.efr = off; off += 2 * 2 * 2 * 3 * 8;
   L.b4 = off; off += 1;
   off += 8;                      // 8 zeros: the background of conv1's binary input
   L.total = (off + 63) & ~63;
@@ -95,7 +98,7 @@ struct PrepParams {
   const float *w;
   float *prep;
   int src_k[7], src_b[7], src_g[7], cin[7], cout[7], dst_w[7], dst_b[7];
-  int src_k4, src_b4, dst_w4eff, dst_w4raw, dst_b4;
+  int src_k4, src_b4, dst_w4eff, dst_w4raw, dst_b4, dst_efr;
   int dst_w4eff_c, dst_w3mf;
   int dst_bg[4];
 };
@@ -137,6 +140,17 @@ __global__ void k_policy_prepare(PrepParams p) {
     p.prep[p.dst_w4eff_c + (ci * 4 + ph) * 9 + tap] = acc;
   }
   for (int e = tid; e < 72; e += blockDim.x) p.prep[p.dst_w4raw + e] = p.w[p.src_k4 + e];
+  // frame pixels of the heat map: the conv taps of the row (column) outside the image, in phase form along the
+  // line: pixel 2j + b of the line gets sum_o E[b][o] L[j + o - 1] of the low-res frame row (column) L
+  for (int e = tid; e < 2 * 2 * 2 * 3 * 8; e += blockDim.x) {
+    const int ci = e % 8, o = (e / 8) % 3, b = (e / 24) % 2, side = (e / 48) % 2, isv = e / 96;
+    float acc = 0.f;
+    for (int d = 0; d < 3; d++) {
+      const int tap = isv ? d * 3 + (side ? 2 : 0) : (side ? 2 : 0) * 3 + d;
+      acc += p.w[p.src_k4 + tap * 8 + ci] * up_coef(b, d, o);
+    }
+    p.prep[p.dst_efr + e] = acc;
+  }
   // background chain of the trunk: an all-empty window (input 0) gives relu(b1') after layer 1, a window of that
   // constant gives a constant after layer 2, ... -- same fma order (ci outer, tap inner) as the conv kernels, so
   // the skipped waves write bit-identical values
@@ -512,12 +526,52 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const float *A, int lda, const
   }
 }
 
+// Split-K form for the tall-K dense1 (M = arenas, N = 100, K = 5000): one wave per (32x32 tile, K chunk), partial
+// sums P[chunk][M][N] reduced in a fixed order by the consumer (k_head_dense) - no atomics, bit-reproducible.
+// K is walked 8 at a time with the k-slots permuted (slot kh of step j <-> k = k0 + 4 kh + j) so that a lane
+// fetches its A operands with one 16-byte load per 4 MFMAs; Kc % 8 == 0, lda % 4 == 0, A 16-byte aligned.
+__global__ __launch_bounds__(256) void k_gemm_f32_splitk(const float *A, int lda, const float *B, int ldb, float *P,
+                                                         int M, int N, int Kc, int tiles, int jobs) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int tiles_n = (N + 31) / 32;
+  const int job = blockIdx.x * 4 + wv;
+  const int chunk = job / tiles, tile = job - chunk * tiles;
+  if (job >= jobs) return;  // wave-uniform
+  const int m0 = (tile / tiles_n) * 32, n0 = (tile % tiles_n) * 32;
+  const int r = m0 + (lane & 31), c = n0 + (lane & 31), kh = lane >> 5;
+  const bool rv = r < M, cv = c < N;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; i++) acc[i] = 0.f;
+  const float *ap = A + (size_t)(rv ? r : 0) * lda + (size_t)chunk * Kc + 4 * kh;
+  const float *bp = B + ((size_t)chunk * Kc + 4 * kh) * ldb + (cv ? c : 0);
+#pragma unroll 2
+  for (int k0 = 0; k0 < Kc; k0 += 8) {
+    const float4 a4 = *reinterpret_cast<const float4 *>(ap + k0);
+    const float b0 = bp[(size_t)(k0 + 0) * ldb], b1 = bp[(size_t)(k0 + 1) * ldb], b2 = bp[(size_t)(k0 + 2) * ldb],
+                b3 = bp[(size_t)(k0 + 3) * ldb];
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rv ? a4.x : 0.f, cv ? b0 : 0.f, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rv ? a4.y : 0.f, cv ? b1 : 0.f, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rv ? a4.z : 0.f, cv ? b2 : 0.f, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rv ? a4.w : 0.f, cv ? b3 : 0.f, acc, 0, 0, 0);
+  }
+  if (cv) {
+    float *out = P + (size_t)chunk * M * N;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int row = m0 + (i & 3) + 8 * (i >> 2) + 4 * kh;
+      if (row < M) out[(size_t)row * N + c] = acc[i];
+    }
+  }
+}
+
 // ---- per-ship dense1 finish + head-1 ---------------------------------------------
 // d1 = relu(G1[arena] + vec8 . K1[0:8] + b1) ; d2 = relu(d1 K2 + b2) ; act = d2 K3 + b3
 struct HeadParams {
   int N, M;
   ofx_state st;
-  const float *g1;            // [N][100]  trunk part of dense1 (no bias)
+  const float *g1;            // [g1_chunks][N][100]  trunk part of dense1 (no bias), split-K partial sums
+  int g1_chunks;
   const float *k1, *b1, *k2, *b2, *k3, *b3;
   const uint8_t *mask;
   float *d1;                  // [S][100]
@@ -542,7 +596,9 @@ __global__ __launch_bounds__(256) void k_head_dense(HeadParams p) {
       float acc = 0.f;
 #pragma unroll
       for (int k = 0; k < 8; k++) acc += vec[k] * p.k1[k * 100 + o];
-      acc += p.g1[(size_t)a * 100 + o];
+      float g = 0.f;
+      for (int ch = 0; ch < p.g1_chunks; ch++) g += p.g1[((size_t)ch * p.N + a) * 100 + o];  // fixed order
+      acc += g;
       acc += p.b1[o];
       acc = fmaxf(acc, 0.f);
       sd1[wv][o] = acc;
@@ -712,6 +768,7 @@ struct HeadTailParams {
   const float *w3raw, *b3;     // BN-folded [9][4][8], folded bias [8]
   const float *w4eff;          // [ci 8][phase 4][tap 9]
   const float *w4raw, *b4;     // [9][8], [1]
+  const float *efr;            // [2][2][2][3][8] frame phase weights of upconv4 (PrepLayout::efr)
   const uint8_t *mask;
   unsigned long long *best;
   float *heat;
@@ -779,6 +836,7 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
   __shared__ __align__(16) float l2[4 * HT_L2P];
   __shared__ __align__(16) float u3f[4 * HT_U3PL];
   __shared__ __align__(16) float w4s[8][36];
+  __shared__ float wfr[192 + 288 + 72];             // border passes: efr | w3raw [9][4][8] | w4raw [9][8] (broadcast reads)
   __shared__ float hb2[4][HT_LB2], vb2[4][HT_LB2];  // U2[0|199][x'] , U2[y'][0|199]  (border tiles)
   __shared__ float facc[2][2 * HT_T];               // zero-padding corrections of the heat-map frame pixels
   __shared__ unsigned gtab[HT_NQP / 4];             // quad group g = 4i -> byte offset of its first cell | qi << 16 | qj0 << 24
@@ -795,6 +853,8 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
     const float wa = p.w4eff[tid], wb = tid < 32 ? p.w4eff[256 + tid] : 0.f;
     (&w4s[0][0])[tid] = wa;
     if (tid < 32) (&w4s[0][0])[256 + tid] = wb;
+    if (tid < 192) wfr[tid] = p.efr[tid];
+    for (int e = tid; e < 288 + 72; e += 256) wfr[192 + e] = e < 288 ? p.w3raw[e] : p.w4raw[e - 288];
     for (int m = tid; m < HT_NQP; m += 256) {
       const int qi = m / HT_QW, qj = min(m - qi * HT_QW, HT_Q - 1);
       atab[m] = (unsigned short)(qi * HT_L2 + qj);
@@ -859,13 +919,14 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
     }
   }
   __syncthreads();
-  if (border) {  // frame lines of the upsampled uprelu2 plane (block-uniform)
-    for (int e = tid; e < 2 * 4 * HT_LB2; e += 256) {
-      const int k = e % HT_LB2, ci = (e / HT_LB2) & 3, line = e / (4 * HT_LB2);
-      if (line == 0 && hline) {  // U2[0] = L[0], U2[199] = L[99] (row clamp): an x-lerp of one patch row
+  if (border) {  // frame lines of the upsampled uprelu2 plane (block-uniform); only the lines this tile has
+    const int nl = (hline ? 1 : 0) + (vline ? 1 : 0);
+    for (int e = tid; e < nl * 4 * HT_LB2; e += 256) {
+      const int li = e / (4 * HT_LB2), rem = e - li * 4 * HT_LB2, ci = rem / HT_LB2, k = rem - ci * HT_LB2;
+      if (hline && li == 0) {  // U2[0] = L[0], U2[199] = L[99] (row clamp): an x-lerp of one patch row
         const int R = top ? 0 : HT_S2 - 1, xc = min(max(c0 - 2 + k, 0), HT_S3 - 1);
         hb2[ci][k] = up1d(&l2[ci * HT_L2P + (R - ib) * HT_L2], 1, jb, xc);
-      } else if (line == 1 && vline) {
+      } else {
         const int Cc = lef ? 0 : HT_S2 - 1, yc = min(max(r0 - 2 + k, 0), HT_S3 - 1);
         vb2[ci][k] = up1d(&l2[ci * HT_L2P + (Cc - jb)], HT_L2, ib, yc);
       }
@@ -942,73 +1003,82 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
     if (border && !(p.ablate & 8)) {
       // Frame cells (row/col 0 or 199 of the plane) hold G + bias without ReLU: subtract the taps that fall
       // into the conv's zero padding, sum w[tap][ci] U2[clamp] from the frame lines, then apply the ReLU.
-      for (int e = tid; e < 4 * 2 * HT_U3; e += 256) {
-        const int k = e % HT_U3, line = (e / HT_U3) & 1, cl = e / (2 * HT_U3);
-        int y, x;
-        if (line == 0) { if (!hline) continue; y = top ? 0 : HT_S3 - 1; x = c0 - 1 + k; }
-        else { if (!vline) continue; x = lef ? 0 : HT_S3 - 1; y = r0 - 1 + k; }
-        if (y < 0 || y >= HT_S3 || x < 0 || x >= HT_S3) continue;
-        const bool fy = y == 0 || y == HT_S3 - 1, fx = x == 0 || x == HT_S3 - 1;
-        if (line == 1 && fy) continue;  // the corner cell belongs to the horizontal line
-        const float *w = p.w3raw + 4 * half + cl;
-        float corr = 0.f;
-        if (fy) {
-          const int trow = (y == 0) ? 0 : 2;
+      // Wave = local channel, lane = cell of the line: the weights are wave-uniform LDS broadcasts.
+      if (lane < HT_U3) {
+        const float *w = &wfr[192 + 4 * half + wv];
+        auto frame_cell = [&](int y, int x) {
+          const bool fy = y == 0 || y == HT_S3 - 1, fx = x == 0 || x == HT_S3 - 1;
+          float corr = 0.f;
+          if (fy) {
+            const int trow = (y == 0) ? 0 : 2;
 #pragma unroll
-          for (int dx = -1; dx <= 1; dx++) {
-            const int xx = min(max(x + dx, 0), HT_S3 - 1) - (c0 - 2);
+            for (int dx = -1; dx <= 1; dx++) {
+              const int xx = min(max(x + dx, 0), HT_S3 - 1) - (c0 - 2);
 #pragma unroll
-            for (int ci = 0; ci < 4; ci++) corr += w[((trow * 3 + dx + 1) * 4 + ci) * 8] * hb2[ci][xx];
+              for (int ci = 0; ci < 4; ci++) corr += w[((trow * 3 + dx + 1) * 4 + ci) * 8] * hb2[ci][xx];
+            }
           }
-        }
-        if (fx) {
-          const int tcol = (x == 0) ? 0 : 2;
+          if (fx) {
+            const int tcol = (x == 0) ? 0 : 2;
 #pragma unroll
-          for (int dy = -1; dy <= 1; dy++) {
-            const int uy = y + dy;
-            if (uy < 0 || uy >= HT_S3) continue;  // counted with the row
+            for (int dy = -1; dy <= 1; dy++) {
+              const int uy = y + dy;
+              if (uy < 0 || uy >= HT_S3) continue;  // counted with the row
 #pragma unroll
-            for (int ci = 0; ci < 4; ci++) corr += w[(((dy + 1) * 3 + tcol) * 4 + ci) * 8] * vb2[ci][uy - (r0 - 2)];
+              for (int ci = 0; ci < 4; ci++) corr += w[(((dy + 1) * 3 + tcol) * 4 + ci) * 8] * vb2[ci][uy - (r0 - 2)];
+            }
           }
+          const int ty = y - (r0 - 1), tx = x - (c0 - 1);
+          const float v = fmaxf(u3f[u3o(wv, ty, tx)] - corr, 0.f);
+          u3f[u3o(wv, ty, tx)] = v;
+          // the halo cells outside the image are clamp copies of exactly these frame cells
+          const int oy = (y == 0) ? -1 : (y == HT_S3 - 1) ? 1 : 0, ox = (x == 0) ? -1 : (x == HT_S3 - 1) ? 1 : 0;
+          if (oy) u3f[u3o(wv, ty + oy, tx)] = v;
+          if (ox) u3f[u3o(wv, ty, tx + ox)] = v;
+          if (oy && ox) u3f[u3o(wv, ty + oy, tx + ox)] = v;
+        };
+        if (hline) {
+          const int x = c0 - 1 + lane;
+          if (x >= 0 && x < HT_S3) frame_cell(top ? 0 : HT_S3 - 1, x);
         }
-        const int ty = y - (r0 - 1), tx = x - (c0 - 1);
-        const float v = fmaxf(u3f[u3o(cl, ty, tx)] - corr, 0.f);
-        u3f[u3o(cl, ty, tx)] = v;
-        // the halo cells outside the image are clamp copies of exactly these frame cells
-        const int oy = (y == 0) ? -1 : (y == HT_S3 - 1) ? 1 : 0, ox = (x == 0) ? -1 : (x == HT_S3 - 1) ? 1 : 0;
-        if (oy) u3f[u3o(cl, ty + oy, tx)] = v;
-        if (ox) u3f[u3o(cl, ty, tx + ox)] = v;
-        if (oy && ox) u3f[u3o(cl, ty + oy, tx + ox)] = v;
+        if (vline) {  // the corner cells belong to the horizontal line
+          const int y = r0 - 1 + lane;
+          if (y > 0 && y < HT_S3 - 1) frame_cell(y, lef ? 0 : HT_S3 - 1);
+        }
       }
       __syncthreads();
-      // zero-padding corrections of the heat-map frame pixels of this tile, accumulated over the two halves:
+      // Zero-padding corrections of the heat-map frame pixels of this tile, accumulated over the two halves:
       // facc[0][k] for (y in {0,399}, x = 2c0 + k) ; facc[1][k] for (y = 2r0 + k, x in {0,399}), rows counted once.
-      // U3[row 0|399][x'] is an x-lerp of the (clamp-extended) tile row 0|199, U3[y'][col 0|399] a y-lerp.
-      for (int e = tid; e < 2 * 2 * HT_T; e += 256) {
-        const int k = e % (2 * HT_T), line = e / (2 * HT_T);
-        const float *w = p.w4raw + 4 * half;
-        float corr = 0.f;
-        if (line == 0 && hline) {
-          const int trow = top ? 0 : 2, x = 2 * c0 + k, R = (top ? 0 : HT_S3 - 1) - (r0 - 1);
+      // In phase form along the line (PrepLayout::efr): pixel 2j + b gets sum_o E[b][o] L[j + o - 1] of the
+      // clamp-extended low-res frame row / column L of the tile.  Wave 0 = horizontal line, wave 1 = vertical line,
+      // lane = j; the other two waves go straight to stage C.
+      if (wv < 2 && lane < HT_T && (wv ? vline : hline)) {
+        const int side = wv ? (lef ? 0 : 1) : (top ? 0 : 1);
+        const float *E = &wfr[(wv * 2 + side) * 48 + 4 * half];  // [b][o][ci]
+        const int R = (top ? 0 : HT_S3 - 1) - (r0 - 1), Cc = (lef ? 0 : HT_S3 - 1) - (c0 - 1);
+        const float *L = u3f + (wv ? u3o(0, lane, Cc) : u3o(0, R, lane));  // sample j - 1
+        const int st = wv ? HT_U3S : 1;
+        float e0 = 0.f, e1 = 0.f;
 #pragma unroll
-          for (int dx = -1; dx <= 1; dx++) {
-            const int xc = min(max(x + dx, 0), PS - 1);
+        for (int cl = 0; cl < 4; cl++)
 #pragma unroll
-            for (int cl = 0; cl < 4; cl++)
-              corr += w[(trow * 3 + dx + 1) * 8 + cl] * up1d(&u3f[u3o(cl, R, 0)], 1, c0 - 1, xc);
+          for (int o = 0; o < 3; o++) {
+            const float v = L[cl * HT_U3PL + o * st];
+            e0 += E[o * 8 + cl] * v;
+            e1 += E[(3 + o) * 8 + cl] * v;
           }
-        } else if (line == 1 && vline) {
-          const int tcol = lef ? 0 : 2, y = 2 * r0 + k, Cc = (lef ? 0 : HT_S3 - 1) - (c0 - 1);
+        if (wv == 1) {  // corner pixels: the conv row outside the image is counted with the horizontal line
+          const float *w4 = &wfr[192 + 288 + 4 * half];
+          const int tcol = lef ? 0 : 2;
+          if (top && lane == 0)
 #pragma unroll
-          for (int dy = -1; dy <= 1; dy++) {
-            const int uy = y + dy;
-            if (uy < 0 || uy >= PS) continue;
+            for (int cl = 0; cl < 4; cl++) e0 -= w4[(0 * 3 + tcol) * 8 + cl] * u3f[u3o(cl, 1, Cc)];
+          if (bot && lane == HT_T - 1)
 #pragma unroll
-            for (int cl = 0; cl < 4; cl++)
-              corr += w[((dy + 1) * 3 + tcol) * 8 + cl] * up1d(&u3f[u3o(cl, 0, Cc)], HT_U3S, r0 - 1, uy);
-          }
+            for (int cl = 0; cl < 4; cl++) e1 -= w4[(2 * 3 + tcol) * 8 + cl] * u3f[u3o(cl, HT_T, Cc)];
         }
-        facc[line][k] += corr;
+        facc[wv][2 * lane] += e0;
+        facc[wv][2 * lane + 1] += e1;
       }
     }
 
@@ -1430,12 +1500,13 @@ static bool policy_unfused() {
 }
 
 static size_t al(size_t b) { return (b + 255) & ~(size_t)255; }
+constexpr int kDense1Chunks = 25;  // split-K of dense1: 5000 = 25 x 200
 
 static int policy_workspace(ofx_handle *h, PolicyWs *ws) {
   const size_t N = h->cfg.n_arenas, S = N * h->cfg.n_ships;
   const PrepLayout L = prep_layout();
   const size_t sz[] = {al(4ull * L.total),          al(4ull * N * 8 * 200 * 200), al(4ull * N * 8 * 100 * 100),
-                       al(4ull * N * 8 * 50 * 50),   al(4ull * N * 5000),          al(4ull * N * 100),
+                       al(4ull * N * 8 * 50 * 50),   al(4ull * N * 5000),          al(4ull * N * 100 * kDense1Chunks),
                        al(4ull * S * 100),           al(4ull * S * 625),           al(4ull * S * 2 * 50 * 50),
                        al(4ull * S * 4 * 100 * 100), al(policy_unfused() ? 4ull * S * 8 * 200 * 200 : 256), al(8ull * S),
                        al(4ull * S),                 al(8ull * S)};
@@ -1518,7 +1589,7 @@ extern "C" int ofx_policy_forward(ofx_handle *h, const float *weights, const uin
     pp.cin[4 + i] = kUpCin[i]; pp.cout[4 + i] = kUpCout[i]; pp.dst_w[4 + i] = L.uw[i]; pp.dst_b[4 + i] = L.ub[i];
   }
   pp.src_k4 = off[t_u4]; pp.src_b4 = off[t_u4 + 1];
-  pp.dst_w4eff = L.w4eff; pp.dst_w4raw = L.w4raw; pp.dst_b4 = L.b4;
+  pp.dst_w4eff = L.w4eff; pp.dst_w4raw = L.w4raw; pp.dst_b4 = L.b4; pp.dst_efr = L.efr;
   pp.dst_w4eff_c = L.w4eff_c; pp.dst_w3mf = L.w3mf;
   for (int i = 0; i < 4; i++) pp.dst_bg[i] = L.bg[i];
   hipLaunchKernelGGL(k_policy_prepare, dim3(1), dim3(256), 0, h->stream, pp);
@@ -1548,9 +1619,14 @@ extern "C" int ofx_policy_forward(ofx_handle *h, const float *weights, const uin
 
   // 2. dense1: trunk features on MFMA once per arena; head + head-1 per ship
   const float *k1 = weights + off[t_d1];
-  if ((rc = launch_gemm(h, ws.p4, 5000, k1 + 8 * 100, 100, nullptr, ws.g1, 100, N, 100, 5000, 0))) return rc;
+  {
+    const int tiles = ((N + 31) / 32) * 4, jobs = tiles * kDense1Chunks;
+    hipLaunchKernelGGL(k_gemm_f32_splitk, dim3((jobs + 3) / 4), dim3(256), 0, h->stream, ws.p4, 5000, k1 + 8 * 100, 100,
+                       ws.g1, N, 100, 5000 / kDense1Chunks, tiles, jobs);
+    OFX_HIP(hipGetLastError());
+  }
   HeadParams hp;
-  hp.N = N; hp.M = c.n_ships; hp.st = h->st; hp.g1 = ws.g1;
+  hp.N = N; hp.M = c.n_ships; hp.st = h->st; hp.g1 = ws.g1; hp.g1_chunks = kDense1Chunks;
   hp.k1 = k1; hp.b1 = weights + off[t_d1 + 1];
   hp.k2 = weights + off[t_d2]; hp.b2 = weights + off[t_d2 + 1];
   hp.k3 = weights + off[t_o1]; hp.b3 = weights + off[t_o1 + 1];
@@ -1574,7 +1650,7 @@ extern "C" int ofx_policy_forward(ofx_handle *h, const float *weights, const uin
     HeadTailParams ht;
     ht.up2 = ws.up2;
     ht.w3mf = ws.prep + L.w3mf; ht.w3raw = ws.prep + L.uw[2]; ht.b3 = ws.prep + L.ub[2];
-    ht.w4eff = ws.prep + L.w4eff_c; ht.w4raw = ws.prep + L.w4raw; ht.b4 = ws.prep + L.b4;
+    ht.w4eff = ws.prep + L.w4eff_c; ht.w4raw = ws.prep + L.w4raw; ht.b4 = ws.prep + L.b4; ht.efr = ws.prep + L.efr;
     ht.mask = ship_mask; ht.best = ws.best; ht.heat = heatmap;
     { const char *e = getenv("OFX_HT_ABLATE"); ht.ablate = e ? atoi(e) : 0; }
     const int pb = h->prof_base;
