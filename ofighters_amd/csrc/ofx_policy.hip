@@ -487,6 +487,244 @@ __global__ __launch_bounds__(((TH / 2) * (TW / 4) + 63) / 64 * 64) void k_conv8(
   }
 }
 
+// max without the canonicalising v_max(x, x) the compiler puts in front of fmaxf() in IEEE mode (x is an MFMA
+// result here, never a signalling NaN)
+__device__ __forceinline__ float max_raw(float x, float floor) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(floor), "v"(x));
+  return r;
+}
+
+// ---- trunk convolution on the matrix cores ---------------------------------------------------------------------
+// conv3x3 (zero padding) + folded BN + ReLU + 2x2 max-pool as a GEMM whose N dimension is 8 output channels x 2
+// adjacent output rows:  D[pixel x][(co, r)] = sum_k A[x][k] B[k][(co, r)],  k = (input row 0..3, dx, ci),
+// B[k][(co, r)] = w[row - r][dx][ci][co] when 0 <= row - r <= 2, else 0  -> K = 12 CIN, 3/4 of the MACs useful, but a
+// v_mfma_f32_16x16x4_f32 retires 32 MAC/cycle against 16 for v_fmac_f32 (both share the SIMD's issue slots on gfx950,
+// tools/ubench_mix.hip), and the whole epilogue of an M-tile (2x2 pool, ReLU, store) is ~10 VALU instructions.
+// A[x][k] is gathered from an LDS copy of the input tile (one ds_read_b32 per lane per MFMA, immediate offsets);
+// the row pair of a column group shares one accumulator quad: lane (n = (co, r), kq) holds pixels 4 kq .. 4 kq + 3,
+// so the x-pool is in-lane and the y-pool is one DPP quad swap.
+// MODE 0: planar f32 input [img][CIN][H][W]; MODE 1: two 1-bit maps (CIN = 2).  Output: planar [img][8][H/2][W/2] or
+// (OUT_HWC) [img][H/2][W/2][8].  TH rows x 16 NG columns per workgroup, TH even, H % TH == 0; W is masked.
+// A workgroup walks TPW consecutive tiles of one image: the weights are fetched once, the global loads of tile i+1 are
+// in flight (in registers) while tile i computes, and the grid stays small (the dispatcher needs ~5 ns per workgroup:
+// one workgroup per tile cost 1.6 ms of launch floor for conv2 alone).
+template <int CIN, int TH, int NG, int MODE, bool OUT_HWC, int TPW>
+__global__ __launch_bounds__(256) void k_convm(ConvParams p) {
+  constexpr int TW = 16 * NG, LS = TW + 8;  // LDS row: image column tx0 + c sits at index c + 4 (16-byte aligned interior),
+                                            // the left / right halo columns at 3 and TW + 4
+  constexpr int PLS = ((TH + 2) * LS + 63) / 64 * 64 + 16;  // plane stride = 16 mod 64: the 4 k-quarters hit different banks
+  constexpr int NK = 3 * CIN;                                // MFMAs per M-tile (K = 12 CIN)
+  constexpr int JOBS = NG * (TH / 2);
+  constexpr int ROWS = CIN * (TH + 2);
+  constexpr bool VEC = MODE == 0 && !OUT_HWC;                // rows of W floats are 16-byte aligned (W % 4 == 0)
+  __shared__ __align__(16) float tile[CIN * PLS];
+  const int first = blockIdx.x * TPW;                        // p.tiles % TPW == 0: all tiles of a workgroup share the image
+  const int img = first / p.tiles, t_first = first - img * p.tiles;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = p.H, W = p.W;
+  const int n16 = lane & 15, kq = lane >> 4, co = n16 >> 1, r = n16 & 1;
+
+  // B operand: the lane's column (co, r) of the banded weight matrix, rows k = 4 j + kq
+  float bw[NK];
+  int aoff[NK];  // LDS offset of A[.][4 j + kq] relative to the M-tile origin (compile-time + kq * PLS when CIN == 8)
+#pragma unroll
+  for (int j = 0; j < NK; j++) {
+    const int k = 4 * j + kq, rd = k / CIN, ci = k - rd * CIN, row = rd / 3, dx = rd - row * 3, tr = row - r;
+    bw[j] = (tr >= 0 && tr < 3) ? p.w[((tr * 3 + dx) * CIN + ci) * 8 + co] : 0.f;
+    aoff[j] = ci * PLS + row * LS + dx;
+  }
+  const float bias = p.b[co];
+  const f32x4 binit = {bias, bias, bias, bias};
+  const int H2 = H >> 1, W2 = W >> 1;
+
+  // ---- staging, split into fetch (global -> registers) and commit (registers -> LDS) ----
+  constexpr int WPR = (TW + 2 + 31) / 32 + 1;                      // MODE 1: words a tile row can touch
+  constexpr int NWI = MODE == 1 ? (ROWS * WPR + 255) / 256 : 1;    // word items per thread
+  constexpr int V4 = TW / 4, RPW = VEC ? (ROWS + 3) / 4 : 1;       // VEC: float4 per row, rows per wave
+  static_assert(!VEC || V4 + 2 <= 64, "tile row wider than one wave");
+  unsigned wpre[NWI];
+  float4 vpre[RPW];
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  auto fetch = [&](int t) {
+    const int ty0 = (t / p.tiles_x) * TH, tx0 = (t % p.tiles_x) * TW;
+    if constexpr (MODE == 1) {
+#pragma unroll
+      for (int u = 0; u < NWI; u++) {
+        const int e = tid + 256 * u;
+        const int k = e % WPR, rr = (e / WPR) % (TH + 2), ci = e / (WPR * (TH + 2));
+        const int gy = ty0 - 1 + rr;
+        unsigned word = 0u;
+        if (e < ROWS * WPR && gy >= 0 && gy < H) {
+          const int cell0 = gy * W + tx0 - 1;
+          const int wi = ((cell0 >= 0 ? cell0 : 0) >> 5) + k;
+          if (wi < (PS * PS) >> 5) word = p.bits[ci][(size_t)img * ((PS * PS) >> 5) + wi];
+        }
+        wpre[u] = word;
+      }
+    } else if constexpr (VEC) {
+      // a wave moves one tile row per step: lane i < V4 the i-th float4 of the interior, lanes V4 / V4+1 the float4
+      // that holds the left / right halo column
+      const int gxl = lane < V4 ? tx0 + 4 * lane : (lane == V4 ? tx0 - 4 : tx0 + TW);
+      const bool colok = lane < V4 + 2 && gxl >= 0 && gxl < W && !(p.ablate & 1);
+#pragma unroll
+      for (int u = 0; u < RPW; u++) {
+        const int rr = wv + 4 * u;
+        const int ci = rr / (TH + 2), r_ = rr - ci * (TH + 2), gy = ty0 - 1 + r_;
+        const bool rowok = rr < ROWS && gy >= 0 && gy < H;  // wave-uniform
+        const float *src = p.in + (((size_t)img * CIN + (rowok ? ci : 0)) * H + (rowok ? gy : 0)) * W;
+        vpre[u] = (rowok && colok) ? *reinterpret_cast<const float4 *>(src + gxl) : z4;
+      }
+    }
+  };
+
+  auto commit = [&](int t) {
+    const int ty0 = (t / p.tiles_x) * TH, tx0 = (t % p.tiles_x) * TW;
+    if constexpr (MODE == 1) {
+#pragma unroll
+      for (int u = 0; u < NWI; u++) {
+        const int e = tid + 256 * u;
+        if (e >= ROWS * WPR) break;
+        const int k = e % WPR, rr = (e / WPR) % (TH + 2), ci = e / (WPR * (TH + 2));
+        const int gy = ty0 - 1 + rr;
+        float *trow = &tile[ci * PLS + rr * LS + 3];  // trow[c] <-> image column tx0 - 1 + c
+        if (gy < 0 || gy >= H) {
+          for (int c = k; c < TW + 2; c += WPR) trow[c] = 0.f;
+          continue;
+        }
+        const int cell0 = gy * W + tx0 - 1;            // cell index of column c = 0 (-1 at the left image edge)
+        const int wi = ((cell0 >= 0 ? cell0 : 0) >> 5) + k;
+        const int cbeg = max(wi * 32 - cell0, 0), cend = min(wi * 32 + 32 - cell0, TW + 2);
+        if (k == 0)
+          for (int c = 0; c < cbeg; c++) trow[c] = 0.f;
+        const unsigned sh = wpre[u] >> ((cell0 + cbeg) & 31);
+        for (int c = cbeg; c < cend; c++) {
+          const int gx = tx0 - 1 + c;
+          trow[c] = (gx >= 0 && gx < W && ((sh >> (c - cbeg)) & 1u)) ? 1.f : 0.f;
+        }
+      }
+    } else if constexpr (VEC) {
+#pragma unroll
+      for (int u = 0; u < RPW; u++) {
+        const int rr = wv + 4 * u;
+        if (rr >= ROWS) break;  // wave-uniform
+        const int ci = rr / (TH + 2), r_ = rr - ci * (TH + 2);
+        float *trow = &tile[ci * PLS + r_ * LS];
+        if (lane < V4) *reinterpret_cast<float4 *>(trow + 4 + 4 * lane) = vpre[u];
+        else if (lane == V4) trow[3] = vpre[u].w;
+        else if (lane == V4 + 1) trow[TW + 4] = vpre[u].x;
+      }
+    } else {  // unaligned rows (W % 4 != 0): element-wise, no prefetch (the 50x50 layer only)
+      constexpr int RW = TW + 2, TOTAL = CIN * (TH + 2) * RW, SU = 8;
+      for (int base = 0; base < TOTAL; base += 256 * SU) {
+        float vals[SU];
+#pragma unroll
+        for (int u = 0; u < SU; u++) {
+          const int e = base + u * 256 + tid;
+          float v = 0.f;
+          if (e < TOTAL) {
+            const int c = e % RW, rr = (e / RW) % (TH + 2), ci = e / (RW * (TH + 2));
+            const int gy = ty0 - 1 + rr, gx = tx0 - 1 + c;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = p.in[(((size_t)img * CIN + ci) * H + gy) * W + gx];
+          }
+          vals[u] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < SU; u++) {
+          const int e = base + u * 256 + tid;
+          if (e < TOTAL) {
+            const int c = e % RW, rr = (e / RW) % (TH + 2), ci = e / (RW * (TH + 2));
+            tile[ci * PLS + rr * LS + 3 + c] = vals[u];
+          }
+        }
+      }
+    }
+  };
+
+  // A[.][4 j + kq]: with 8 input channels the (row, dx) of step j is a compile-time constant and the channel is
+  // 4 (j & 1) + kq, so every LDS read is base + immediate; with 2 channels the per-lane offsets live in registers
+  const float *abase = &tile[(CIN == 8 ? kq * PLS : 0) + n16 + 3];
+  auto aof = [&](int j) -> int {
+    if (CIN == 8) return (4 * (j & 1)) * PLS + ((j >> 1) / 3) * LS + ((j >> 1) % 3);
+    return aoff[j];
+  };
+
+  fetch(t_first);
+#pragma unroll 1
+  for (int i = 0; i < TPW; i++) {
+    const int t = t_first + i;
+    const int ty0 = (t / p.tiles_x) * TH, tx0 = (t % p.tiles_x) * TW;
+    commit(t);
+    __syncthreads();
+    if (i + 1 < TPW) fetch(t + 1);
+
+    // epilogue of an M-tile: x-pool + ReLU in one v_max3, y-pool = max with the DPP quad swap [1,0,3,2] (rows r = 0 / 1
+    // sit in lanes n, n ^ 1), one 8-byte store from the r = 0 lanes
+    float *const obase = OUT_HWC ? p.out + (((size_t)img * H2 + (ty0 >> 1)) * W2 + (tx0 >> 1) + 2 * kq) * 8 + co
+                                 : p.out + (((size_t)img * 8 + co) * H2 + (ty0 >> 1)) * W2 + (tx0 >> 1) + 2 * kq;
+    auto finish = [&](const f32x4 d, int g, int tt) {
+      float q0, q1;
+      asm("v_max3_f32 %0, %1, %2, 0" : "=v"(q0) : "v"(d[0]), "v"(d[1]));
+      asm("v_max3_f32 %0, %1, %2, 0" : "=v"(q1) : "v"(d[2]), "v"(d[3]));
+      q0 = max_raw(q0, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, q0), 0xB1, 0xF, 0xF, true)));
+      q1 = max_raw(q1, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, q1), 0xB1, 0xF, 0xF, true)));
+      const int px = ((tx0 + 16 * g) >> 1) + 2 * kq;
+      if (r == 0 && px < W2 && !(p.ablate & 4)) {
+        if (OUT_HWC) {
+          float *op = obase + ((size_t)tt * W2 + 8 * g) * 8;
+          op[0] = q0;
+          if (px + 1 < W2) op[8] = q1;
+        } else {  // W2 is even here: px < W2 implies px + 1 < W2
+          *reinterpret_cast<float2 *>(obase + tt * W2 + 8 * g) = make_float2(q0, q1);
+        }
+      }
+    };
+    // two M-tiles per iteration (independent accumulator chains keep the matrix pipe busy); a trailing odd one alone
+#pragma unroll 1
+    for (int job = wv; job < JOBS; job += 8) {
+      const int job1 = job + 4;
+      const int g0 = job % NG, t0 = job / NG;
+      const float *a0 = abase + (2 * t0) * LS + 16 * g0;
+      if (job1 < JOBS) {  // wave-uniform
+        const int g1 = job1 % NG, t1 = job1 / NG;
+        const float *a1 = abase + (2 * t1) * LS + 16 * g1;
+        f32x4 d0 = binit, d1 = binit;
+        if (!(p.ablate & 2)) {
+#pragma unroll
+          for (int j = 0; j < NK; j++) {
+            d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[aof(j)], bw[j], d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[aof(j)], bw[j], d1, 0, 0, 0);
+          }
+        }
+        finish(d0, g0, t0);
+        finish(d1, g1, t1);
+      } else {
+        f32x4 d0 = binit;
+        if (!(p.ablate & 2)) {
+#pragma unroll
+          for (int j = 0; j < NK; j++) d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[aof(j)], bw[j], d0, 0, 0, 0);
+        }
+        finish(d0, g0, t0);
+      }
+    }
+    if (i + 1 < TPW) __syncthreads();  // the next commit overwrites the tile
+  }
+}
+
+template <int CIN, int TH, int NG, int MODE, bool OUT_HWC, int TPW>
+static int launch_convm(ofx_handle *h, ConvParams p, int images, int H) {
+  p.H = H; p.W = H;
+  p.tiles_x = (H + 16 * NG - 1) / (16 * NG);
+  p.tiles = p.tiles_x * (H / TH);
+  if (p.tiles % TPW) { ofx_set_error("launch_convm: %d tiles per image not divisible by %d", p.tiles, TPW); return OFX_ERR_INVALID; }
+  hipLaunchKernelGGL((k_convm<CIN, TH, NG, MODE, OUT_HWC, TPW>), dim3((unsigned)(images * (p.tiles / TPW))), dim3(256), 0,
+                     h->stream, p);
+  OFX_HIP(hipGetLastError());
+  return OFX_OK;
+}
+
 // ---- fp32 MFMA GEMM for the dense layers -------------------------------------------
 // C[M][N] = act(A[M][K] (lda) x B[K][N] (ldb) + bias[N])   one wave per 32x32 tile,
 // v_mfma_f32_32x32x2_f32: lane l holds A[row l&31][k l>>5], B[k l>>5][col l&31];
@@ -545,7 +783,6 @@ __global__ __launch_bounds__(256) void k_gemm_f32_splitk(const float *A, int lda
   for (int i = 0; i < 16; i++) acc[i] = 0.f;
   const float *ap = A + (size_t)(rv ? r : 0) * lda + (size_t)chunk * Kc + 4 * kh;
   const float *bp = B + ((size_t)chunk * Kc + 4 * kh) * ldb + (cv ? c : 0);
-#pragma unroll 2
   for (int k0 = 0; k0 < Kc; k0 += 8) {
     const float4 a4 = *reinterpret_cast<const float4 *>(ap + k0);
     const float b0 = bp[(size_t)(k0 + 0) * ldb], b1 = bp[(size_t)(k0 + 1) * ldb], b2 = bp[(size_t)(k0 + 2) * ldb],
@@ -813,14 +1050,6 @@ __device__ __forceinline__ float up1d(const float *line, int stride, int base, i
   const float w = (u & 1) ? 0.25f : 0.75f;
   const float l0 = line[(ka - base) * stride], l1 = line[(ka + 1 - base) * stride];
   return l0 + (l1 - l0) * w;
-}
-
-// max without the canonicalising v_max(x, x) the compiler puts in front of fmaxf() in IEEE mode (x is an MFMA
-// result here, never a signalling NaN)
-__device__ __forceinline__ float max_raw(float x, float floor) {
-  float r;
-  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(floor), "v"(x));
-  return r;
 }
 
 constexpr int HT_L2P = HT_L2 * HT_L2 + 16;  // plane stride of the patch: +16 floats so the 4 channel planes of
@@ -1606,16 +1835,27 @@ extern "C" int ofx_policy_forward(ofx_handle *h, const float *weights, const uin
   const bool bgskip = getenv("OFX_POLICY_BG_SKIP") != nullptr;
   cp.w = ws.prep + L.tw[0]; cp.b = ws.prep + L.tb[0]; cp.out = ws.p1;
   if (bgskip) { cp.bg_in = ws.prep + L.total - 8; cp.bg_out = ws.prep + L.bg[0]; }  // the 8 pad floats are zero
-  if ((rc = launch_conv8<2, 40, 100, 1, true, false>(h, cp, N, 400))) return rc;
+  // TPW (tiles walked per workgroup with register prefetch) = 1: walking 2..25 tiles measured 40-150 % slower (the
+  // prefetch registers push the kernels to 160-256 VGPRs); tile shapes from an A/B on the chip (tools/ab_convm.sh)
+  const bool trunk_valu = getenv("OFX_TRUNK_VALU") != nullptr;  // A/B: the pre-MFMA trunk kernels
+  if (trunk_valu) rc = launch_conv8<2, 40, 100, 1, true, false>(h, cp, N, 400);
+  else rc = launch_convm<2, 8, 13, 1, false, 1>(h, cp, N, 400);
+  if (rc) return rc;
   cp.in = ws.p1; cp.w = ws.prep + L.tw[1]; cp.b = ws.prep + L.tb[1]; cp.out = ws.p2;
   if (bgskip) { cp.bg_in = ws.prep + L.bg[0]; cp.bg_out = ws.prep + L.bg[1]; }
-  if ((rc = launch_conv<8, 8, 10, 100, 0, true, false>(h, cp, N, 200))) return rc;
+  if (trunk_valu) rc = launch_conv<8, 8, 10, 100, 0, true, false>(h, cp, N, 200);
+  else rc = launch_convm<8, 4, 13, 0, false, 1>(h, cp, N, 200);
+  if (rc) return rc;
   cp.in = ws.p2; cp.w = ws.prep + L.tw[2]; cp.b = ws.prep + L.tb[2]; cp.out = ws.p3;
   if (bgskip) { cp.bg_in = ws.prep + L.bg[1]; cp.bg_out = ws.prep + L.bg[2]; }
-  if ((rc = launch_conv<8, 8, 10, 100, 0, true, false>(h, cp, N, 100))) return rc;
+  if (trunk_valu) rc = launch_conv<8, 8, 10, 100, 0, true, false>(h, cp, N, 100);
+  else rc = launch_convm<8, 10, 7, 0, false, 1>(h, cp, N, 100);
+  if (rc) return rc;
   cp.in = ws.p3; cp.w = ws.prep + L.tw[3]; cp.b = ws.prep + L.tb[3]; cp.out = ws.p4;
   cp.bg_in = nullptr; cp.bg_out = nullptr;
-  if ((rc = launch_conv<8, 8, 10, 50, 0, true, true>(h, cp, N, 50))) return rc;  // (h,w,c) = Flatten order
+  if (trunk_valu) rc = launch_conv<8, 8, 10, 50, 0, true, true>(h, cp, N, 50);  // (h,w,c) = Flatten order
+  else rc = launch_convm<8, 10, 4, 0, true, 1>(h, cp, N, 50);
+  if (rc) return rc;
 
   // 2. dense1: trunk features on MFMA once per arena; head + head-1 per ship
   const float *k1 = weights + off[t_d1];
