@@ -68,6 +68,7 @@ struct PrepLayout {
   int bg[4];          // background response after trunk layer i ([8] each): the value every output channel takes
                       // where the whole receptive window shows empty space
   int w3mf;           // [half 2][k = tap*4 + ci (36)][n = phase*4 + co_local (16)]  MFMA B operand
+  int w2mf;           // upconv2 in phase form: [k = tap*2 + ci (18, padded to 20)][n = phase*4 + co (16)]
   int w4eff;          // [4 phases][9 low-res taps][8 ci] (v1 kernel)
   int w4eff_c;        // [8 ci][4 phases][9 taps] (fused kernel: one contiguous slice per input channel)
   int w4raw;          // [9][8]
@@ -84,6 +85,7 @@ static PrepLayout prep_layout() {
   for (int i = 0; i < 3; i++) { L.uw[i] = off; off += 9 * kUpCin[i] * kUpCout[i]; L.ub[i] = off; off += kUpCout[i]; }
   for (int i = 0; i < 4; i++) { L.bg[i] = off; off += 8; }
   L.w3mf = off; off += 36 * 32;
+  L.w2mf = off; off += 20 * 16;
   L.w4eff = off; off += 4 * 9 * 8;
   L.w4eff_c = off; off += 8 * 4 * 9;
   L.w4raw = off; off += 72;
@@ -99,7 +101,7 @@ struct PrepParams {
   float *prep;
   int src_k[7], src_b[7], src_g[7], cin[7], cout[7], dst_w[7], dst_b[7];
   int src_k4, src_b4, dst_w4eff, dst_w4raw, dst_b4, dst_efr;
-  int dst_w4eff_c, dst_w3mf;
+  int dst_w4eff_c, dst_w3mf, dst_w2mf;
   int dst_bg[4];
 };
 
@@ -182,6 +184,23 @@ __global__ void k_policy_prepare(PrepParams p) {
         for (int dx = 0; dx < 3; dx++)
           acc += (p.w[p.src_k[6] + ((dy * 3 + dx) * cin + ci) * cout + co] * inv) * (up_coef(a, dy, ty) * up_coef(b, dx, tx));
       p.prep[p.dst_w3mf + ((co >> 2) * 36 + tap * 4 + ci) * 16 + ph * 4 + (co & 3)] = acc;
+    }
+  }
+  // upconv2 (layer index 5): the same for the 2 -> 4 layer, K padded from 18 to 20 with zero rows
+  {
+    const int cout = 4, cin = 2;
+    const float *g = p.w + p.src_g[5];
+    for (int e = tid; e < 20 * 16; e += blockDim.x) {
+      const int n = e % 16, k = e / 16, co = n & 3, ph = n >> 2, ci = k & 1, tap = k >> 1;
+      float acc = 0.f;
+      if (k < 18) {
+        const int a = ph >> 1, b = ph & 1, ty = tap / 3, tx = tap % 3;
+        const float inv = g[co] / sqrtf(g[3 * cout + co] + 1e-3f);
+        for (int dy = 0; dy < 3; dy++)
+          for (int dx = 0; dx < 3; dx++)
+            acc += (p.w[p.src_k[5] + ((dy * 3 + dx) * cin + ci) * cout + co] * inv) * (up_coef(a, dy, ty) * up_coef(b, dx, tx));
+      }
+      p.prep[p.dst_w2mf + e] = acc;
     }
   }
   if (tid == 0) p.prep[p.dst_b4] = p.w[p.src_b4];
@@ -1000,7 +1019,10 @@ __global__ __launch_bounds__(256) void k_upconv4(Up4Params p) {
 //   differs from the clamp-extended phase form: border tiles recompute those cells from the definition
 //   (upsample, then conv with zero padding) in a small rolled pass.
 struct HeadTailParams {
-  const float *up2;            // planar [S][4][100][100]
+  const float *up2;            // planar [S][4][100][100]  (k_head_tail_w only)
+  const float *up1;            // planar [S][2][50][50]: k_head_tail computes its uprelu2 patches itself
+  const float *w2mf;           // [20][16] phase weights of upconv2 (MFMA B operand), PrepLayout::w2mf
+  const float *w2raw, *b2;     // BN-folded [9][2][4], folded bias [4]
   const float *w3mf;           // [half 2][k = tap*4 + ci (36)][n = phase*4 + co_local (16)]  MFMA B operand
   const float *w3raw, *b3;     // BN-folded [9][4][8], folded bias [8]
   const float *w4eff;          // [ci 8][phase 4][tap 9]
@@ -1055,6 +1077,10 @@ __device__ __forceinline__ float up1d(const float *line, int stride, int base, i
 constexpr int HT_L2P = HT_L2 * HT_L2 + 16;  // plane stride of the patch: +16 floats so the 4 channel planes of
                                             // the MFMA A-gather land on different LDS banks
 constexpr int HT_LB2 = HT_T + 4;            // frame-line length of stage B (x' in [c0-2, c0+T+1])
+constexpr int HT_S1 = 50;                   // uprelu1 plane side
+constexpr int HT_L1 = HT_L2 / 2 + 2;        // uprelu1 patch side (14)
+constexpr int HT_L1P = HT_L1 * HT_L1 + 4;   // plane stride
+constexpr int HT_LB1 = HT_L2 + 2;           // level-2 frame-line length (x' in [jb-1, jb+24])
 
 // The f32 MFMAs and the VALU share the SIMD's issue slots on gfx950 (tools/ubench_mix.hip: their rates do not add
 // up), so every VALU instruction costs matrix throughput.  The kernel is written to keep the VALU count per tile
@@ -1065,7 +1091,9 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
   __shared__ __align__(16) float l2[4 * HT_L2P];
   __shared__ __align__(16) float u3f[4 * HT_U3PL];
   __shared__ __align__(16) float w4s[8][36];
-  __shared__ float wfr[192 + 288 + 72];             // border passes: efr | w3raw [9][4][8] | w4raw [9][8] (broadcast reads)
+  __shared__ float wfr[192 + 288 + 72 + 72];        // border passes: efr | w3raw [9][4][8] | w4raw [9][8] | w2raw [9][2][4]
+  __shared__ float l1[2 * HT_L1P];                  // uprelu1 patch 14 x 14 x 2, clamp-extended
+  __shared__ float hb1[2][HT_LB1], vb1[2][HT_LB1];  // U1[0|99][x'] , U1[y'][0|99]: level-2 frame lines (border tiles)
   __shared__ float hb2[4][HT_LB2], vb2[4][HT_LB2];  // U2[0|199][x'] , U2[y'][0|199]  (border tiles)
   __shared__ float facc[2][2 * HT_T];               // zero-padding corrections of the heat-map frame pixels
   __shared__ unsigned gtab[HT_NQP / 4];             // quad group g = 4i -> byte offset of its first cell | qi << 16 | qj0 << 24
@@ -1083,7 +1111,8 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
     (&w4s[0][0])[tid] = wa;
     if (tid < 32) (&w4s[0][0])[256 + tid] = wb;
     if (tid < 192) wfr[tid] = p.efr[tid];
-    for (int e = tid; e < 288 + 72; e += 256) wfr[192 + e] = e < 288 ? p.w3raw[e] : p.w4raw[e - 288];
+    for (int e = tid; e < 288 + 72 + 72; e += 256)
+      wfr[192 + e] = e < 288 ? p.w3raw[e] : e < 360 ? p.w4raw[e - 288] : p.w2raw[e - 360];
     for (int m = tid; m < HT_NQP; m += 256) {
       const int qi = m / HT_QW, qj = min(m - qi * HT_QW, HT_Q - 1);
       atab[m] = (unsigned short)(qi * HT_L2 + qj);
@@ -1098,21 +1127,23 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
   unsigned bestk = 0xFFFFFFFFu;
   const float bias4 = p.b4[0];
 
-  // software pipeline over the row: the patch of tile t+1 is fetched from HBM while tile t computes
-  constexpr int PATCH = 4 * HT_L2 * HT_L2;  // 2304 = 9 x 256
-  int poff[PATCH / 256], prow[PATCH / 256], pcol[PATCH / 256];  // tile-independent part of the patch addressing
+  // software pipeline over the row: the uprelu1 patch of tile t+1 (14 x 14 x 2, clamp-extended) is fetched from HBM
+  // while tile t computes; low-res origin of the patch = (r0/4 - 2, c0/4 - 2)
+  constexpr int PATCH1 = 2 * HT_L1 * HT_L1;  // 392 = 2 per thread
+  const int ib1 = r0 / 4 - 2;
+  int poff[2], prow[2], pcol[2];
 #pragma unroll
-  for (int u = 0; u < PATCH / 256; u++) {
-    const int e = u * 256 + tid;
-    const int c = e % HT_L2, r = (e / HT_L2) % HT_L2, ci = e / (HT_L2 * HT_L2);
-    poff[u] = e + ci * 16;
-    prow[u] = (ci * HT_S2 + min(max(ib + r, 0), HT_S2 - 1)) * HT_S2;
+  for (int u = 0; u < 2; u++) {
+    const int e = min(u * 256 + tid, PATCH1 - 1);
+    const int ci = e / (HT_L1 * HT_L1), rem = e - ci * (HT_L1 * HT_L1), r = rem / HT_L1, c = rem - r * HT_L1;
+    poff[u] = ci * HT_L1P + rem;
+    prow[u] = (ci * HT_S1 + min(max(ib1 + r, 0), HT_S1 - 1)) * HT_S1;
     pcol[u] = c;
   }
-  const float *up2s = p.up2 + (size_t)s * 4 * HT_S2 * HT_S2;
-  float vals[PATCH / 256];
+  const float *up1s = p.up1 + (size_t)s * 2 * HT_S1 * HT_S1;
+  float vals[2];
 #pragma unroll
-  for (int u = 0; u < PATCH / 256; u++) vals[u] = up2s[prow[u] + min(max(pcol[u] - 2, 0), HT_S2 - 1)];
+  for (int u = 0; u < 2; u++) vals[u] = up1s[prow[u] + min(max(pcol[u] - 2, 0), HT_S1 - 1)];
 
   // per-lane constants of the MFMA stage: n = lane & 15 -> (phase, local channel); kq = lane >> 4 -> input channel
   const int n16 = lane & 15, kq = lane >> 4;
@@ -1125,6 +1156,21 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
   // x = 0 <=> left tile, quad column 1 (register 1 of group 0), phase column 0 ; x = 199 <=> right tile, quad column
   // Q-2 (register 0 of group 20), phase column 1
   const int fr_qi = (top && pa3 == 0) ? 1 : (bot && pa3 == 1) ? HT_Q - 2 : -1;
+  // level 2 (uprelu2 patch from uprelu1, 12 x 12 low-res pixels = 9 M-tiles, K = 9 taps x 2 channels padded to 20):
+  // A[pixel][k = 4 j + kq] = L1[ci = kq & 1][qi + ty][qj + tx], tap = 2 j + (kq >> 1); the two padding rows read cell 0
+  int a2off[5];
+  float bw2[5];
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    const int tap = 2 * j + (kq >> 1);
+    a2off[j] = tap < 9 ? (kq & 1) * HT_L1P + (tap / 3) * HT_L1 + tap % 3 : 0;
+    bw2[j] = p.w2mf[(4 * j + kq) * 16 + n16];
+  }
+  const float bias2 = p.b2[cl3];
+  // frame cells of the uprelu2 plane inside the patch: y2 = 0 <=> top tile, low-res row 1, phase row 0; y2 = 99 <=>
+  // bottom tile, row 10, phase row 1; x2 = 0 <=> left tile, column 1 (register 1 of group 0), phase column 0;
+  // x2 = 99 <=> right tile, column 10 (register 2 of group 8), phase column 1
+  const int fr2_qi = (top && pa3 == 0) ? 1 : (bot && pa3 == 1) ? 10 : -1;
 
 #pragma unroll 1
   for (int tcol = 0; tcol < tiles_x; tcol++) {
@@ -1136,18 +1182,104 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
   // M-tile of stage B instead; the light wave rotates so that the four SIMDs of the CU see the same load
   const int light = (tcol + (int)blockIdx.x) & 3;
 
-  // ---- stage A: the prefetched uprelu2 patch goes to LDS; the next tile's loads are issued right away ----
+  // ---- stage A: the prefetched uprelu1 patch goes to LDS (the next tile's loads are issued right away), then the
+  // uprelu2 patch of the tile is computed in place: upconv2 in phase form on the matrix cores, so the 5 GB uprelu2
+  // tensor never exists either ----
+  const int jb1 = c0 / 4 - 2;
+  const int fc2_q0 = (lef && pb3 == 0) ? 0 : (rig && pb3 == 1) ? 8 : -1, fc2_i = lef ? 1 : 2;
   {
 #pragma unroll
-    for (int u = 0; u < PATCH / 256; u++) l2[poff[u]] = vals[u];
+    for (int u = 0; u < 2; u++)
+      if (u * 256 + tid < PATCH1) l1[poff[u]] = vals[u];
     if (tid < 2 * 2 * HT_T) (&facc[0][0])[tid] = 0.f;
     if (tcol + 1 < tiles_x) {
-      const int jn = (c0 + HT_T) / 2 - 2;
+      const int jn = (c0 + HT_T) / 4 - 2;
 #pragma unroll
-      for (int u = 0; u < PATCH / 256; u++) vals[u] = up2s[prow[u] + min(max(jn + pcol[u], 0), HT_S2 - 1)];
+      for (int u = 0; u < 2; u++) vals[u] = up1s[prow[u] + min(max(jn + pcol[u], 0), HT_S1 - 1)];
     }
   }
   __syncthreads();
+  {
+    const f32x4 binit2 = {bias2, bias2, bias2, bias2};
+#pragma unroll 1
+    for (int mt = wv; mt < 9; mt += 4) {
+      const int m = 16 * mt + n16, qi = m / 12, qj = m - qi * 12;
+      const float *a = &l1[qi * HT_L1 + qj];
+      f32x4 d = binit2;
+#pragma unroll
+      for (int j = 0; j < 5; j++) d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[a2off[j]], bw2[j], d, 0, 0, 0);
+      // D: the 4 consecutive low-res pixels of group 16 mt + 4 kq (one row: 12 = 3 groups), column n = (phase, co)
+      const int g = 16 * mt + 4 * kq, gi = g / 12, gj0 = g - gi * 12;
+      const float rf = gi == fr2_qi ? -INFINITY : 0.f;  // -inf keeps a frame cell raw for the border pass
+      const bool cf = gj0 == fc2_q0;
+      float *w = &l2[cl3 * HT_L2P + (2 * gi + pa3) * HT_L2 + 2 * gj0 + pb3];
+#pragma unroll
+      for (int i = 0; i < 4; i++) w[2 * i] = max_raw(d[i], (cf && fc2_i == i) ? -INFINITY : rf);
+    }
+  }
+  __syncthreads();
+  if (border) {
+    // level-2 frame: lines of the upsampled uprelu1 plane, then the zero-padding correction of the frame cells of
+    // uprelu2 (wave = output channel, lane = cell of the line) and the clamp copies into the cells outside the plane
+    const int nl = (hline ? 1 : 0) + (vline ? 1 : 0);
+    const int ib = r0 / 2 - 2, jb = c0 / 2 - 2;
+    for (int e = tid; e < nl * 2 * HT_LB1; e += 256) {
+      const int li = e / (2 * HT_LB1), rem = e - li * 2 * HT_LB1, ci = rem / HT_LB1, k = rem - ci * HT_LB1;
+      if (hline && li == 0) {
+        const int R = top ? 0 : HT_S1 - 1, xc = min(max(jb - 1 + k, 0), HT_S2 - 1);
+        hb1[ci][k] = up1d(&l1[ci * HT_L1P + (R - ib1) * HT_L1], 1, jb1, xc);
+      } else {
+        const int Cc = lef ? 0 : HT_S1 - 1, yc = min(max(ib - 1 + k, 0), HT_S2 - 1);
+        vb1[ci][k] = up1d(&l1[ci * HT_L1P + (Cc - jb1)], HT_L1, ib1, yc);
+      }
+    }
+    __syncthreads();
+    if (lane < HT_L2) {
+      const float *w = &wfr[192 + 288 + 72 + wv];  // w2raw[(tap * 2 + ci) * 4 + co], co = wave
+      float *pl = &l2[wv * HT_L2P];
+      auto frame_cell2 = [&](int y, int x) {
+        const bool fy = y == 0 || y == HT_S2 - 1, fx = x == 0 || x == HT_S2 - 1;
+        float corr = 0.f;
+        if (fy) {
+          const int trow = (y == 0) ? 0 : 2;
+#pragma unroll
+          for (int dx = -1; dx <= 1; dx++) {
+            const int xx = min(max(x + dx, 0), HT_S2 - 1) - (jb - 1);
+#pragma unroll
+            for (int ci = 0; ci < 2; ci++) corr += w[((trow * 3 + dx + 1) * 2 + ci) * 4] * hb1[ci][xx];
+          }
+        }
+        if (fx) {
+          const int tcol = (x == 0) ? 0 : 2;
+#pragma unroll
+          for (int dy = -1; dy <= 1; dy++) {
+            const int uy = y + dy;
+            if (uy < 0 || uy >= HT_S2) continue;  // counted with the row
+#pragma unroll
+            for (int ci = 0; ci < 2; ci++) corr += w[(((dy + 1) * 3 + tcol) * 2 + ci) * 4] * vb1[ci][uy - (ib - 1)];
+          }
+        }
+        const int pr = y - ib, pc = x - jb;
+        const float v = fmaxf(pl[pr * HT_L2 + pc] - corr, 0.f);
+        // the patch reaches 2 cells beyond the plane: they are clamp copies of the frame cell
+        const int oy = (y == 0) ? -1 : (y == HT_S2 - 1) ? 1 : 0, ox = (x == 0) ? -1 : (x == HT_S2 - 1) ? 1 : 0;
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+          for (int b = 0; b < 3; b++)
+            if ((a == 0 || oy) && (b == 0 || ox)) pl[(pr + a * oy) * HT_L2 + pc + b * ox] = v;
+      };
+      if (hline) {
+        const int x = jb + lane;
+        if (x >= 0 && x < HT_S2) frame_cell2(top ? 0 : HT_S2 - 1, x);
+      }
+      if (vline) {  // the corner cells belong to the horizontal line
+        const int y = ib + lane;
+        if (y > 0 && y < HT_S2 - 1) frame_cell2(y, lef ? 0 : HT_S2 - 1);
+      }
+    }
+    __syncthreads();
+  }
   if (border) {  // frame lines of the upsampled uprelu2 plane (block-uniform); only the lines this tile has
     const int nl = (hline ? 1 : 0) + (vline ? 1 : 0);
     for (int e = tid; e < nl * 4 * HT_LB2; e += 256) {
@@ -1819,7 +1951,7 @@ extern "C" int ofx_policy_forward(ofx_handle *h, const float *weights, const uin
   }
   pp.src_k4 = off[t_u4]; pp.src_b4 = off[t_u4 + 1];
   pp.dst_w4eff = L.w4eff; pp.dst_w4raw = L.w4raw; pp.dst_b4 = L.b4; pp.dst_efr = L.efr;
-  pp.dst_w4eff_c = L.w4eff_c; pp.dst_w3mf = L.w3mf;
+  pp.dst_w4eff_c = L.w4eff_c; pp.dst_w3mf = L.w3mf; pp.dst_w2mf = L.w2mf;
   for (int i = 0; i < 4; i++) pp.dst_bg[i] = L.bg[i];
   hipLaunchKernelGGL(k_policy_prepare, dim3(1), dim3(256), 0, h->stream, pp);
   OFX_HIP(hipGetLastError());
@@ -1884,19 +2016,23 @@ extern "C" int ofx_policy_forward(ofx_handle *h, const float *weights, const uin
   up.in = ws.u0; up.w = ws.prep + L.uw[0]; up.b = ws.prep + L.ub[0]; up.out = ws.up1;
   if ((rc = launch_conv<1, 2, 10, 50, 2, false, false>(h, up, S, 50))) return rc;
   up.in = ws.up1; up.w = ws.prep + L.uw[1]; up.b = ws.prep + L.ub[1]; up.out = ws.up2;
-  if ((rc = launch_conv<2, 4, 10, 100, 2, false, false>(h, up, S, 100))) return rc;
+  const char *hvar = getenv("OFX_HT_VARIANT");
+  const bool wave_private = hvar && hvar[0] == 'w';
+  // upconv2 is computed inside k_head_tail (its 24x24x4 patches are a 9 M-tile phase GEMM from uprelu1); the
+  // stand-alone kernel only feeds the A/B variants
+  if (policy_unfused() || wave_private)
+    if ((rc = launch_conv<2, 4, 10, 100, 2, false, false>(h, up, S, 100))) return rc;
   OFX_HIP(hipMemsetAsync(ws.best, 0, sizeof(unsigned long long) * S, h->stream));
   if (!policy_unfused()) {
     HeadTailParams ht;
-    ht.up2 = ws.up2;
+    ht.up2 = ws.up2; ht.up1 = ws.up1;
+    ht.w2mf = ws.prep + L.w2mf; ht.w2raw = ws.prep + L.uw[1]; ht.b2 = ws.prep + L.ub[1];
     ht.w3mf = ws.prep + L.w3mf; ht.w3raw = ws.prep + L.uw[2]; ht.b3 = ws.prep + L.ub[2];
     ht.w4eff = ws.prep + L.w4eff_c; ht.w4raw = ws.prep + L.w4raw; ht.b4 = ws.prep + L.b4; ht.efr = ws.prep + L.efr;
     ht.mask = ship_mask; ht.best = ws.best; ht.heat = heatmap;
     { const char *e = getenv("OFX_HT_ABLATE"); ht.ablate = e ? atoi(e) : 0; }
     const int pb = h->prof_base;
     if (pb >= 0 && (rc = ofx_event_record(h, pb))) return rc;
-    const char *hv = getenv("OFX_HT_VARIANT");
-    const bool wave_private = hv && hv[0] == 'w';
     if (wave_private) hipLaunchKernelGGL(k_head_tail_w, dim3((unsigned)S), dim3(256), 0, h->stream, ht);
     else hipLaunchKernelGGL(k_head_tail, dim3((unsigned)(S * (HT_S3 / HT_T))), dim3(256), 0, h->stream, ht);
     OFX_HIP(hipGetLastError());
