@@ -75,6 +75,8 @@ struct PrepLayout {
   int efr;            // [line h|v][side first|last][parity 2][low-res offset 3][ci 8]: phase weights of the taps of
                       // upconv4 that fall into the zero padding of a frame pixel (k_head_tail border pass)
   int b4;             // [1]
+  int lut1;           // conv1 on the binary maps as a table: [ci 2][3x3 bit pattern 512][co 8] = sum of the folded
+                      // weights of the set taps (k_conv1_lut)
   int total;
 };
 
@@ -92,6 +94,8 @@ static PrepLayout prep_layout() {
   L.efr = off; off += 2 * 2 * 2 * 3 * 8;
   L.b4 = off; off += 1;
   off += 8;                      // 8 zeros: the background of conv1's binary input
+  off = (off + 3) & ~3;
+  L.lut1 = off; off += 2 * 512 * 8;
   L.total = (off + 63) & ~63;
   return L;
 }
@@ -101,7 +105,7 @@ struct PrepParams {
   float *prep;
   int src_k[7], src_b[7], src_g[7], cin[7], cout[7], dst_w[7], dst_b[7];
   int src_k4, src_b4, dst_w4eff, dst_w4raw, dst_b4, dst_efr;
-  int dst_w4eff_c, dst_w3mf, dst_w2mf;
+  int dst_w4eff_c, dst_w3mf, dst_w2mf, dst_lut1;
   int dst_bg[4];
 };
 
@@ -184,6 +188,20 @@ __global__ void k_policy_prepare(PrepParams p) {
         for (int dx = 0; dx < 3; dx++)
           acc += (p.w[p.src_k[6] + ((dy * 3 + dx) * cin + ci) * cout + co] * inv) * (up_coef(a, dy, ty) * up_coef(b, dx, tx));
       p.prep[p.dst_w3mf + ((co >> 2) * 36 + tap * 4 + ci) * 16 + ph * 4 + (co & 3)] = acc;
+    }
+  }
+  // conv1 (layer 0) reads two BINARY maps: the response of a 3x3 window of one map is one of 512 values per output
+  // channel.  Same fold as above (recomputed: the in-place fold may still be running in other threads); bit
+  // (dy*3 + dx) of the pattern <-> tap (dy, dx), taps summed in tap order.
+  {
+    const float *g = p.w + p.src_g[0];
+    for (int e = tid; e < 2 * 512 * 8; e += blockDim.x) {
+      const int co = e & 7, pat = (e >> 3) & 511, ci = e >> 12;
+      const float inv = g[co] / sqrtf(g[3 * 8 + co] + 1e-3f);
+      float acc = 0.f;
+      for (int tap = 0; tap < 9; tap++)
+        if ((pat >> tap) & 1) acc += p.w[p.src_k[0] + (tap * 2 + ci) * 8 + co] * inv;
+      p.prep[p.dst_lut1 + e] = acc;
     }
   }
   // upconv2 (layer index 5): the same for the 2 -> 4 layer, K padded from 18 to 20 with zero rows
@@ -742,6 +760,87 @@ static int launch_convm(ofx_handle *h, ConvParams p, int images, int H) {
                      h->stream, p);
   OFX_HIP(hipGetLastError());
   return OFX_OK;
+}
+
+// ---- conv1 on the binary observation maps as a table lookup ------------------------------------------------------
+// The two input channels are 1-bit maps, so conv3x3 of one channel at one pixel takes one of 512 values per output
+// channel: out[co] = b[co] + LUT[0][pattern0][co] + LUT[1][pattern1][co] (PrepLayout::lut1, 32 KB, staged in LDS).
+// Every pixel is evaluated (no sparsity shortcut); a thread owns one pooled output pixel = 2x2 conv outputs = a
+// 4x4 bit window per channel: 8 aligned word pairs + funnel shifts give the windows, 16 ds_read_b128 the table rows,
+// then 2x2 max-pool + ReLU and 8 coalesced stores (planar [img][8][200][200]).  ~170 VALU instructions per pooled
+// pixel against 6 MFMAs + epilogue per 16 in the GEMM form (3.4 ms): the kernel is bound by its 5.2 GB of output.
+// Input rows are re-aligned while staging: bit x + 1 of LDS row r <-> image column x of row ty0 - 1 + r (bit 0 and
+// the bits past column W-1 are the zero padding).
+template <int TH>
+__global__ __launch_bounds__(256) void k_conv1_lut(ConvParams p, const float *lut) {
+  constexpr int W = PS, H = PS, WR = 14;                       // words per staged row (402 bits)
+  constexpr int W2 = W / 2, NPX = (TH / 2) * W2;
+  __shared__ __align__(16) float slut[2 * 512 * 8];
+  __shared__ unsigned rows[2][TH + 2][WR];
+  const int tiles = H / TH;
+  const int img = blockIdx.x / tiles, ty0 = (blockIdx.x - img * tiles) * TH;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < 2 * 512 * 8 / 4; e += 256)
+    reinterpret_cast<float4 *>(slut)[e] = reinterpret_cast<const float4 *>(lut)[e];
+  for (int e = tid; e < 2 * (TH + 2) * WR; e += 256) {
+    const int w = e % WR, r = (e / WR) % (TH + 2), ci = e / (WR * (TH + 2));
+    const int gy = ty0 - 1 + r;
+    unsigned out = 0u;
+    if (gy >= 0 && gy < H) {
+      // output bits b = 0..31 <-> column x = 32 w - 1 + b <-> cell gy * W + x
+      const long long s0 = (long long)gy * W + 32 * w - 1;        // cell of output bit 0 (-1 only for gy = 0, w = 0)
+      const unsigned *bits = p.bits[ci] + (size_t)img * ((PS * PS) >> 5);
+      const long long sw = s0 >> 5;                               // arithmetic shift: -1 -> word -1
+      const unsigned lo = (sw >= 0 && sw < (PS * PS) >> 5) ? bits[sw] : 0u;
+      const unsigned hi = (sw + 1 < (PS * PS) >> 5) ? bits[sw + 1] : 0u;
+      out = __funnelshift_r(lo, hi, (unsigned)(s0 & 31));
+      // keep only columns 0 <= x < W of THIS row
+      const int xlo = 32 * w - 1;
+      if (xlo < 0) out &= ~1u;
+      const int over = xlo + 32 - W;                              // bits past the last column
+      if (over > 0) out = over >= 32 ? 0u : (out & (0xFFFFFFFFu >> over));
+    }
+    rows[ci][r][w] = out;
+  }
+  __syncthreads();
+  float bias[8];
+#pragma unroll
+  for (int co = 0; co < 8; co++) bias[co] = p.b[co];
+  for (int px = tid; px < NPX; px += 256) {
+    const int py = px / W2, pxx = px - py * W2;                   // pooled pixel of the tile
+    const int x0 = 2 * pxx;                                       // window = staged bits x0 .. x0 + 3 of rows 2 py .. 2 py + 3
+    float acc[4][8];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+      for (int co = 0; co < 8; co++) acc[q][co] = bias[co];
+#pragma unroll
+    for (int ci = 0; ci < 2; ci++) {
+      unsigned f[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const unsigned *rw = &rows[ci][2 * py + r][x0 >> 5];
+        f[r] = __funnelshift_r(rw[0], rw[1], (unsigned)(x0 & 31)) & 15u;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int dy = q >> 1, dx = q & 1;
+        const unsigned pat = ((f[dy] >> dx) & 7u) | (((f[dy + 1] >> dx) & 7u) << 3) | (((f[dy + 2] >> dx) & 7u) << 6);
+        const float4 *e = reinterpret_cast<const float4 *>(&slut[(ci * 512 + pat) * 8]);
+        const float4 a = e[0], b = e[1];
+        acc[q][0] += a.x; acc[q][1] += a.y; acc[q][2] += a.z; acc[q][3] += a.w;
+        acc[q][4] += b.x; acc[q][5] += b.y; acc[q][6] += b.z; acc[q][7] += b.w;
+      }
+    }
+    float *op = p.out + (((size_t)img * 8) * (H / 2) + (ty0 >> 1) + py) * W2 + pxx;
+#pragma unroll
+    for (int co = 0; co < 8; co++) {
+      float m;
+      asm("v_max3_f32 %0, %1, %2, 0" : "=v"(m) : "v"(acc[0][co]), "v"(acc[1][co]));
+      asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(acc[2][co]), "v"(acc[3][co]), "v"(m));
+      if (!(p.ablate & 4)) op[(size_t)co * (H / 2) * W2] = m;
+    }
+  }
 }
 
 // ---- fp32 MFMA GEMM for the dense layers -------------------------------------------
@@ -1951,7 +2050,7 @@ extern "C" int ofx_policy_forward(ofx_handle *h, const float *weights, const uin
   }
   pp.src_k4 = off[t_u4]; pp.src_b4 = off[t_u4 + 1];
   pp.dst_w4eff = L.w4eff; pp.dst_w4raw = L.w4raw; pp.dst_b4 = L.b4; pp.dst_efr = L.efr;
-  pp.dst_w4eff_c = L.w4eff_c; pp.dst_w3mf = L.w3mf; pp.dst_w2mf = L.w2mf;
+  pp.dst_w4eff_c = L.w4eff_c; pp.dst_w3mf = L.w3mf; pp.dst_w2mf = L.w2mf; pp.dst_lut1 = L.lut1;
   for (int i = 0; i < 4; i++) pp.dst_bg[i] = L.bg[i];
   hipLaunchKernelGGL(k_policy_prepare, dim3(1), dim3(256), 0, h->stream, pp);
   OFX_HIP(hipGetLastError());
@@ -1971,7 +2070,13 @@ extern "C" int ofx_policy_forward(ofx_handle *h, const float *weights, const uin
   // prefetch registers push the kernels to 160-256 VGPRs); tile shapes from an A/B on the chip (tools/ab_convm.sh)
   const bool trunk_valu = getenv("OFX_TRUNK_VALU") != nullptr;  // A/B: the pre-MFMA trunk kernels
   if (trunk_valu) rc = launch_conv8<2, 40, 100, 1, true, false>(h, cp, N, 400);
-  else rc = launch_convm<2, 8, 13, 1, false, 1>(h, cp, N, 400);
+  else if (getenv("OFX_CONV1_MFMA")) rc = launch_convm<2, 8, 13, 1, false, 1>(h, cp, N, 400);  // A/B: the GEMM form
+  else {
+    cp.H = 400; cp.W = 400;
+    hipLaunchKernelGGL(k_conv1_lut<20>, dim3((unsigned)(N * (400 / 20))), dim3(256), 0, h->stream, cp,
+                       (const float *)(ws.prep + L.lut1));
+    OFX_HIP(hipGetLastError());
+  }
   if (rc) return rc;
   cp.in = ws.p1; cp.w = ws.prep + L.tw[1]; cp.b = ws.prep + L.tb[1]; cp.out = ws.p2;
   if (bgskip) { cp.bg_in = ws.prep + L.bg[0]; cp.bg_out = ws.prep + L.bg[1]; }
