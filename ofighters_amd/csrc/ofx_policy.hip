@@ -1130,7 +1130,8 @@ struct HeadTailParams {
   const uint8_t *mask;
   unsigned long long *best;
   float *heat;
-  int ablate;                  // diagnostics (OFX_HT_ABLATE): 1 no stage-A loads, 2 no stage B, 4 no stage C, 8 no border passes
+  int ablate;                  // diagnostics (OFX_HT_ABLATE): 1 no stage-A loads, 2 no stage B, 4 no stage C, 8 no border passes,
+                               // 16 / 32 drop the barrier after stage C / stage B (timing only: the results are wrong)
 };
 
 constexpr int HT_T = 40;              // uprelu3 tile side
@@ -1423,12 +1424,17 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
       // latency -> two independent accumulators keep the matrix pipe full)
       auto run = [&](auto BT) {
         constexpr bool BORDER = decltype(BT)::value;
+        auto floors = [&](unsigned g, float *f) {  // ReLU floor of the 4 cells of a group; -inf keeps a frame cell raw
+          f[0] = f[1] = f[2] = f[3] = 0.f;
+          if (BORDER) {
+            const float rf = (int)((g >> 16) & 0xFFu) == fr_qi ? -INFINITY : 0.f;
+            const bool cf = (int)(g >> 24) == fc_q0;
+            f[0] = (cf && fc_i == 0) ? -INFINITY : rf; f[1] = (cf && fc_i == 1) ? -INFINITY : rf; f[2] = f[3] = rf;
+          }
+        };
 #pragma unroll 1
-        for (int it = 0; it < 5; it++) {
-          int mt0, mt1;
-          bool two = true;  // wave-uniform
-          if (it < 4) { mt0 = wv + 8 * it; mt1 = mt0 + 4; }
-          else { if (wv != light) break; mt0 = mt1 = HT_MT - 1; two = false; }
+        for (int it = 0; it < 4; it++) {
+          const int mt0 = wv + 8 * it, mt1 = mt0 + 4;
           const float *a0 = arow + atab[mt0 * 16 + n16];  // A row = quad m + (lane & 15), k = 4 j + kq
           const float *a1 = arow + atab[mt1 * 16 + n16];
           f32x4 d0 = binit, d1 = binit;
@@ -1439,27 +1445,33 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
           }
           // D: col = lane & 15, row = 4 (lane >> 4) + reg -> the 4 consecutive quads of group mt * 4 + kq
           const unsigned g0 = gtab[mt0 * 4 + kq], g1 = gtab[mt1 * 4 + kq];
-          float f0[4] = {0.f, 0.f, 0.f, 0.f}, f1[4] = {0.f, 0.f, 0.f, 0.f};  // ReLU floor; -inf keeps a frame cell raw
-          if (BORDER) {
-            const float r0f = (int)((g0 >> 16) & 0xFFu) == fr_qi ? -INFINITY : 0.f;
-            const float r1f = (int)((g1 >> 16) & 0xFFu) == fr_qi ? -INFINITY : 0.f;
-            const bool c0f = (int)(g0 >> 24) == fc_q0, c1f = (int)(g1 >> 24) == fc_q0;
-            f0[0] = (c0f && fc_i == 0) ? -INFINITY : r0f; f0[1] = (c0f && fc_i == 1) ? -INFINITY : r0f; f0[2] = f0[3] = r0f;
-            f1[0] = (c1f && fc_i == 0) ? -INFINITY : r1f; f1[1] = (c1f && fc_i == 1) ? -INFINITY : r1f; f1[2] = f1[3] = r1f;
-          }
+          float f0[4], f1[4];
+          floors(g0, f0);
+          floors(g1, f1);
+          float *w0 = (float *)(wbase + (g0 & 0xFFFFu));
+          float *w1 = (float *)(wbase + (g1 & 0xFFFFu));
+#pragma unroll
+          for (int i = 0; i < 4; i++) w0[2 * i] = max_raw(d0[i], f0[i]);
+#pragma unroll
+          for (int i = 0; i < 4; i++) w1[2 * i] = max_raw(d1[i], f1[i]);
+        }
+        if (wv == light) {  // the odd 33rd M-tile: one chain
+          const float *a0 = arow + atab[(HT_MT - 1) * 16 + n16];
+          f32x4 d0 = binit;
+#pragma unroll
+          for (int j = 0; j < 9; j++)
+            d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[(j / 3) * HT_L2 + (j % 3)], bw[j], d0, 0, 0, 0);
+          const unsigned g0 = gtab[(HT_MT - 1) * 4 + kq];
+          float f0[4];
+          floors(g0, f0);
           float *w0 = (float *)(wbase + (g0 & 0xFFFFu));
 #pragma unroll
           for (int i = 0; i < 4; i++) w0[2 * i] = max_raw(d0[i], f0[i]);
-          if (two) {
-            float *w1 = (float *)(wbase + (g1 & 0xFFFFu));
-#pragma unroll
-            for (int i = 0; i < 4; i++) w1[2 * i] = max_raw(d1[i], f1[i]);
-          }
         }
       };
       if (border) run(std::true_type{}); else run(std::false_type{});
     }
-    __syncthreads();
+    if (!(p.ablate & 32)) __syncthreads();
     if (border && !(p.ablate & 8)) {
       // Frame cells (row/col 0 or 199 of the plane) hold G + bias without ReLU: subtract the taps that fall
       // into the conv's zero padding, sum w[tap][ci] U2[clamp] from the frame lines, then apply the ReLU.
@@ -1570,7 +1582,7 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
           }
       }
     }
-    __syncthreads();  // the tile is overwritten by the next half
+    if (!(p.ablate & 16)) __syncthreads();  // the tile is overwritten by the next half
   }
 
   // ---- outputs + arg-max (first maximum in C order) ----
