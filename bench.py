@@ -175,13 +175,14 @@ def main():
     if do_policy:
         # dense algorithmic FLOPs, no sparsity credit: trunk 53.28 MMAC once per arena +
         # 24.37 MMAC per policy ship
-        # dominant kernel: k_head_tail = [x2 bilinear + conv 4->8 + BN + ReLU] + [x2 bilinear + conv 8->1] + arg-max
-        # per policy ship: 200*200*4*9*8 + 400*400*8*9*1 = 23.04 MMAC, dense, no sparsity credit
+        # dominant kernel: k_head_tail = the last three up-convolutions of head-2 + arg-max, fused:
+        # [x2 bilinear + conv 2->4 @100^2] + [x2 + conv 4->8 @200^2] + [x2 + conv 8->1 @400^2]
+        # per policy ship: 0.72 + 11.52 + 11.52 = 23.76 MMAC, dense, no sparsity credit
         kernel = "k_head_tail"
         n_eff = n_pol
         if args.policy_alive_only:   # forwards actually run ~ mean number of playable ships (sampled at the end)
             n_eff = float(b.get(nat.F_SHIP_ALIVE).mean()) * M
-        alg_flops = N * n_eff * 2.0 * 23.04e6
+        alg_flops = N * n_eff * 2.0 * 23.76e6
         whole_forward_flops = N * 2.0 * (53.28e6 + n_eff * 24.37e6)
         achieved = alg_flops / (k_avg_ms * 1e-3) / 1e12
         roof_unit, roof_peak, roof_bound = "TFLOP/s", 157.3, "mfma"

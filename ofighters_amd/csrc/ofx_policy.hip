@@ -75,6 +75,7 @@ struct PrepLayout {
   int efr;            // [line h|v][side first|last][parity 2][low-res offset 3][ci 8]: phase weights of the taps of
                       // upconv4 that fall into the zero padding of a frame pixel (k_head_tail border pass)
   int b4;             // [1]
+  int wbm[3];         // conv2..4: the banded B operand of k_convm laid out per lane: [j 24][lane 64]
   int lut1;           // conv1 on the binary maps as a table: [ci 2][3x3 bit pattern 512][co 8] = sum of the folded
                       // weights of the set taps (k_conv1_lut)
   int total;
@@ -96,6 +97,7 @@ static PrepLayout prep_layout() {
   off += 8;                      // 8 zeros: the background of conv1's binary input
   off = (off + 3) & ~3;
   L.lut1 = off; off += 2 * 512 * 8;
+  for (int i = 0; i < 3; i++) { L.wbm[i] = off; off += 24 * 64; }
   L.total = (off + 63) & ~63;
   return L;
 }
@@ -105,7 +107,7 @@ struct PrepParams {
   float *prep;
   int src_k[7], src_b[7], src_g[7], cin[7], cout[7], dst_w[7], dst_b[7];
   int src_k4, src_b4, dst_w4eff, dst_w4raw, dst_b4, dst_efr;
-  int dst_w4eff_c, dst_w3mf, dst_w2mf, dst_lut1;
+  int dst_w4eff_c, dst_w3mf, dst_w2mf, dst_lut1, dst_wbm[3];
   int dst_bg[4];
 };
 
@@ -161,6 +163,14 @@ __global__ void k_policy_prepare(PrepParams p) {
   // constant gives a constant after layer 2, ... -- same fma order (ci outer, tap inner) as the conv kernels, so
   // the skipped waves write bit-identical values
   __syncthreads();
+  // k_convm's B operand for the 8 -> 8 layers, exactly as lane (n = (co, r), kq) of MFMA step j wants it:
+  // B[k = 4 j + kq][(co, r)] = w[row - r][dx][ci][co] for k = (row * 3 + dx) * 8 + ci inside the 3-row window, else 0
+  for (int l = 1; l < 4; l++)
+    for (int e = tid; e < 24 * 64; e += blockDim.x) {
+      const int lane = e & 63, j = e >> 6, n16 = lane & 15, kq = lane >> 4, co = n16 >> 1, r = n16 & 1;
+      const int k = 4 * j + kq, rd = k >> 3, ci = k & 7, row = rd / 3, dx = rd - row * 3, tr = row - r;
+      p.prep[p.dst_wbm[l - 1] + e] = (tr >= 0 && tr < 3) ? p.prep[p.dst_w[l] + ((tr * 3 + dx) * 8 + ci) * 8 + co] : 0.f;
+    }
   if (tid < 8) {
     float bgv[8];
     for (int ci = 0; ci < 8; ci++) bgv[ci] = 0.f;
@@ -231,6 +241,7 @@ struct ConvParams {
   const float *w, *b;              // folded [9][CIN][COUT], [COUT]
   float *out;                      // planar [img][COUT][Ho][Wo] or HWC [img][Ho][Wo][COUT]
   const uint8_t *mask;             // per image, may be null
+  const float *wbm;                // k_convm, CIN = 8: per-lane B operand [24][64] (PrepLayout::wbm)
   int ablate;                      // diagnostics (OFX_CONV_ABLATE): 1 no global loads, 2 no FMAs, 4 no stores
   const float *bg_in, *bg_out;     // background value per input / output channel (null = no background skip)
   int H, W;                        // conv domain (input after any upsampling) = conv output size
@@ -569,7 +580,8 @@ __global__ __launch_bounds__(256) void k_convm(ConvParams p) {
 #pragma unroll
   for (int j = 0; j < NK; j++) {
     const int k = 4 * j + kq, rd = k / CIN, ci = k - rd * CIN, row = rd / 3, dx = rd - row * 3, tr = row - r;
-    bw[j] = (tr >= 0 && tr < 3) ? p.w[((tr * 3 + dx) * CIN + ci) * 8 + co] : 0.f;
+    if constexpr (CIN == 8) bw[j] = p.wbm[j * 64 + lane];  // pre-arranged by k_policy_prepare: one coalesced load
+    else bw[j] = (tr >= 0 && tr < 3) ? p.w[((tr * 3 + dx) * CIN + ci) * 8 + co] : 0.f;
     aoff[j] = ci * PLS + row * LS + dx;
   }
   const float bias = p.b[co];
@@ -2063,6 +2075,7 @@ extern "C" int ofx_policy_forward(ofx_handle *h, const float *weights, const uin
   pp.src_k4 = off[t_u4]; pp.src_b4 = off[t_u4 + 1];
   pp.dst_w4eff = L.w4eff; pp.dst_w4raw = L.w4raw; pp.dst_b4 = L.b4; pp.dst_efr = L.efr;
   pp.dst_w4eff_c = L.w4eff_c; pp.dst_w3mf = L.w3mf; pp.dst_w2mf = L.w2mf; pp.dst_lut1 = L.lut1;
+  for (int i = 0; i < 3; i++) pp.dst_wbm[i] = L.wbm[i];
   for (int i = 0; i < 4; i++) pp.dst_bg[i] = L.bg[i];
   hipLaunchKernelGGL(k_policy_prepare, dim3(1), dim3(256), 0, h->stream, pp);
   OFX_HIP(hipGetLastError());
@@ -2090,17 +2103,17 @@ extern "C" int ofx_policy_forward(ofx_handle *h, const float *weights, const uin
     OFX_HIP(hipGetLastError());
   }
   if (rc) return rc;
-  cp.in = ws.p1; cp.w = ws.prep + L.tw[1]; cp.b = ws.prep + L.tb[1]; cp.out = ws.p2;
+  cp.in = ws.p1; cp.w = ws.prep + L.tw[1]; cp.b = ws.prep + L.tb[1]; cp.out = ws.p2; cp.wbm = ws.prep + L.wbm[0];
   if (bgskip) { cp.bg_in = ws.prep + L.bg[0]; cp.bg_out = ws.prep + L.bg[1]; }
   if (trunk_valu) rc = launch_conv<8, 8, 10, 100, 0, true, false>(h, cp, N, 200);
   else rc = launch_convm<8, 4, 13, 0, false, 1>(h, cp, N, 200);
   if (rc) return rc;
-  cp.in = ws.p2; cp.w = ws.prep + L.tw[2]; cp.b = ws.prep + L.tb[2]; cp.out = ws.p3;
+  cp.in = ws.p2; cp.w = ws.prep + L.tw[2]; cp.b = ws.prep + L.tb[2]; cp.out = ws.p3; cp.wbm = ws.prep + L.wbm[1];
   if (bgskip) { cp.bg_in = ws.prep + L.bg[1]; cp.bg_out = ws.prep + L.bg[2]; }
   if (trunk_valu) rc = launch_conv<8, 8, 10, 100, 0, true, false>(h, cp, N, 100);
   else rc = launch_convm<8, 10, 7, 0, false, 1>(h, cp, N, 100);
   if (rc) return rc;
-  cp.in = ws.p3; cp.w = ws.prep + L.tw[3]; cp.b = ws.prep + L.tb[3]; cp.out = ws.p4;
+  cp.in = ws.p3; cp.w = ws.prep + L.tw[3]; cp.b = ws.prep + L.tb[3]; cp.out = ws.p4; cp.wbm = ws.prep + L.wbm[2];
   cp.bg_in = nullptr; cp.bg_out = nullptr;
   if (trunk_valu) rc = launch_conv<8, 8, 10, 50, 0, true, true>(h, cp, N, 50);  // (h,w,c) = Flatten order
   else rc = launch_convm<8, 10, 4, 0, true, 1>(h, cp, N, 50);
