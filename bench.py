@@ -43,6 +43,26 @@ def cpu_policy_sample(pyoracle, cfg, w, n_arenas, ticks, n_pol, seed):
             a.step(act)
 
 
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of a kernel from the committed PMC summary (profiles/r01_full_pmc_hbm.txt: rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this same command, tools/final_profile.sh; counters cannot be
+    collected from inside a timed run).  FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950.
+    None when the file or the kernel is missing."""
+    path = os.path.join(ROOT, "profiles", "r01_full_pmc_hbm.txt")
+    try:
+        kb = {}
+        for line in open(path):
+            f = line.rstrip("\n").split("\t")
+            if len(f) == 2 and f[0].startswith(kernel_prefix) and "=" in f[1]:
+                name, val = f[1].split("=")
+                kb[name] = float(val)
+        if "FETCH_SIZE" in kb and "WRITE_SIZE" in kb:
+            return (2.0 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024.0
+    except OSError:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -224,7 +244,9 @@ def main():
         },
         "roofline": {
             "bound": roof_bound, "kernel": kernel, "achieved": achieved, "peak": roof_peak, "unit": roof_unit,
-            "frac": achieved / roof_peak, "traffic": None,
+            "frac": achieved / roof_peak,
+            "traffic": pmc_traffic({"k_head_tail": "k_head_tail", "k_raster<u8>": "void k_raster<0>"}.get(kernel, "\0"))
+                       if (N == 4096 and M == 8 and (not do_policy or (n_pol == M and not args.policy_alive_only))) else None,
             "avg_kernel_ms": k_avg_ms,
             ("algorithmic_flops_per_launch" if do_policy else "algorithmic_bytes_per_launch"):
                 (alg_flops if do_policy else alg_bytes),
@@ -232,6 +254,9 @@ def main():
     }
     if roof_note:
         out["roofline"]["note"] = roof_note
+    if out["roofline"]["traffic"] is not None:
+        out["roofline"]["traffic_source"] = ("HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE in separate "
+                                             "passes of this command: profiles/r01_full_pmc_hbm.txt")
     if score_log:
         out["config"]["last_episode_score_sum"] = int(score_log[-1][:M].sum().item())
         out["config"]["last_episode_arenas"] = int(score_log[-1][M].item())

@@ -96,21 +96,34 @@ def test_policy_determinism_and_trunk_sharing():
     b.close()
 
 
-def test_background_skip_is_bit_identical():
-    """Waves whose receptive windows show only empty space write the precomputed background response instead of
-    running the FMAs; the prepare kernel uses the conv kernels' fma order, so both paths agree bit for bit."""
+def test_trunk_variants_agree():
+    """The trunk has three implementations kept for A/B: the default (conv1 as a table lookup on the bit maps, conv2-4
+    as banded GEMMs on the matrix cores), OFX_CONV1_MFMA=1 (conv1 as a GEMM too) and OFX_TRUNK_VALU=1 (the VALU
+    convolutions).  They agree up to fp32 summation order; the VALU trunk's opt-in background skip
+    (OFX_POLICY_BG_SKIP: waves whose receptive windows show only empty space write the precomputed background
+    response) is bit-identical to the VALU trunk."""
     import os
     from oracle import pyoracle
     b = _rollout(4, 8, seed=8, ticks=30)
     w, _ = pyoracle.policy_init(6, trained_like=True)
-    slow = b.policy_forward_host(w, want_heat=True)
-    os.environ["OFX_POLICY_BG_SKIP"] = "1"     # opt-in (only pays off on sparse scenes)
-    try:
-        fast = b.policy_forward_host(w, want_heat=True)
-    finally:
-        del os.environ["OFX_POLICY_BG_SKIP"]
-    for k in fast:
-        assert np.array_equal(fast[k], slow[k]), k
+
+    def run(**env):
+        os.environ.update(env)
+        try:
+            return b.policy_forward_host(w, want_heat=True)
+        finally:
+            for k in env:
+                del os.environ[k]
+
+    base = run()
+    hs = float(np.abs(base["heat"]).max())
+    valu = run(OFX_TRUNK_VALU="1")
+    for other in (valu, run(OFX_CONV1_MFMA="1")):
+        np.testing.assert_allclose(other["heat"], base["heat"], rtol=0, atol=TOL * hs)
+        np.testing.assert_allclose(other["act"], base["act"], rtol=0, atol=TOL * max(1.0, float(np.abs(base["act"]).max())))
+    skip = run(OFX_TRUNK_VALU="1", OFX_POLICY_BG_SKIP="1")
+    for k in skip:
+        assert np.array_equal(skip[k], valu[k]), k
     b.close()
 
 
