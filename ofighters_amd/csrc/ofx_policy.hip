@@ -594,8 +594,8 @@ __global__ __launch_bounds__(256) void k_convm(ConvParams p) {
   constexpr int V4 = TW / 4, RPW = VEC ? (ROWS + 3) / 4 : 1;       // VEC: float4 per row, rows per wave
   static_assert(!VEC || V4 + 2 <= 64, "tile row wider than one wave");
   unsigned wpre[NWI];
-  float4 vpre[RPW];
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  f32x4 vpre[RPW];  // native vectors: a float4 select is lowered to a pointer select + flat loads
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 
   auto fetch = [&](int t) {
     const int ty0 = (t / p.tiles_x) * TH, tx0 = (t % p.tiles_x) * TW;
@@ -618,13 +618,16 @@ __global__ __launch_bounds__(256) void k_convm(ConvParams p) {
       // that holds the left / right halo column
       const int gxl = lane < V4 ? tx0 + 4 * lane : (lane == V4 ? tx0 - 4 : tx0 + TW);
       const bool colok = lane < V4 + 2 && gxl >= 0 && gxl < W && !(p.ablate & 1);
+      const float *imgbase = p.in + (size_t)img * CIN * H * W;
 #pragma unroll
       for (int u = 0; u < RPW; u++) {
         const int rr = wv + 4 * u;
         const int ci = rr / (TH + 2), r_ = rr - ci * (TH + 2), gy = ty0 - 1 + r_;
         const bool rowok = rr < ROWS && gy >= 0 && gy < H;  // wave-uniform
-        const float *src = p.in + (((size_t)img * CIN + (rowok ? ci : 0)) * H + (rowok ? gy : 0)) * W;
-        vpre[u] = (rowok && colok) ? *reinterpret_cast<const float4 *>(src + gxl) : z4;
+        // 32-bit offset from the image's base (scalar base + vector offset addressing; an image is < 4 GB)
+        const unsigned off = (unsigned)((rowok ? ci * H + gy : 0) * W + gxl);
+        vpre[u] = z4;
+        if (rowok && colok) vpre[u] = *reinterpret_cast<const f32x4 *>(imgbase + off);  // exec-masked global load
       }
     }
   };
@@ -661,9 +664,9 @@ __global__ __launch_bounds__(256) void k_convm(ConvParams p) {
         if (rr >= ROWS) break;  // wave-uniform
         const int ci = rr / (TH + 2), r_ = rr - ci * (TH + 2);
         float *trow = &tile[ci * PLS + r_ * LS];
-        if (lane < V4) *reinterpret_cast<float4 *>(trow + 4 + 4 * lane) = vpre[u];
-        else if (lane == V4) trow[3] = vpre[u].w;
-        else if (lane == V4 + 1) trow[TW + 4] = vpre[u].x;
+        if (lane < V4) *reinterpret_cast<f32x4 *>(trow + 4 + 4 * lane) = vpre[u];
+        else if (lane == V4) trow[3] = vpre[u][3];
+        else if (lane == V4 + 1) trow[TW + 4] = vpre[u][0];
       }
     } else {  // unaligned rows (W % 4 != 0): element-wise, no prefetch (the 50x50 layer only)
       constexpr int RW = TW + 2, TOTAL = CIN * (TH + 2) * RW, SU = 8;
