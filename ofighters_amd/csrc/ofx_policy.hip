@@ -2094,8 +2094,9 @@ extern "C" int ofx_policy_forward(ofx_handle *h, const float *weights, const uin
   const bool bgskip = getenv("OFX_POLICY_BG_SKIP") != nullptr;
   cp.w = ws.prep + L.tw[0]; cp.b = ws.prep + L.tb[0]; cp.out = ws.p1;
   if (bgskip) { cp.bg_in = ws.prep + L.total - 8; cp.bg_out = ws.prep + L.bg[0]; }  // the 8 pad floats are zero
-  // TPW (tiles walked per workgroup with register prefetch) = 1: walking 2..25 tiles measured 40-150 % slower (the
-  // prefetch registers push the kernels to 160-256 VGPRs); tile shapes from an A/B on the chip (tools/ab_convm.sh)
+  // TPW (tiles walked per workgroup with register prefetch) = 1: walking 5 or 25 tiles measured the same time (2.95-2.97
+  // ms for conv2): the kernels are bound by their instruction streams, not by launch or staging latency; tile shapes
+  // from an A/B on the chip (tools/ab_convm.sh)
   const bool trunk_valu = getenv("OFX_TRUNK_VALU") != nullptr;  // A/B: the pre-MFMA trunk kernels
   if (trunk_valu) rc = launch_conv8<2, 40, 100, 1, true, false>(h, cp, N, 400);
   else if (getenv("OFX_CONV1_MFMA")) rc = launch_convm<2, 8, 13, 1, false, 1>(h, cp, N, 400);  // A/B: the GEMM form
@@ -2114,7 +2115,7 @@ extern "C" int ofx_policy_forward(ofx_handle *h, const float *weights, const uin
   cp.in = ws.p2; cp.w = ws.prep + L.tw[2]; cp.b = ws.prep + L.tb[2]; cp.out = ws.p3; cp.wbm = ws.prep + L.wbm[1];
   if (bgskip) { cp.bg_in = ws.prep + L.bg[1]; cp.bg_out = ws.prep + L.bg[2]; }
   if (trunk_valu) rc = launch_conv<8, 8, 10, 100, 0, true, false>(h, cp, N, 100);
-  else rc = launch_convm<8, 10, 7, 0, false, 1>(h, cp, N, 100);
+  else rc = launch_convm<8, 4, 7, 0, false, 1>(h, cp, N, 100);
   if (rc) return rc;
   cp.in = ws.p3; cp.w = ws.prep + L.tw[3]; cp.b = ws.prep + L.tb[3]; cp.out = ws.p4; cp.wbm = ws.prep + L.wbm[2];
   cp.bg_in = nullptr; cp.bg_out = nullptr;
