@@ -1133,7 +1133,6 @@ __global__ __launch_bounds__(256) void k_upconv4(Up4Params p) {
 //   differs from the clamp-extended phase form: border tiles recompute those cells from the definition
 //   (upsample, then conv with zero padding) in a small rolled pass.
 struct HeadTailParams {
-  const float *up2;            // planar [S][4][100][100]  (k_head_tail_w only)
   const float *up1;            // planar [S][2][50][50]: k_head_tail computes its uprelu2 patches itself
   const float *w2mf;           // [20][16] phase weights of upconv2 (MFMA B operand), PrepLayout::w2mf
   const float *w2raw, *b2;     // BN-folded [9][2][4], folded bias [4]
@@ -1677,279 +1676,6 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
   if (lane == 0 && key) atomicMax(&p.best[s], key);
 }
 
-// ---- barrier-free variant of the fused head tail ---------------------------------------------------------------
-// Same math as k_head_tail, different decomposition: one workgroup per ship, its 4 waves are INDEPENDENT pipelines
-// (no __syncthreads anywhere): each wave walks its share of the 13 x 13 tiles of 16 x 16 uprelu3 pixels with a
-// wave-private LDS region (patch 2.3 KB + 4-channel tile 5.8 KB), so a wave never waits for a slower sibling and 16
-// waves per CU (4 per SIMD) interleave their LDS / VALU phases with each other's MFMA phases.  Tiles start at
-// 0,16,...,176,184: the last one overlaps its neighbour by 8 pixels (same values recomputed) because 200 = 12.5 x 16.
-constexpr int WT = 16;                 // uprelu3 tile side
-constexpr int WQ = WT / 2 + 2;         // quads per side (10)
-constexpr int WNQ = WQ * WQ;           // 100
-constexpr int WMT = (WNQ + 15) / 16;   // 16-quad M-tiles (7)
-constexpr int WL2 = WT / 2 + 4;        // uprelu2 patch side (12); plane = 144 floats = 16 mod 32 banks: no padding needed
-constexpr int WU3 = WT + 2;            // tile side incl. halo (18)
-constexpr int WU3P = 20;               // row stride (16-byte aligned rows)
-constexpr int WTD = 13;                // tiles per dimension
-constexpr int WLB2 = WT + 4;           // frame-line length (20)
-
-struct WaveLds {
-  float l2[4][WL2 * WL2];
-  float u3[4][WU3][WU3P];
-  float hb2[4][WLB2], vb2[4][WLB2];
-  float facc[2][2 * WT];
-};
-
-__device__ __forceinline__ void wave_sync() {  // orders this wave's LDS traffic (lanes exchange data through LDS)
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-__global__ __launch_bounds__(256, 4) void k_head_tail_w(HeadTailParams p) {
-  __shared__ __align__(16) WaveLds lds[4];
-  __shared__ __align__(16) unsigned otab[WMT * 16];   // quad -> (2qi-1)*U3P + (2qj-1) + 32 | flags << 12
-  __shared__ unsigned short atab[WMT * 16];           // quad -> qi*L2 + qj
-  __shared__ __align__(16) float w4s[8][36];
-  const int s = blockIdx.x;
-  if (p.mask && !p.mask[s]) return;  // block-uniform
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  {
-    const float wa = p.w4eff[tid], wb = tid < 32 ? p.w4eff[256 + tid] : 0.f;
-    (&w4s[0][0])[tid] = wa;
-    if (tid < 32) (&w4s[0][0])[256 + tid] = wb;
-    if (tid < WMT * 16) {
-      const int mq = min(tid, WNQ - 1), qi = mq / WQ, qj = mq - qi * WQ;
-      unsigned f = (qi == 0 ? 1u : 0u) | (qi == WQ - 1 ? 2u : 0u) | (qj == 0 ? 4u : 0u) | (qj == WQ - 1 ? 8u : 0u) |
-                   (qi == 1 ? 16u : 0u) | (qi == WQ - 2 ? 32u : 0u) | (qj == 1 ? 64u : 0u) | (qj == WQ - 2 ? 128u : 0u);
-      if (tid >= WNQ) f = 15u;
-      otab[tid] = (unsigned)((2 * qi - 1) * WU3P + (2 * qj - 1) + 32) | (f << 12);
-      atab[tid] = (unsigned short)(qi * WL2 + qj);
-    }
-  }
-  __syncthreads();  // the only workgroup barrier: shared read-only tables
-  WaveLds &L = lds[wv];
-  float *l2 = &L.l2[0][0];
-  const float *up2s = p.up2 + (size_t)s * 4 * HT_S2 * HT_S2;
-  const int n16 = lane & 15, kq = lane >> 4;
-  const int ph3 = n16 >> 2, cl3 = n16 & 3, pa3 = ph3 >> 1, pb3 = ph3 & 1;
-  const unsigned badmask = ((pa3 ? 2u : 1u) | (pb3 ? 8u : 4u)) << 12;
-  const int cell_off = cl3 * WU3 * WU3P + pa3 * WU3P + pb3 - 32;
-  const float bias4 = p.b4[0];
-  const int crow = lane >> 2, ccol = 4 * (lane & 3);   // stage C: lane owns pixels (crow, ccol..ccol+3) of the tile
-  const int coff = crow * WU3P + ccol;
-  float bestv = -INFINITY;
-  unsigned bestk = 0xFFFFFFFFu;
-
-  // patch element e = u*64 + lane -> (ci, r, c) of the 12x12x4 patch (9 per lane)
-  auto patch_src = [&](int u, int ib_, int jb_) {
-    const int e = u * 64 + lane;
-    const int c = e % WL2, r = (e / WL2) % WL2, ci = e / (WL2 * WL2);
-    return (ci * HT_S2 + min(max(ib_ + r, 0), HT_S2 - 1)) * HT_S2 + min(max(jb_ + c, 0), HT_S2 - 1);
-  };
-  constexpr int PN = 4 * WL2 * WL2 / 64;  // 9
-  float vals[PN];
-  {
-    const int t0 = wv, r0 = min((t0 / WTD) * WT, HT_S3 - WT), c0 = min((t0 % WTD) * WT, HT_S3 - WT);
-#pragma unroll
-    for (int u = 0; u < PN; u++) vals[u] = up2s[patch_src(u, r0 / 2 - 2, c0 / 2 - 2)];
-  }
-
-#pragma unroll 1
-  for (int t = wv; t < WTD * WTD; t += 4) {
-    const int r0 = min((t / WTD) * WT, HT_S3 - WT), c0 = min((t % WTD) * WT, HT_S3 - WT);
-    const int ib = r0 / 2 - 2, jb = c0 / 2 - 2;
-    const bool top = r0 == 0, bot = r0 + WT == HT_S3, lef = c0 == 0, rig = c0 + WT == HT_S3;
-    const bool hline = top || bot, vline = lef || rig, border = hline || vline;
-    const unsigned framemask = (((top && pa3 == 0) ? 16u : 0u) | ((bot && pa3 == 1) ? 32u : 0u) |
-                                ((lef && pb3 == 0) ? 64u : 0u) | ((rig && pb3 == 1) ? 128u : 0u)) << 12;
-    wave_sync();  // the previous tile's readers are done with this wave's LDS
-    // ---- stage A ----
-#pragma unroll
-    for (int u = 0; u < PN; u++) l2[u * 64 + lane] = vals[u];
-    if (lane < 2 * 2 * WT) (&L.facc[0][0])[lane] = 0.f;
-    if (t + 4 < WTD * WTD) {
-      const int tn = t + 4, rn = min((tn / WTD) * WT, HT_S3 - WT), cn = min((tn % WTD) * WT, HT_S3 - WT);
-#pragma unroll
-      for (int u = 0; u < PN; u++) vals[u] = up2s[patch_src(u, rn / 2 - 2, cn / 2 - 2)];
-    }
-    wave_sync();
-    if (border) {
-      for (int e = lane; e < 2 * 4 * WLB2; e += 64) {
-        const int k = e % WLB2, ci = (e / WLB2) & 3, line = e / (4 * WLB2);
-        if (line == 0 && hline) {
-          const int R = top ? 0 : HT_S2 - 1, xc = min(max(c0 - 2 + k, 0), HT_S3 - 1);
-          L.hb2[ci][k] = up1d(&L.l2[ci][(R - ib) * WL2], 1, jb, xc);
-        } else if (line == 1 && vline) {
-          const int Cc = lef ? 0 : HT_S2 - 1, yc = min(max(r0 - 2 + k, 0), HT_S3 - 1);
-          L.vb2[ci][k] = up1d(&L.l2[ci][Cc - jb], WL2, ib, yc);
-        }
-      }
-      wave_sync();
-    }
-    f32x4 cacc[4];
-#pragma unroll
-    for (int g = 0; g < 4; g++) cacc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll 1
-    for (int half = 0; half < 2; half++) {
-      // ---- stage B ----
-      {
-        const float bias3 = p.b3[4 * half + cl3];
-        float bw[9];  // re-read per half (L1/L2 resident): keeping both halves live spilled registers
-#pragma unroll
-        for (int j = 0; j < 9; j++) bw[j] = p.w3mf[(half * 36 + 4 * j + kq) * 16 + n16];
-        float *ubase = &L.u3[0][0][0] + cell_off;
-#pragma unroll 1
-        for (int mt = 0; mt < WMT; mt += 2) {
-          const int m0 = mt * 16, m1 = min(mt + 1, WMT - 1) * 16;
-          const bool two = mt + 1 < WMT;
-          const float *a0 = &L.l2[kq][0] + atab[m0 + n16];
-          const float *a1 = &L.l2[kq][0] + atab[m1 + n16];
-          f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int j = 0; j < 9; j++) {
-            const float b = bw[j];
-            d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[(j / 3) * WL2 + (j % 3)], b, d0, 0, 0, 0);
-            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[(j / 3) * WL2 + (j % 3)], b, d1, 0, 0, 0);
-          }
-          const uint4 oa = *reinterpret_cast<const uint4 *>(&otab[m0 + 4 * kq]);
-          const uint4 ob = *reinterpret_cast<const uint4 *>(&otab[m1 + 4 * kq]);
-          const unsigned o0[4] = {oa.x, oa.y, oa.z, oa.w}, o1[4] = {ob.x, ob.y, ob.z, ob.w};
-#pragma unroll
-          for (int i = 0; i < 4; i++) {
-            if (!(o0[i] & badmask)) ubase[o0[i] & 0xFFFu] = fmaxf(d0[i] + bias3, (o0[i] & framemask) ? -INFINITY : 0.f);
-            if (two && !(o1[i] & badmask))
-              ubase[o1[i] & 0xFFFu] = fmaxf(d1[i] + bias3, (o1[i] & framemask) ? -INFINITY : 0.f);
-          }
-        }
-      }
-      wave_sync();
-      if (border) {
-        for (int e = lane; e < 4 * 2 * WU3; e += 64) {
-          const int k = e % WU3, line = (e / WU3) & 1, cl = e / (2 * WU3);
-          int y, x;
-          if (line == 0) { if (!hline) continue; y = top ? 0 : HT_S3 - 1; x = c0 - 1 + k; }
-          else { if (!vline) continue; x = lef ? 0 : HT_S3 - 1; y = r0 - 1 + k; }
-          if (y < 0 || y >= HT_S3 || x < 0 || x >= HT_S3) continue;
-          const bool fy = y == 0 || y == HT_S3 - 1, fx = x == 0 || x == HT_S3 - 1;
-          if (line == 1 && fy) continue;
-          const float *w = p.w3raw + 4 * half + cl;
-          float corr = 0.f;
-          if (fy) {
-            const int trow = (y == 0) ? 0 : 2;
-#pragma unroll
-            for (int dx = -1; dx <= 1; dx++) {
-              const int xx = min(max(x + dx, 0), HT_S3 - 1) - (c0 - 2);
-#pragma unroll
-              for (int ci = 0; ci < 4; ci++) corr += w[((trow * 3 + dx + 1) * 4 + ci) * 8] * L.hb2[ci][xx];
-            }
-          }
-          if (fx) {
-            const int tcol = (x == 0) ? 0 : 2;
-#pragma unroll
-            for (int dy = -1; dy <= 1; dy++) {
-              const int uy = y + dy;
-              if (uy < 0 || uy >= HT_S3) continue;
-#pragma unroll
-              for (int ci = 0; ci < 4; ci++) corr += w[(((dy + 1) * 3 + tcol) * 4 + ci) * 8] * L.vb2[ci][uy - (r0 - 2)];
-            }
-          }
-          const int ty = y - (r0 - 1), tx = x - (c0 - 1);
-          const float v = fmaxf(L.u3[cl][ty][tx] - corr, 0.f);
-          L.u3[cl][ty][tx] = v;
-          const int oy = (y == 0) ? -1 : (y == HT_S3 - 1) ? 1 : 0, ox = (x == 0) ? -1 : (x == HT_S3 - 1) ? 1 : 0;
-          if (oy) L.u3[cl][ty + oy][tx] = v;
-          if (ox) L.u3[cl][ty][tx + ox] = v;
-          if (oy && ox) L.u3[cl][ty + oy][tx + ox] = v;
-        }
-        wave_sync();
-        for (int e = lane; e < 2 * 2 * WT; e += 64) {
-          const int k = e % (2 * WT), line = e / (2 * WT);
-          const float *w = p.w4raw + 4 * half;
-          float corr = 0.f;
-          if (line == 0 && hline) {
-            const int trow = top ? 0 : 2, x = 2 * c0 + k, R = (top ? 0 : HT_S3 - 1) - (r0 - 1);
-#pragma unroll
-            for (int dx = -1; dx <= 1; dx++) {
-              const int xc = min(max(x + dx, 0), PS - 1);
-#pragma unroll
-              for (int cl = 0; cl < 4; cl++) corr += w[(trow * 3 + dx + 1) * 8 + cl] * up1d(&L.u3[cl][R][0], 1, c0 - 1, xc);
-            }
-          } else if (line == 1 && vline) {
-            const int tcol = lef ? 0 : 2, y = 2 * r0 + k, Cc = (lef ? 0 : HT_S3 - 1) - (c0 - 1);
-#pragma unroll
-            for (int dy = -1; dy <= 1; dy++) {
-              const int uy = y + dy;
-              if (uy < 0 || uy >= PS) continue;
-#pragma unroll
-              for (int cl = 0; cl < 4; cl++) corr += w[((dy + 1) * 3 + tcol) * 8 + cl] * up1d(&L.u3[cl][0][Cc], WU3P, r0 - 1, uy);
-            }
-          }
-          L.facc[line][k] += corr;
-        }
-      }
-      // ---- stage C on the VALU: v_mfma_f32_4x4x1 measured 70 TFLOP/s (half rate), v_fmac with VGPR operands 115,
-      // and VALU work overlaps the other waves' 16x16x4 MFMAs (separate pipe).  The 36 phase weights of a channel
-      // arrive as broadcast b128 LDS reads; each feeds the lane's 4 pixels. ----
-      {
-        const float *ub = &L.u3[0][0][0] + coff;
-#pragma unroll
-        for (int cl = 0; cl < 4; cl++) {
-          float wv4[36];
-#pragma unroll
-          for (int q = 0; q < 9; q++) {
-            const float4 t4 = *reinterpret_cast<const float4 *>(&w4s[4 * half + cl][4 * q]);
-            wv4[4 * q] = t4.x; wv4[4 * q + 1] = t4.y; wv4[4 * q + 2] = t4.z; wv4[4 * q + 3] = t4.w;
-          }
-#pragma unroll
-          for (int a = 0; a < 3; a++) {
-            const float *row = ub + cl * WU3 * WU3P + a * WU3P;
-            const float4 lo = *reinterpret_cast<const float4 *>(row);
-            const float2 hi = *reinterpret_cast<const float2 *>(row + 4);
-            const float v[6] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y};
-#pragma unroll
-            for (int b = 0; b < 3; b++)
-#pragma unroll
-              for (int ph = 0; ph < 4; ph++) {
-                const float wv = wv4[ph * 9 + a * 3 + b];
-#pragma unroll
-                for (int g = 0; g < 4; g++) cacc[g][ph] = __builtin_fmaf(v[g + b], wv, cacc[g][ph]);
-              }
-          }
-        }
-      }
-      wave_sync();  // the tile is overwritten by the next half
-    }
-
-    // ---- outputs + arg-max ----
-    const int li = r0 + crow, lj0 = c0 + ccol;
-#pragma unroll
-    for (int g = 0; g < 4; g++)
-#pragma unroll
-      for (int ph = 0; ph < 4; ph++) {
-        const int y = 2 * li + (ph >> 1), x = 2 * (lj0 + g) + (ph & 1);
-        float val = cacc[g][ph] + bias4;
-        if (border) {
-          if (y == 0 || y == PS - 1) val -= L.facc[0][x - 2 * c0];
-          if (x == 0 || x == PS - 1) val -= L.facc[1][y - 2 * r0];
-        }
-        const unsigned k = (unsigned)(y * PS + x);
-        if (p.heat) p.heat[(size_t)s * PS * PS + k] = val;
-        if (val > bestv || (val == bestv && k < bestk)) { bestv = val; bestk = k; }
-      }
-  }
-
-  unsigned long long key = ((unsigned long long)ordered_f32(bestv) << 32) | (unsigned long long)(~bestk);
-  if (bestk == 0xFFFFFFFFu) key = 0ull;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const unsigned long long other = __shfl_xor(key, o);
-    key = other > key ? other : key;
-  }
-  if (lane == 0 && key) atomicMax(&p.best[s], key);
-}
-
 __global__ void k_policy_finish(int S, const uint8_t *mask, const unsigned long long *best, int32_t *ipointer) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= S || (mask && !mask[s])) return;
@@ -2150,16 +1876,14 @@ extern "C" int ofx_policy_forward(ofx_handle *h, const float *weights, const uin
   up.in = ws.u0; up.w = ws.prep + L.uw[0]; up.b = ws.prep + L.ub[0]; up.out = ws.up1;
   if ((rc = launch_conv<1, 2, 10, 50, 2, false, false>(h, up, S, 50))) return rc;
   up.in = ws.up1; up.w = ws.prep + L.uw[1]; up.b = ws.prep + L.ub[1]; up.out = ws.up2;
-  const char *hvar = getenv("OFX_HT_VARIANT");
-  const bool wave_private = hvar && hvar[0] == 'w';
   // upconv2 is computed inside k_head_tail (its 24x24x4 patches are a 9 M-tile phase GEMM from uprelu1); the
-  // stand-alone kernel only feeds the A/B variants
-  if (policy_unfused() || wave_private)
+  // stand-alone kernel only feeds the layer-by-layer A/B path
+  if (policy_unfused())
     if ((rc = launch_conv<2, 4, 10, 100, 2, false, false>(h, up, S, 100))) return rc;
   OFX_HIP(hipMemsetAsync(ws.best, 0, sizeof(unsigned long long) * S, h->stream));
   if (!policy_unfused()) {
     HeadTailParams ht;
-    ht.up2 = ws.up2; ht.up1 = ws.up1;
+    ht.up1 = ws.up1;
     ht.w2mf = ws.prep + L.w2mf; ht.w2raw = ws.prep + L.uw[1]; ht.b2 = ws.prep + L.ub[1];
     ht.w3mf = ws.prep + L.w3mf; ht.w3raw = ws.prep + L.uw[2]; ht.b3 = ws.prep + L.ub[2];
     ht.w4eff = ws.prep + L.w4eff_c; ht.w4raw = ws.prep + L.w4raw; ht.b4 = ws.prep + L.b4; ht.efr = ws.prep + L.efr;
@@ -2167,8 +1891,7 @@ extern "C" int ofx_policy_forward(ofx_handle *h, const float *weights, const uin
     { const char *e = getenv("OFX_HT_ABLATE"); ht.ablate = e ? atoi(e) : 0; }
     const int pb = h->prof_base;
     if (pb >= 0 && (rc = ofx_event_record(h, pb))) return rc;
-    if (wave_private) hipLaunchKernelGGL(k_head_tail_w, dim3((unsigned)S), dim3(256), 0, h->stream, ht);
-    else hipLaunchKernelGGL(k_head_tail, dim3((unsigned)(S * (HT_S3 / HT_T))), dim3(256), 0, h->stream, ht);
+    hipLaunchKernelGGL(k_head_tail, dim3((unsigned)(S * (HT_S3 / HT_T))), dim3(256), 0, h->stream, ht);
     OFX_HIP(hipGetLastError());
     if (pb >= 0) {
       if ((rc = ofx_event_record(h, pb + 1))) return rc;
