@@ -323,6 +323,27 @@ int ofx_replay_sample(ofx_handle *h, uint64_t seed, uint32_t draw, int32_t batch
 int ofx_replay_gather(ofx_handle *h, const int32_t *slot, int32_t batch, ofx_transition *rows, void *bits_prev,
                       void *bits_next);
 
+/* ---- forward on stored observations, TD targets -------------------------
+ * The predictions Trainer.replay makes on a minibatch (agents/qlearnIA_V2.py:251-268): n_obs observations given as
+ * 1-bit map pairs bits[n_obs][2 (ship, laser)][W*H/32] uint32 (the layout ofx_replay_gather writes) + their toVector
+ * heads vec8[n_obs][8]; every observation gets its own trunk run.  Outputs (device, any may be NULL): act_values
+ * [n_obs][2], iaction [n_obs], ipointer [n_obs][2], ptr_max [n_obs] = np.max of the heat map; with probe [n_obs][2]
+ * (x, y) also ptr_probe [n_obs] = the heat-map value at that pointer.  Uses the policy workspace: the (iaction,
+ * ipointer) a previous ofx_policy_forward left there are gone afterwards.                                        */
+int ofx_policy_forward_obs(ofx_handle *h, const float *weights, int32_t n_obs, const void *bits, const float *vec8,
+                           float *act_values, int32_t *iaction, int32_t *ipointer, float *ptr_max,
+                           const int32_t *probe, float *ptr_probe);
+/* The targets Trainer.replay builds (:269-270) for n gathered transitions (rows, bits_prev, bits_next from
+ * ofx_replay_gather): two forwards, then per row
+ *   q_sa  = act_values(state)[iaction]           y_act = reward + gamma * max(act_values(next_state)) * (not done)
+ *   p_sp  = heat(state) at ipointer              y_ptr = reward + gamma * max(heat(next_state))       * (not done)
+ * i.e. the current values and the values written into target[iaction] / ptr_target[ipointer]; their squared
+ * differences are the two MSE terms the fit minimises.  The reference indexes ptr_target[x][y] on a [y][x] map
+ * (:280) and fits on next_state's inputs (:282-283); here the pointer addresses the pixel it was chosen as - the
+ * quirks are stated, not reproduced.  Padding rows (ship < 0) give zeros.  The fit itself is not built.           */
+int ofx_dqn_targets(ofx_handle *h, const float *weights, int32_t n, const ofx_transition *rows, const void *bits_prev,
+                    const void *bits_next, float gamma, float *q_sa, float *p_sp, float *y_act, float *y_ptr);
+
 /* ---- timing helpers (HIP events on the handle's stream) ---------------- */
 int ofx_timer_start(ofx_handle *h);
 int ofx_timer_stop(ofx_handle *h, float *ms_host); /* synchronises */

@@ -58,6 +58,8 @@ struct ofx_handle {
   int ring_n;
   int prof_base;                   // ofx_policy_profile: next event pair, -1 = off
   ofx_replay *replay;              // transition memory (ofx_replay_create), null = none
+  void *aux;                       // temporaries of ofx_dqn_targets (grown on demand)
+  size_t aux_bytes;
 };
 
 // kernels / launchers implemented in the other translation units

@@ -237,7 +237,8 @@ __global__ void k_policy_prepare(PrepParams p) {
 // ---- generic direct 3x3 convolution ------------------------------------------------
 struct ConvParams {
   const float *in;                 // MODE 0 / 2: planar [img][CIN][Hin][Win]
-  const unsigned *bits[2];         // MODE 1: [arena][PS*PS/32] LSB-first (ch0 ship, ch1 laser)
+  const unsigned *bits[2];         // MODE 1: word bits[ci][img * bits_stride + w], LSB-first (ch0 ship, ch1 laser)
+  size_t bits_stride;              // words between consecutive images (PS*PS/32, or twice that for interleaved maps)
   const float *w, *b;              // folded [9][CIN][COUT], [COUT]
   float *out;                      // planar [img][COUT][Ho][Wo] or HWC [img][Ho][Wo][COUT]
   const uint8_t *mask;             // per image, may be null
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(((TH / 2) * (TW / 2) + 63) / 64 * 64) void k_conv(C
             v = (p.ablate & 1) ? 1.f : p.in[(((size_t)img * CIN + ci) * H + gy) * W + gx];
           } else if (MODE == 1) {
             const int cell = gy * W + gx;
-            v = (float)((p.bits[ci][(size_t)img * ((PS * PS) >> 5) + (cell >> 5)] >> (cell & 31)) & 1u);
+            v = (float)((p.bits[ci][(size_t)img * p.bits_stride + (cell >> 5)] >> (cell & 31)) & 1u);
           } else {
             const int Hs = H >> 1, Ws = W >> 1;
             const float sy = ((float)gy + 0.5f) * 0.5f - 0.5f, sx = ((float)gx + 0.5f) * 0.5f - 0.5f;
@@ -418,7 +419,7 @@ __global__ __launch_bounds__(((TH / 2) * (TW / 4) + 63) / 64 * 64) void k_conv8(
       const int cell0 = gy * W + tx0 - 1;            // cell index of tile column 0 (may be -1 at the left image edge)
       const int w0 = (cell0 >= 0 ? cell0 : 0) >> 5;  // first word of the row segment
       const int wi = w0 + k;
-      const unsigned word = (wi < (PS * PS) >> 5) ? p.bits[ci][(size_t)img * ((PS * PS) >> 5) + wi] : 0u;
+      const unsigned word = (wi < (PS * PS) >> 5) ? p.bits[ci][(size_t)img * p.bits_stride + wi] : 0u;
       // cells of this word: wi*32 .. wi*32+31 -> tile columns c = cell - cell0
       const int cbeg = max(wi * 32 - cell0, 0), cend = min(wi * 32 + 32 - cell0, TWP);
       if (k == 0)
@@ -609,7 +610,7 @@ __global__ __launch_bounds__(256) void k_convm(ConvParams p) {
         if (e < ROWS * WPR && gy >= 0 && gy < H) {
           const int cell0 = gy * W + tx0 - 1;
           const int wi = ((cell0 >= 0 ? cell0 : 0) >> 5) + k;
-          if (wi < (PS * PS) >> 5) word = p.bits[ci][(size_t)img * ((PS * PS) >> 5) + wi];
+          if (wi < (PS * PS) >> 5) word = p.bits[ci][(size_t)img * p.bits_stride + wi];
         }
         wpre[u] = word;
       }
@@ -804,7 +805,7 @@ __global__ __launch_bounds__(256) void k_conv1_lut(ConvParams p, const float *lu
     if (gy >= 0 && gy < H) {
       // output bits b = 0..31 <-> column x = 32 w - 1 + b <-> cell gy * W + x
       const long long s0 = (long long)gy * W + 32 * w - 1;        // cell of output bit 0 (-1 only for gy = 0, w = 0)
-      const unsigned *bits = p.bits[ci] + (size_t)img * ((PS * PS) >> 5);
+      const unsigned *bits = p.bits[ci] + (size_t)img * p.bits_stride;
       const long long sw = s0 >> 5;                               // arithmetic shift: -1 -> word -1
       const unsigned lo = (sw >= 0 && sw < (PS * PS) >> 5) ? bits[sw] : 0u;
       const unsigned hi = (sw + 1 < (PS * PS) >> 5) ? bits[sw + 1] : 0u;
@@ -944,6 +945,7 @@ struct HeadParams {
   int g1_chunks;
   const float *k1, *b1, *k2, *b2, *k3, *b3;
   const uint8_t *mask;
+  const float *vec8;          // [S][8] explicit observation heads (ofx_policy_forward_obs) or null = the live state
   float *d1;                  // [S][100]
   float *act;                 // [S][2] or null
   int32_t *iaction;           // [S] or null
@@ -958,10 +960,15 @@ __global__ __launch_bounds__(256) void k_head_dense(HeadParams p) {
   const int a = on ? s / p.M : 0;
   float vec[8];
   if (on) {  // obs.vector[:8] (observation.py:119-123): reward, can_shoot, pointing, dim, pos
-    vec[0] = (float)p.st.reward[s]; vec[1] = 1.f;
-    vec[2] = (float)p.st.ship_px[s]; vec[3] = (float)p.st.ship_py[s];
-    vec[4] = (float)PS; vec[5] = (float)PS;
-    vec[6] = (float)p.st.ship_x[s]; vec[7] = (float)p.st.ship_y[s];
+    if (p.vec8) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) vec[k] = p.vec8[(size_t)s * 8 + k];
+    } else {
+      vec[0] = (float)p.st.reward[s]; vec[1] = 1.f;
+      vec[2] = (float)p.st.ship_px[s]; vec[3] = (float)p.st.ship_py[s];
+      vec[4] = (float)PS; vec[5] = (float)PS;
+      vec[6] = (float)p.st.ship_x[s]; vec[7] = (float)p.st.ship_y[s];
+    }
     for (int o = lane; o < 100; o += 64) {
       float acc = 0.f;
 #pragma unroll
@@ -1144,6 +1151,8 @@ struct HeadTailParams {
   const uint8_t *mask;
   unsigned long long *best;
   float *heat;
+  const int32_t *probe;        // [S][2] (x, y) or null: ptr_probe[s] = heat-map value at that pointer
+  float *ptr_probe;
   int ablate;                  // diagnostics (OFX_HT_ABLATE): 1 no stage-A loads, 2 no stage B, 4 no stage C, 8 no border passes,
                                // 16 / 32 drop the barrier after stage C / stage B (timing only: the results are wrong)
 };
@@ -1637,6 +1646,19 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
           p.heat[(size_t)s * PS * PS + (size_t)(2 * li + (ph >> 1)) * PS + 2 * (lj0 + g) + (ph & 1)] = cacc[q][g][ph];
     }
   }
+  if (p.ptr_probe) {  // block-uniform; one pixel per ship: the lane that owns it stores it
+    const int pk = p.probe[2 * s + 1] * PS + p.probe[2 * s];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      if (q == 1 && !pass1) break;
+      const int li = r0 + ctask[q] / (HT_T / 4), lj0 = c0 + 4 * (ctask[q] % (HT_T / 4));
+#pragma unroll
+      for (int g = 0; g < 4; g++)
+#pragma unroll
+        for (int ph = 0; ph < 4; ph++)
+          if ((2 * li + (ph >> 1)) * PS + 2 * (lj0 + g) + (ph & 1) == pk) p.ptr_probe[s] = cacc[q][g][ph];
+    }
+  }
   {
     // per thread the 32 values are visited in increasing flat index, so a strict > keeps the first maximum; the slot
     // is a compile-time constant (3 VALU instructions per value); lanes past the 400th task hold copies of task 399
@@ -1676,12 +1698,18 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
   if (lane == 0 && key) atomicMax(&p.best[s], key);
 }
 
-__global__ void k_policy_finish(int S, const uint8_t *mask, const unsigned long long *best, int32_t *ipointer) {
+__device__ inline float unordered_f32(unsigned o) {  // inverse of ordered_f32
+  return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o);
+}
+
+__global__ void k_policy_finish(int S, const uint8_t *mask, const unsigned long long *best, int32_t *ipointer,
+                                float *ptr_max) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= S || (mask && !mask[s])) return;
   const unsigned k = ~(unsigned)(best[s] & 0xFFFFFFFFull);
   ipointer[2 * s] = (int)(k % PS);      // unravel_index(order='F') of a C-order flat index = (x, y)
   ipointer[2 * s + 1] = (int)(k / PS);  // qlearnIA_V2.py:218-220
+  if (ptr_max) ptr_max[s] = unordered_f32((unsigned)(best[s] >> 32));  // np.max(ptr_prediction)
 }
 
 // QlearnIA.play packing (qlearnIA_V2.py:447-454): exactly one of shoot / thrust, pointer always set
@@ -1715,8 +1743,9 @@ static bool policy_unfused() {
 static size_t al(size_t b) { return (b + 255) & ~(size_t)255; }
 constexpr int kDense1Chunks = 25;  // split-K of dense1: 5000 = 25 x 200
 
-static int policy_workspace(ofx_handle *h, PolicyWs *ws) {
-  const size_t N = h->cfg.n_arenas, S = N * h->cfg.n_ships;
+// N images (trunk runs), S policy samples (heads); the layout depends on both, so a forward with other sizes
+// (ofx_policy_forward_obs) invalidates the results a previous forward left in the workspace
+static int policy_workspace(ofx_handle *h, PolicyWs *ws, size_t N, size_t S) {
   const PrepLayout L = prep_layout();
   const size_t sz[] = {al(4ull * L.total),          al(4ull * N * 8 * 200 * 200), al(4ull * N * 8 * 100 * 100),
                        al(4ull * N * 8 * 50 * 50),   al(4ull * N * 5000),          al(4ull * N * 100 * kDense1Chunks),
@@ -1768,27 +1797,22 @@ static int launch_gemm(ofx_handle *h, const float *A, int lda, const float *B, i
   return OFX_OK;
 }
 
-extern "C" int ofx_policy_forward(ofx_handle *h, const float *weights, const uint8_t *ship_mask, float *act_values,
-                                  int32_t *iaction, int32_t *ipointer, float *heatmap) {
-  if (!h || !weights) { ofx_set_error("ofx_policy_forward: null argument"); return OFX_ERR_INVALID; }
-  if (!h->spawned) { ofx_set_error("You must execute analyse_battleground first."); return OFX_ERR_STATE; }
+// The forward proper: N images (two 1-bit maps each: word bits?[img * bits_stride + w]) with M policy samples per
+// image; vec8 = explicit observation heads [N*M][8] or null (the live state of the handle's arenas).
+static int policy_forward_impl(ofx_handle *h, const float *weights, int N, int M, const unsigned *bits0,
+                               const unsigned *bits1, size_t bits_stride, const float *vec8, const uint8_t *ship_mask,
+                               float *act_values, int32_t *iaction, int32_t *ipointer, float *heatmap, float *ptr_max,
+                               const int32_t *probe, float *ptr_probe) {
   const ofx_config &c = h->cfg;
-  if (c.width != PS || c.height != PS) {
-    // Input((DEFAULT_WIDTH, DEFAULT_HEIGHT, 2)) is fixed at 400x400 (qlearnIA_V2.py:125)
-    ofx_set_error("ofx_policy_forward: the pointer_model takes 400x400 maps (got %d x %d)", c.width, c.height);
-    return OFX_ERR_INVALID;
-  }
-  OFX_HIP(hipSetDevice(c.device));
-  const int N = c.n_arenas, S = N * c.n_ships;
+  const int S = N * M;
   PolicyWs ws;
-  int rc = policy_workspace(h, &ws);
+  int rc = policy_workspace(h, &ws, N, S);
   if (rc) return rc;
   int32_t off[64], cnt[64];
   policy_layout(off, cnt);
   const PrepLayout L = prep_layout();
 
-  // 0. observation bit maps + BN folding
-  if ((rc = ofx_launch_raster(h, OFX_MAP_BITS_LSB, nullptr, nullptr))) return rc;
+  // 0. BN folding, phase weights, tables
   PrepParams pp;
   pp.w = weights; pp.prep = ws.prep;
   OFX_HIP(hipMemsetAsync(ws.prep + L.total - 64, 0, 64 * sizeof(float), h->stream));
@@ -1813,8 +1837,9 @@ extern "C" int ofx_policy_forward(ofx_handle *h, const float *weights, const uin
   ConvParams cp;
   memset(&cp, 0, sizeof(cp));
   { const char *e = getenv("OFX_CONV_ABLATE"); cp.ablate = e ? atoi(e) : 0; }
-  cp.bits[0] = (const unsigned *)h->maps[OFX_MAP_BITS_LSB][0];
-  cp.bits[1] = (const unsigned *)h->maps[OFX_MAP_BITS_LSB][1];
+  cp.bits[0] = bits0;
+  cp.bits[1] = bits1;
+  cp.bits_stride = bits_stride;
   // opt-in: pays off on sparse scenes only (measured: with policy-driven play the maps are full of lasers
   // and the window checks cost more than they save)
   const bool bgskip = getenv("OFX_POLICY_BG_SKIP") != nullptr;
@@ -1858,7 +1883,7 @@ extern "C" int ofx_policy_forward(ofx_handle *h, const float *weights, const uin
     OFX_HIP(hipGetLastError());
   }
   HeadParams hp;
-  hp.N = N; hp.M = c.n_ships; hp.st = h->st; hp.g1 = ws.g1; hp.g1_chunks = kDense1Chunks;
+  hp.N = N; hp.M = M; hp.st = h->st; hp.vec8 = vec8; hp.g1 = ws.g1; hp.g1_chunks = kDense1Chunks;
   hp.k1 = k1; hp.b1 = weights + off[t_d1 + 1];
   hp.k2 = weights + off[t_d2]; hp.b2 = weights + off[t_d2 + 1];
   hp.k3 = weights + off[t_o1]; hp.b3 = weights + off[t_o1 + 1];
@@ -1887,7 +1912,7 @@ extern "C" int ofx_policy_forward(ofx_handle *h, const float *weights, const uin
     ht.w2mf = ws.prep + L.w2mf; ht.w2raw = ws.prep + L.uw[1]; ht.b2 = ws.prep + L.ub[1];
     ht.w3mf = ws.prep + L.w3mf; ht.w3raw = ws.prep + L.uw[2]; ht.b3 = ws.prep + L.ub[2];
     ht.w4eff = ws.prep + L.w4eff_c; ht.w4raw = ws.prep + L.w4raw; ht.b4 = ws.prep + L.b4; ht.efr = ws.prep + L.efr;
-    ht.mask = ship_mask; ht.best = ws.best; ht.heat = heatmap;
+    ht.mask = ship_mask; ht.best = ws.best; ht.heat = heatmap; ht.probe = probe; ht.ptr_probe = probe ? ptr_probe : nullptr;
     { const char *e = getenv("OFX_HT_ABLATE"); ht.ablate = e ? atoi(e) : 0; }
     const int pb = h->prof_base;
     if (pb >= 0 && (rc = ofx_event_record(h, pb))) return rc;
@@ -1908,7 +1933,112 @@ extern "C" int ofx_policy_forward(ofx_handle *h, const float *weights, const uin
     OFX_HIP(hipGetLastError());
   }
   hipLaunchKernelGGL(k_policy_finish, dim3((S + 255) / 256), dim3(256), 0, h->stream, S, ship_mask, ws.best,
-                     ipointer ? ipointer : ws.ipointer);
+                     ipointer ? ipointer : ws.ipointer, ptr_max);
+  OFX_HIP(hipGetLastError());
+  (void)c;
+  return OFX_OK;
+}
+
+extern "C" int ofx_policy_forward(ofx_handle *h, const float *weights, const uint8_t *ship_mask, float *act_values,
+                                  int32_t *iaction, int32_t *ipointer, float *heatmap) {
+  if (!h || !weights) { ofx_set_error("ofx_policy_forward: null argument"); return OFX_ERR_INVALID; }
+  if (!h->spawned) { ofx_set_error("You must execute analyse_battleground first."); return OFX_ERR_STATE; }
+  const ofx_config &c = h->cfg;
+  if (c.width != PS || c.height != PS) {
+    // Input((DEFAULT_WIDTH, DEFAULT_HEIGHT, 2)) is fixed at 400x400 (qlearnIA_V2.py:125)
+    ofx_set_error("ofx_policy_forward: the pointer_model takes 400x400 maps (got %d x %d)", c.width, c.height);
+    return OFX_ERR_INVALID;
+  }
+  OFX_HIP(hipSetDevice(c.device));
+  int rc = ofx_launch_raster(h, OFX_MAP_BITS_LSB, nullptr, nullptr);  // the observation as 1-bit maps
+  if (rc) return rc;
+  return policy_forward_impl(h, weights, c.n_arenas, c.n_ships, (const unsigned *)h->maps[OFX_MAP_BITS_LSB][0],
+                             (const unsigned *)h->maps[OFX_MAP_BITS_LSB][1], (size_t)(PS * PS) >> 5, nullptr, ship_mask,
+                             act_values, iaction, ipointer, heatmap, nullptr, nullptr, nullptr);
+}
+
+extern "C" int ofx_policy_forward_obs(ofx_handle *h, const float *weights, int32_t n_obs, const void *bits,
+                                      const float *vec8, float *act_values, int32_t *iaction, int32_t *ipointer,
+                                      float *ptr_max, const int32_t *probe, float *ptr_probe) {
+  if (!h || !weights || !bits || !vec8 || n_obs < 1) { ofx_set_error("ofx_policy_forward_obs: bad argument"); return OFX_ERR_INVALID; }
+  if ((probe == nullptr) != (ptr_probe == nullptr)) { ofx_set_error("ofx_policy_forward_obs: pass probe and ptr_probe together"); return OFX_ERR_INVALID; }
+  if (policy_unfused()) { ofx_set_error("ofx_policy_forward_obs: not available with OFX_POLICY_UNFUSED"); return OFX_ERR_STATE; }
+  OFX_HIP(hipSetDevice(h->cfg.device));
+  const size_t words = (size_t)(PS * PS) >> 5;
+  return policy_forward_impl(h, weights, n_obs, 1, (const unsigned *)bits, (const unsigned *)bits + words, 2 * words, vec8,
+                             nullptr, act_values, iaction, ipointer, nullptr, ptr_max, probe, ptr_probe);
+}
+
+// ---- TD targets of Trainer.replay (agents/qlearnIA_V2.py:251-270) -------------------------------------------------
+__global__ void k_dqn_unpack(int n, const ofx_transition *rows, float *vec_prev, float *vec_next, int32_t *probe) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const ofx_transition r = rows[i];
+  const bool pad = r.ship < 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    vec_prev[(size_t)i * 8 + k] = pad ? 0.f : r.head_prev[k];
+    vec_next[(size_t)i * 8 + k] = pad ? 0.f : r.head_next[k];
+  }
+  probe[2 * i] = pad ? 0 : min(max(r.px, 0), PS - 1);
+  probe[2 * i + 1] = pad ? 0 : min(max(r.py, 0), PS - 1);
+}
+
+__global__ void k_dqn_targets(int n, const ofx_transition *rows, float gamma, const float *act_prev, const float *probe_prev,
+                              const float *act_next, const float *max_next, float *q_sa, float *p_sp, float *y_act,
+                              float *y_ptr) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const ofx_transition r = rows[i];
+  if (r.ship < 0) { q_sa[i] = p_sp[i] = y_act[i] = y_ptr[i] = 0.f; return; }
+  const float live = r.done ? 0.f : 1.f;  // int(not done)
+  q_sa[i] = act_prev[2 * i + (r.iaction ? 1 : 0)];
+  p_sp[i] = probe_prev[i];
+  y_act[i] = (float)r.reward + gamma * fmaxf(act_next[2 * i], act_next[2 * i + 1]) * live;  // np.max(prediction)
+  y_ptr[i] = (float)r.reward + gamma * max_next[i] * live;                                    // np.max(ptr_prediction)
+}
+
+static int ensure_aux(ofx_handle *h, size_t bytes) {
+  if (h->aux_bytes >= bytes) return OFX_OK;
+  OFX_HIP(hipStreamSynchronize(h->stream));
+  if (h->aux) (void)hipFree(h->aux);
+  h->aux = nullptr; h->aux_bytes = 0;
+  OFX_HIP(hipMalloc(&h->aux, bytes));
+  h->aux_bytes = bytes;
+  return OFX_OK;
+}
+
+extern "C" int ofx_policy_forward_obs(ofx_handle *h, const float *weights, int32_t n_obs, const void *bits,
+                                      const float *vec8, float *act_values, int32_t *iaction, int32_t *ipointer,
+                                      float *ptr_max, const int32_t *probe, float *ptr_probe);
+
+extern "C" int ofx_dqn_targets(ofx_handle *h, const float *weights, int32_t n, const ofx_transition *rows,
+                               const void *bits_prev, const void *bits_next, float gamma, float *q_sa, float *p_sp,
+                               float *y_act, float *y_ptr) {
+  if (!h || !weights || !rows || !bits_prev || !bits_next || !q_sa || !p_sp || !y_act || !y_ptr || n < 1) {
+    ofx_set_error("ofx_dqn_targets: bad argument");
+    return OFX_ERR_INVALID;
+  }
+  OFX_HIP(hipSetDevice(h->cfg.device));
+  const size_t nn = (size_t)n;
+  int rc = ensure_aux(h, al(32 * nn) * 2 + al(8 * nn) * 3 + al(4 * nn) * 2);
+  if (rc) return rc;
+  char *b = (char *)h->aux;
+  float *vec_prev = (float *)b; b += al(32 * nn);
+  float *vec_next = (float *)b; b += al(32 * nn);
+  int32_t *probe = (int32_t *)b; b += al(8 * nn);
+  float *act_prev = (float *)b; b += al(8 * nn);
+  float *act_next = (float *)b; b += al(8 * nn);
+  float *probe_prev = (float *)b; b += al(4 * nn);
+  float *max_next = (float *)b;
+  hipLaunchKernelGGL(k_dqn_unpack, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, rows, vec_prev, vec_next, probe);
+  OFX_HIP(hipGetLastError());
+  if ((rc = ofx_policy_forward_obs(h, weights, n, bits_prev, vec_prev, act_prev, nullptr, nullptr, nullptr, probe, probe_prev)))
+    return rc;
+  if ((rc = ofx_policy_forward_obs(h, weights, n, bits_next, vec_next, act_next, nullptr, nullptr, max_next, nullptr, nullptr)))
+    return rc;
+  hipLaunchKernelGGL(k_dqn_targets, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, rows, gamma, act_prev, probe_prev,
+                     act_next, max_next, q_sa, p_sp, y_act, y_ptr);
   OFX_HIP(hipGetLastError());
   return OFX_OK;
 }
@@ -1916,7 +2046,7 @@ extern "C" int ofx_policy_forward(ofx_handle *h, const float *weights, const uin
 // (iaction, ipointer) of the last forward / explore, for the other translation units (ofx_replay.hip)
 int ofx_policy_results(ofx_handle *h, int32_t **iaction, int32_t **ipointer) {
   PolicyWs ws;
-  int rc = policy_workspace(h, &ws);
+  int rc = policy_workspace(h, &ws, h->cfg.n_arenas, (size_t)h->cfg.n_arenas * h->cfg.n_ships);
   if (rc) return rc;
   *iaction = ws.iaction;
   *ipointer = ws.ipointer;
@@ -1947,7 +2077,7 @@ extern "C" int ofx_policy_explore(ofx_handle *h, double epsilon, uint64_t seed, 
   OFX_HIP(hipSetDevice(h->cfg.device));
   if (!iaction || !ipointer) {
     PolicyWs ws;
-    int rc = policy_workspace(h, &ws);
+    int rc = policy_workspace(h, &ws, h->cfg.n_arenas, (size_t)h->cfg.n_arenas * h->cfg.n_ships);
     if (rc) return rc;
     if (!iaction) iaction = ws.iaction;
     if (!ipointer) ipointer = ws.ipointer;
@@ -1968,7 +2098,7 @@ extern "C" int ofx_policy_actions(ofx_handle *h, const int32_t *iaction, const i
   const int S = h->cfg.n_arenas * h->cfg.n_ships;
   if (!iaction || !ipointer) {  // use the results the last ofx_policy_forward kept in the workspace
     PolicyWs ws;
-    int rc = policy_workspace(h, &ws);
+    int rc = policy_workspace(h, &ws, h->cfg.n_arenas, (size_t)h->cfg.n_arenas * h->cfg.n_ships);
     if (rc) return rc;
     if (!iaction) iaction = ws.iaction;
     if (!ipointer) ipointer = ws.ipointer;

@@ -369,6 +369,38 @@ class ArenaBatch:
             out += [bp.download(np.uint32, (self.N, batch, 2, words)), bn.download(np.uint32, (self.N, batch, 2, words))]
         return out
 
+    def replay_gather_device(self, slot, batch):
+        """Like replay_gather but the minibatch stays in HBM: (rows, bits_prev, bits_next) DeviceBuffers."""
+        rows = DeviceBuffer(self.N * batch * self.TRANSITION_DTYPE.itemsize)
+        words = self.W * self.H // 32
+        bp, bn = DeviceBuffer(4 * self.N * batch * 2 * words), DeviceBuffer(4 * self.N * batch * 2 * words)
+        nat.check(nat.lib().ofx_replay_gather(self._h, slot.ptr, int(batch), rows.ptr, bp.ptr, bn.ptr))
+        return rows, bp, bn
+
+    def policy_forward_obs(self, weights_ptr, n_obs, bits_ptr, vec8_ptr, want_probe_ptr=None):
+        """Forward on stored observations (Trainer.replay's predictions): host dict of act / iaction / ipointer /
+        ptr_max (+ ptr_probe when want_probe_ptr, an int32 [n_obs][2] device array of (x, y), is given)."""
+        n = int(n_obs)
+        act, ia, ip, pm = DeviceBuffer(8 * n), DeviceBuffer(4 * n), DeviceBuffer(8 * n), DeviceBuffer(4 * n)
+        pp = DeviceBuffer(4 * n) if want_probe_ptr else None
+        nat.check(nat.lib().ofx_policy_forward_obs(self._h, weights_ptr, n, bits_ptr, vec8_ptr, act.ptr, ia.ptr, ip.ptr,
+                                                    pm.ptr, want_probe_ptr, pp.ptr if pp else None))
+        self.sync()
+        out = {"act": act.download(np.float32, (n, 2)), "iaction": ia.download(np.int32, (n,)),
+               "ipointer": ip.download(np.int32, (n, 2)), "ptr_max": pm.download(np.float32, (n,))}
+        if pp:
+            out["ptr_probe"] = pp.download(np.float32, (n,))
+        return out
+
+    def dqn_targets(self, weights_ptr, n, rows_ptr, bits_prev_ptr, bits_next_ptr, gamma=0.9):
+        """Trainer.replay's targets (qlearnIA_V2.py:251-270; gamma = 0.9, :51): host arrays q_sa, p_sp, y_act, y_ptr."""
+        n = int(n)
+        bufs = [DeviceBuffer(4 * n) for _ in range(4)]
+        nat.check(nat.lib().ofx_dqn_targets(self._h, weights_ptr, n, rows_ptr, bits_prev_ptr, bits_next_ptr, float(gamma),
+                                             *[b.ptr for b in bufs]))
+        self.sync()
+        return tuple(b.download(np.float32, (n,)) for b in bufs)
+
     def policy_explore(self, epsilon, seed, tick=None, collecting=False, ship_mask_ptr=None, iaction_ptr=None,
                        ipointer_ptr=None):
         """epsilon-greedy / collecting-phase random play over the last forward's results."""

@@ -209,3 +209,75 @@ def test_replay_errors():
     with pytest.raises(Exception, match="capacity must be > 0"):
         b.replay_create(0)
     b.close()
+
+
+@pytest.mark.gpu
+def test_dqn_targets_vs_oracle():
+    """Replay memory -> sample -> gather -> ofx_dqn_targets (two forwards on the stored observations + the TD
+    arithmetic of Trainer.replay, qlearnIA_V2.py:251-270) against the CPU restatement of the policy forward run on
+    the unpacked frames.  Also checks ofx_policy_forward_obs on live observations against ofx_policy_forward."""
+    from ofighters_amd import ArenaBatch, DeviceBuffer, _native as nat
+    N, M, seed, cap, batch, gamma = 8, 5, 0x0F160001, 40, 3, 0.9
+    b = ArenaBatch(N, M)
+    b.replay_create(cap, 0)
+    b.spawn_random(seed)
+    w, _ = pyoracle.policy_init(6, trained_like=True)
+    dw = DeviceBuffer(w.nbytes).upload(w)
+    mask = np.zeros((N, M), np.uint8)
+    mask[:, [1, 3]] = 1
+    mask_d = DeviceBuffer(mask.nbytes).upload(mask)
+    ia_d, ip_d = DeviceBuffer(4 * N * M), DeviceBuffer(8 * N * M)
+    for t in range(45):
+        b.bot_actions(["random"] * M, seed, tick=t)
+        b.policy_explore(1.0, seed, tick=t, collecting=True, ship_mask_ptr=mask_d.ptr, iaction_ptr=ia_d.ptr,
+                         ipointer_ptr=ip_d.ptr)
+        b.policy_actions(out_ptr=b._actions.ptr, ship_mask_ptr=mask_d.ptr, iaction_ptr=ia_d.ptr, ipointer_ptr=ip_d.ptr)
+        b.replay_capture(t, mask_d.ptr, ia_d.ptr, ip_d.ptr)
+        b.step(actions_ptr=b._actions.ptr)
+    slot, _ = b.replay_sample(0x0F160003, 0, batch)
+    rows_d, bp_d, bn_d = b.replay_gather_device(slot, batch)
+    n = N * batch
+    q_sa, p_sp, y_act, y_ptr = b.dqn_targets(dw.ptr, n, rows_d.ptr, bp_d.ptr, bn_d.ptr, gamma)
+    rows = rows_d.download(b.TRANSITION_DTYPE, (n,))
+    bp = bp_d.download(np.uint32, (n, 2, 5000))
+    bn = bn_d.download(np.uint32, (n, 2, 5000))
+    assert (rows["ship"] >= 0).sum() >= 10
+    unpack = lambda x: np.unpackbits(x.view(np.uint8), bitorder="little").reshape(2, 400, 400)
+    checked = 0
+    for i in range(0, n, 3):
+        r = rows[i]
+        if r["ship"] < 0:
+            assert q_sa[i] == p_sp[i] == y_act[i] == y_ptr[i] == 0
+            continue
+        m0, m1 = unpack(bp[i]), unpack(bn[i])
+        act0, heat0, _, _ = pyoracle.policy_forward(m0[0], m0[1], r["head_prev"], w)
+        act1, heat1, _, _ = pyoracle.policy_forward(m1[0], m1[1], r["head_next"], w)
+        live = 0.0 if r["done"] else 1.0
+        tol_a = 2e-4 * max(1.0, float(np.abs(act0).max()), float(np.abs(act1).max()))
+        tol_h = 2e-4 * max(float(np.abs(heat0).max()), float(np.abs(heat1).max()))
+        assert abs(q_sa[i] - act0[r["iaction"]]) <= tol_a
+        assert abs(p_sp[i] - heat0[r["py"], r["px"]]) <= tol_h
+        assert abs(y_act[i] - (r["reward"] + gamma * act1.max() * live)) <= tol_a
+        assert abs(y_ptr[i] - (r["reward"] + gamma * heat1.max() * live)) <= tol_h
+        checked += 1
+    assert checked >= 4
+    # forward_obs on the live observation == the arena forward (same kernels, one trunk run per observation)
+    full = b.policy_forward_host(w)
+    b.rasterise(nat.MAP_BITS)
+    head, _ = b.observe_head()
+    sm, lm = b.maps_host(nat.MAP_U8)
+    pick = [(0, 1), (3, 3), (7, 0)]
+    bits = np.stack([np.stack([np.packbits(sm[g].ravel(), bitorder="little"), np.packbits(lm[g].ravel(), bitorder="little")])
+                     for g, _ in pick]).view(np.uint32)
+    vec = np.stack([head[g, i] for g, i in pick]).astype(np.float32)
+    probe = np.array([[full["ipointer"][g, i][0], full["ipointer"][g, i][1]] for g, i in pick], np.int32)
+    b.sync()
+    bits_d = DeviceBuffer(bits.nbytes).upload(bits)
+    vec_d = DeviceBuffer(vec.nbytes).upload(vec)
+    probe_d = DeviceBuffer(probe.nbytes).upload(probe)
+    o = b.policy_forward_obs(dw.ptr, len(pick), bits_d.ptr, vec_d.ptr, probe_d.ptr)
+    for k, (g, i) in enumerate(pick):
+        assert np.array_equal(o["act"][k], full["act"][g, i]) and o["iaction"][k] == full["iaction"][g, i]
+        assert tuple(o["ipointer"][k]) == tuple(full["ipointer"][g, i])
+        assert o["ptr_probe"][k] == o["ptr_max"][k]          # the probe sits on the arg-max
+    b.close()
