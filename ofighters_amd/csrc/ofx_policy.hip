@@ -208,7 +208,8 @@ __global__ void k_policy_prepare(PrepParams p) {
     for (int e = tid; e < 2 * 512 * 8; e += blockDim.x) {
       const int co = e & 7, pat = (e >> 3) & 511, ci = e >> 12;
       const float inv = g[co] / sqrtf(g[3 * 8 + co] + 1e-3f);
-      float acc = 0.f;
+      // the folded bias rides in the table of channel 0: out = LUT[0][pattern0] + LUT[1][pattern1]
+      float acc = ci == 0 ? p.w[p.src_b[0] + co] * inv + (g[8 + co] - g[2 * 8 + co] * inv) : 0.f;
       for (int tap = 0; tap < 9; tap++)
         if ((pat >> tap) & 1) acc += p.w[p.src_k[0] + (tap * 2 + ci) * 8 + co] * inv;
       p.prep[p.dst_lut1 + e] = acc;
@@ -819,17 +820,11 @@ __global__ __launch_bounds__(256) void k_conv1_lut(ConvParams p, const float *lu
     rows[ci][r][w] = out;
   }
   __syncthreads();
-  float bias[8];
-#pragma unroll
-  for (int co = 0; co < 8; co++) bias[co] = p.b[co];
+  float *const obase = p.out + ((size_t)img * 8 * (H / 2) + (ty0 >> 1)) * W2;  // wave-uniform: scalar base + 32-bit offsets
   for (int px = tid; px < NPX; px += 256) {
     const int py = px / W2, pxx = px - py * W2;                   // pooled pixel of the tile
     const int x0 = 2 * pxx;                                       // window = staged bits x0 .. x0 + 3 of rows 2 py .. 2 py + 3
-    float acc[4][8];
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-#pragma unroll
-      for (int co = 0; co < 8; co++) acc[q][co] = bias[co];
+    f32x4 acc[4][2];                                              // [2x2 pixel][channels 0-3 | 4-7]
 #pragma unroll
     for (int ci = 0; ci < 2; ci++) {
       unsigned f[4];
@@ -842,19 +837,18 @@ __global__ __launch_bounds__(256) void k_conv1_lut(ConvParams p, const float *lu
       for (int q = 0; q < 4; q++) {
         const int dy = q >> 1, dx = q & 1;
         const unsigned pat = ((f[dy] >> dx) & 7u) | (((f[dy + 1] >> dx) & 7u) << 3) | (((f[dy + 2] >> dx) & 7u) << 6);
-        const float4 *e = reinterpret_cast<const float4 *>(&slut[(ci * 512 + pat) * 8]);
-        const float4 a = e[0], b = e[1];
-        acc[q][0] += a.x; acc[q][1] += a.y; acc[q][2] += a.z; acc[q][3] += a.w;
-        acc[q][4] += b.x; acc[q][5] += b.y; acc[q][6] += b.z; acc[q][7] += b.w;
+        const f32x4 *e = reinterpret_cast<const f32x4 *>(&slut[(ci * 512 + pat) * 8]);
+        if (ci == 0) { acc[q][0] = e[0]; acc[q][1] = e[1]; }      // the table of channel 0 carries the bias
+        else { acc[q][0] += e[0]; acc[q][1] += e[1]; }
       }
     }
-    float *op = p.out + (((size_t)img * 8) * (H / 2) + (ty0 >> 1) + py) * W2 + pxx;
+    const unsigned off = (unsigned)(py * W2 + pxx);
 #pragma unroll
     for (int co = 0; co < 8; co++) {
       float m;
-      asm("v_max3_f32 %0, %1, %2, 0" : "=v"(m) : "v"(acc[0][co]), "v"(acc[1][co]));
-      asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(acc[2][co]), "v"(acc[3][co]), "v"(m));
-      if (!(p.ablate & 4)) op[(size_t)co * (H / 2) * W2] = m;
+      asm("v_max3_f32 %0, %1, %2, 0" : "=v"(m) : "v"(acc[0][co >> 2][co & 3]), "v"(acc[1][co >> 2][co & 3]));
+      asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(acc[2][co >> 2][co & 3]), "v"(acc[3][co >> 2][co & 3]), "v"(m));
+      if (!(p.ablate & 4)) (obase + (size_t)co * (H / 2) * W2)[off] = m;
     }
   }
 }
@@ -1853,7 +1847,7 @@ static int policy_forward_impl(ofx_handle *h, const float *weights, int N, int M
   else if (getenv("OFX_CONV1_MFMA")) rc = launch_convm<2, 8, 13, 1, false, 1>(h, cp, N, 400);  // A/B: the GEMM form
   else {
     cp.H = 400; cp.W = 400;
-    hipLaunchKernelGGL(k_conv1_lut<20>, dim3((unsigned)(N * (400 / 20))), dim3(256), 0, h->stream, cp,
+    hipLaunchKernelGGL(k_conv1_lut<40>, dim3((unsigned)(N * (400 / 40))), dim3(256), 0, h->stream, cp,
                        (const float *)(ws.prep + L.lut1));
     OFX_HIP(hipGetLastError());
   }
