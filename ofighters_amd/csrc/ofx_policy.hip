@@ -1855,7 +1855,7 @@ static int policy_forward_impl(ofx_handle *h, const float *weights, int N, int M
   cp.in = ws.p1; cp.w = ws.prep + L.tw[1]; cp.b = ws.prep + L.tb[1]; cp.out = ws.p2; cp.wbm = ws.prep + L.wbm[0];
   if (bgskip) { cp.bg_in = ws.prep + L.bg[0]; cp.bg_out = ws.prep + L.bg[1]; }
   if (trunk_valu) rc = launch_conv<8, 8, 10, 100, 0, true, false>(h, cp, N, 200);
-  else rc = launch_convm<8, 4, 13, 0, false, 1>(h, cp, N, 200);
+  else rc = launch_convm<8, 2, 13, 0, false, 1>(h, cp, N, 200);  // 29 KB of LDS: five workgroups per CU
   if (rc) return rc;
   cp.in = ws.p2; cp.w = ws.prep + L.tw[2]; cp.b = ws.prep + L.tb[2]; cp.out = ws.p3; cp.wbm = ws.prep + L.wbm[1];
   if (bgskip) { cp.bg_in = ws.prep + L.bg[1]; cp.bg_out = ws.prep + L.bg[2]; }
