@@ -108,6 +108,7 @@ struct PrepParams {
   int src_k[7], src_b[7], src_g[7], cin[7], cout[7], dst_w[7], dst_b[7];
   int src_k4, src_b4, dst_w4eff, dst_w4raw, dst_b4, dst_efr;
   int dst_w4eff_c, dst_w3mf, dst_w2mf, dst_lut1, dst_wbm[3];
+  int phase;
   int dst_bg[4];
 };
 
@@ -121,23 +122,27 @@ __device__ inline float up_coef(int a, int dy, int t) {
   return a ? c1[dy][t] : c0[dy][t];
 }
 
+// Two launches: phase 0 (many workgroups) folds and builds every table that depends on the raw weights only; phase 1
+// builds what needs the folded kernels (k_convm's per-lane B operands, the background chain).
 __global__ void k_policy_prepare(PrepParams p) {
-  const int tid = threadIdx.x;
+  const int ltid = threadIdx.x;
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nthr = gridDim.x * blockDim.x;
+  if (p.phase == 0) {
   for (int l = 0; l < 7; l++) {  // BN fold: y = (conv + b) * inv + (beta - mean * inv)
     const int cin = p.cin[l], cout = p.cout[l];
     const float *g = p.w + p.src_g[l];  // gamma, beta, mean, var consecutive, each [cout]
-    for (int e = tid; e < 9 * cin * cout; e += blockDim.x) {
+    for (int e = tid; e < 9 * cin * cout; e += nthr) {
       const int co = e % cout;
       const float inv = g[co] / sqrtf(g[3 * cout + co] + 1e-3f);
       p.prep[p.dst_w[l] + e] = p.w[p.src_k[l] + e] * inv;
     }
-    for (int co = tid; co < cout; co += blockDim.x) {
+    for (int co = tid; co < cout; co += nthr) {
       const float inv = g[co] / sqrtf(g[3 * cout + co] + 1e-3f);
       p.prep[p.dst_b[l] + co] = p.w[p.src_b[l] + co] * inv + (g[cout + co] - g[2 * cout + co] * inv);
     }
   }
   // upconv4 (linear, no BN): effective weights of the 4 output phases on the low-res grid
-  for (int e = tid; e < 4 * 9 * 8; e += blockDim.x) {
+  for (int e = tid; e < 4 * 9 * 8; e += nthr) {
     const int ci = e % 8, tap = (e / 8) % 9, ph = e / 72;
     const int a = ph >> 1, b = ph & 1, ty = tap / 3, tx = tap % 3;
     float acc = 0.f;
@@ -147,10 +152,10 @@ __global__ void k_policy_prepare(PrepParams p) {
     p.prep[p.dst_w4eff + e] = acc;
     p.prep[p.dst_w4eff_c + (ci * 4 + ph) * 9 + tap] = acc;
   }
-  for (int e = tid; e < 72; e += blockDim.x) p.prep[p.dst_w4raw + e] = p.w[p.src_k4 + e];
+  for (int e = tid; e < 72; e += nthr) p.prep[p.dst_w4raw + e] = p.w[p.src_k4 + e];
   // frame pixels of the heat map: the conv taps of the row (column) outside the image, in phase form along the
   // line: pixel 2j + b of the line gets sum_o E[b][o] L[j + o - 1] of the low-res frame row (column) L
-  for (int e = tid; e < 2 * 2 * 2 * 3 * 8; e += blockDim.x) {
+  for (int e = tid; e < 2 * 2 * 2 * 3 * 8; e += nthr) {
     const int ci = e % 8, o = (e / 8) % 3, b = (e / 24) % 2, side = (e / 48) % 2, isv = e / 96;
     float acc = 0.f;
     for (int d = 0; d < 3; d++) {
@@ -162,34 +167,12 @@ __global__ void k_policy_prepare(PrepParams p) {
   // background chain of the trunk: an all-empty window (input 0) gives relu(b1') after layer 1, a window of that
   // constant gives a constant after layer 2, ... -- same fma order (ci outer, tap inner) as the conv kernels, so
   // the skipped waves write bit-identical values
-  __syncthreads();
-  // k_convm's B operand for the 8 -> 8 layers, exactly as lane (n = (co, r), kq) of MFMA step j wants it:
-  // B[k = 4 j + kq][(co, r)] = w[row - r][dx][ci][co] for k = (row * 3 + dx) * 8 + ci inside the 3-row window, else 0
-  for (int l = 1; l < 4; l++)
-    for (int e = tid; e < 24 * 64; e += blockDim.x) {
-      const int lane = e & 63, j = e >> 6, n16 = lane & 15, kq = lane >> 4, co = n16 >> 1, r = n16 & 1;
-      const int k = 4 * j + kq, rd = k >> 3, ci = k & 7, row = rd / 3, dx = rd - row * 3, tr = row - r;
-      p.prep[p.dst_wbm[l - 1] + e] = (tr >= 0 && tr < 3) ? p.prep[p.dst_w[l] + ((tr * 3 + dx) * 8 + ci) * 8 + co] : 0.f;
-    }
-  if (tid < 8) {
-    float bgv[8];
-    for (int ci = 0; ci < 8; ci++) bgv[ci] = 0.f;
-    for (int l = 0; l < 4; l++) {
-      const int cin = p.cin[l];
-      float acc = 0.f;
-      for (int ci = 0; ci < cin; ci++)
-        for (int tap = 0; tap < 9; tap++) acc = __builtin_fmaf(bgv[ci], p.prep[p.dst_w[l] + (tap * cin + ci) * 8 + tid], acc);
-      const float o = fmaxf(acc + p.prep[p.dst_b[l] + tid], 0.f);
-      p.prep[p.dst_bg[l] + tid] = o;
-      for (int ci = 0; ci < 8; ci++) bgv[ci] = __shfl(o, ci, 8);
-    }
-  }
   // upconv3 (layer index 6): phase weights from the BN-folded kernel (folded in place, same thread order
   // would race with the fold above: recompute the fold here)
   {
     const int cout = 8, cin = 4;
     const float *g = p.w + p.src_g[6];
-    for (int e = tid; e < 4 * 9 * cin * cout; e += blockDim.x) {
+    for (int e = tid; e < 4 * 9 * cin * cout; e += nthr) {
       const int co = e % cout, ci = (e / cout) % cin, tap = (e / (cout * cin)) % 9, ph = e / (cout * cin * 9);
       const int a = ph >> 1, b = ph & 1, ty = tap / 3, tx = tap % 3;
       const float inv = g[co] / sqrtf(g[3 * cout + co] + 1e-3f);
@@ -205,7 +188,7 @@ __global__ void k_policy_prepare(PrepParams p) {
   // (dy*3 + dx) of the pattern <-> tap (dy, dx), taps summed in tap order.
   {
     const float *g = p.w + p.src_g[0];
-    for (int e = tid; e < 2 * 512 * 8; e += blockDim.x) {
+    for (int e = tid; e < 2 * 512 * 8; e += nthr) {
       const int co = e & 7, pat = (e >> 3) & 511, ci = e >> 12;
       const float inv = g[co] / sqrtf(g[3 * 8 + co] + 1e-3f);
       // the folded bias rides in the table of channel 0: out = LUT[0][pattern0] + LUT[1][pattern1]
@@ -219,7 +202,7 @@ __global__ void k_policy_prepare(PrepParams p) {
   {
     const int cout = 4, cin = 2;
     const float *g = p.w + p.src_g[5];
-    for (int e = tid; e < 20 * 16; e += blockDim.x) {
+    for (int e = tid; e < 20 * 16; e += nthr) {
       const int n = e % 16, k = e / 16, co = n & 3, ph = n >> 2, ci = k & 1, tap = k >> 1;
       float acc = 0.f;
       if (k < 18) {
@@ -233,6 +216,30 @@ __global__ void k_policy_prepare(PrepParams p) {
     }
   }
   if (tid == 0) p.prep[p.dst_b4] = p.w[p.src_b4];
+  } else {
+  // k_convm's B operand for the 8 -> 8 layers, exactly as lane (n = (co, r), kq) of MFMA step j wants it:
+  // B[k = 4 j + kq][(co, r)] = w[row - r][dx][ci][co] for k = (row * 3 + dx) * 8 + ci inside the 3-row window, else 0
+  for (int l = 1; l < 4; l++)
+    for (int e = tid; e < 24 * 64; e += nthr) {
+      const int lane = e & 63, j = e >> 6, n16 = lane & 15, kq = lane >> 4, co = n16 >> 1, r = n16 & 1;
+      const int k = 4 * j + kq, rd = k >> 3, ci = k & 7, row = rd / 3, dx = rd - row * 3, tr = row - r;
+      p.prep[p.dst_wbm[l - 1] + e] = (tr >= 0 && tr < 3) ? p.prep[p.dst_w[l] + ((tr * 3 + dx) * 8 + ci) * 8 + co] : 0.f;
+    }
+  if (blockIdx.x == 0 && ltid < 8) {
+    const int tid = ltid;
+    float bgv[8];
+    for (int ci = 0; ci < 8; ci++) bgv[ci] = 0.f;
+    for (int l = 0; l < 4; l++) {
+      const int cin = p.cin[l];
+      float acc = 0.f;
+      for (int ci = 0; ci < cin; ci++)
+        for (int tap = 0; tap < 9; tap++) acc = __builtin_fmaf(bgv[ci], p.prep[p.dst_w[l] + (tap * cin + ci) * 8 + tid], acc);
+      const float o = fmaxf(acc + p.prep[p.dst_b[l] + tid], 0.f);
+      p.prep[p.dst_bg[l] + tid] = o;
+      for (int ci = 0; ci < 8; ci++) bgv[ci] = __shfl(o, ci, 8);
+    }
+  }
+  }
 }
 
 // ---- generic direct 3x3 convolution ------------------------------------------------
@@ -1824,7 +1831,10 @@ static int policy_forward_impl(ofx_handle *h, const float *weights, int N, int M
   pp.dst_w4eff_c = L.w4eff_c; pp.dst_w3mf = L.w3mf; pp.dst_w2mf = L.w2mf; pp.dst_lut1 = L.lut1;
   for (int i = 0; i < 3; i++) pp.dst_wbm[i] = L.wbm[i];
   for (int i = 0; i < 4; i++) pp.dst_bg[i] = L.bg[i];
-  hipLaunchKernelGGL(k_policy_prepare, dim3(1), dim3(256), 0, h->stream, pp);
+  pp.phase = 0;
+  hipLaunchKernelGGL(k_policy_prepare, dim3(32), dim3(256), 0, h->stream, pp);
+  pp.phase = 1;
+  hipLaunchKernelGGL(k_policy_prepare, dim3(4), dim3(256), 0, h->stream, pp);
   OFX_HIP(hipGetLastError());
 
   // 1. trunk, once per arena
