@@ -281,3 +281,44 @@ def test_dqn_targets_vs_oracle():
         assert tuple(o["ipointer"][k]) == tuple(full["ipointer"][g, i])
         assert o["ptr_probe"][k] == o["ptr_max"][k]          # the probe sits on the arg-max
     b.close()
+
+
+@pytest.mark.gpu
+def test_replay_partial_restart_and_small_capacity():
+    """ofx_restart with an arena mask resets previous_* / the done latch of the masked arenas only (QlearnIA.reset per
+    restarted Battleground); capacity 3 keeps the last 3 rows; M = 64 ships fill a whole wave."""
+    from ofighters_amd import ArenaBatch, DeviceBuffer
+    N, M, seed = 3, 64, 5
+    b = ArenaBatch(N, M)
+    b.replay_create(3, 8)
+    b.spawn_random(seed)
+    mask = np.zeros((N, M), np.uint8)
+    mask[:, 0] = 1                                   # one capturing ship per arena
+    mask_d = DeviceBuffer(mask.nbytes).upload(mask)
+    ia = np.zeros((N, M), np.int32)
+    ip = np.zeros((N, M, 2), np.int32)
+    ia_d, ip_d = DeviceBuffer(ia.nbytes), DeviceBuffer(ip.nbytes)
+
+    def tick(t):
+        ia[:, 0], ip[:, 0, 0], ip[:, 0, 1] = t % 2, 10 + t, 20 + t
+        b.sync()
+        ia_d.upload(ia), ip_d.upload(ip)
+        b.bot_actions(["idle"] * M, seed, tick=t)    # nobody moves or shoots: nobody dies
+        b.replay_capture(t, mask_d.ptr, ia_d.ptr, ip_d.ptr)
+        b.step(actions_ptr=b._actions.ptr)
+
+    for t in range(3):
+        tick(t)
+    cnt, app = b.replay_count()
+    assert list(app) == [2, 2, 2]                    # transitions 0->1, 1->2
+    b.restart(np.full((N, M, 2), 7, np.int32), arena_mask=[0, 1, 0])     # only arena 1 starts a new episode
+    for t in range(3, 6):
+        tick(t)
+    cnt, app = b.replay_count()
+    assert list(app) == [5, 4, 5] and list(cnt) == [3, 3, 3]             # arena 1 has no row across its restart
+    r0, r1 = b.replay_rows(0), b.replay_rows(1)
+    assert [(r["tick_prev"], r["tick_next"]) for r in r0] == [(2, 3), (3, 4), (4, 5)]
+    assert [(r["tick_prev"], r["tick_next"]) for r in r1] == [(1, 2), (3, 4), (4, 5)]
+    assert [(r["iaction"], r["px"], r["py"]) for r in r0] == [(0, 12, 22), (1, 13, 23), (0, 14, 24)]   # previous_* of tick_prev
+    assert all(r["ship"] == 0 and r["done"] == 0 for r in r0)
+    b.close()
