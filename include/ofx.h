@@ -344,6 +344,18 @@ int ofx_policy_forward_obs(ofx_handle *h, const float *weights, int32_t n_obs, c
 int ofx_dqn_targets(ofx_handle *h, const float *weights, int32_t n, const ofx_transition *rows, const void *bits_prev,
                     const void *bits_next, float gamma, float *q_sa, float *p_sp, float *y_act, float *y_ptr);
 
+/* One fit step of Trainer.replay (model.fit, agents/qlearnIA_V2.py:284; loss 'mse' on both heads, Adam(lr) :190) on n
+ * gathered transitions: forward in training mode (BatchNorm on the batch statistics, moving statistics updated with
+ * momentum 0.99 like Keras), targets = the current predictions except target[iaction] = y_act[i] and
+ * ptr_target at the pointer = y_ptr[i] (from ofx_dqn_targets), backward, Adam (beta 0.9 / 0.999, eps 1e-7, `step`
+ * 1-based).  weights / adam_m / adam_v: device float32 [n_floats] in the ofx_policy_layout order, updated in place;
+ * grad_out (device, may be NULL) receives the gradient; loss_host[2] = the two mse terms.  Inputs are the
+ * transitions' `state` observations and the pointer addresses heat[y][x] (the reference fits on next_state's inputs
+ * and indexes [x][y], :280-283: stated, not reproduced).  Reference-quality kernels, not the hot path; synchronises. */
+int ofx_dqn_fit(ofx_handle *h, float *weights, float *adam_m, float *adam_v, int32_t step, float lr, int32_t n,
+                const ofx_transition *rows, const void *bits_prev, const float *y_act, const float *y_ptr,
+                float *grad_out, float *loss_host);
+
 /* ---- timing helpers (HIP events on the handle's stream) ---------------- */
 int ofx_timer_start(ofx_handle *h);
 int ofx_timer_stop(ofx_handle *h, float *ms_host); /* synchronises */

@@ -101,6 +101,7 @@ SIGNATURES = {
     "ofx_policy_explore": (_i, [_vp, C.c_double, _u64, _u32, C.c_int32, _vp, _vp, _vp]),
     "ofx_policy_forward_obs": (_i, [_vp, _vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ofx_dqn_targets": (_i, [_vp, _vp, C.c_int32, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp]),
+    "ofx_dqn_fit": (_i, [_vp, _vp, _vp, _vp, C.c_int32, C.c_float, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ofx_replay_create": (_i, [_vp, C.c_int32, C.c_int32]),
     "ofx_replay_destroy": (_i, [_vp]),
     "ofx_replay_capture": (_i, [_vp, _u32, _vp, _vp, _vp]),

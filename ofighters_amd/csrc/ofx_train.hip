@@ -1,0 +1,500 @@
+// ofx_train.hip - one DQN fit step of the bi-head pointer_model: the model.fit call of
+// Trainer.replay (agents/qlearnIA_V2.py:284; model.compile(loss='mse', optimizer=Adam(lr)) :190).
+//
+// Straightforward reference-quality kernels (one thread per output element, plain loops, fp32): this path runs once
+// per 50 environment steps on a minibatch, it is not the hot path and is NOT tuned - correctness first (checked
+// against torch autograd, tests/test_train.py).  Keras semantics assumed (parity unpinned: no keras in the image):
+//   * fit runs the graph in training mode: BatchNorm normalises with the batch mean / biased variance (eps 1e-3) and
+//     moves the stored statistics: moving = 0.99 moving + 0.01 batch;
+//   * loss = mse(output1) + mse(output2), each the mean over the batch and the output elements;
+//   * the targets equal the current predictions except target[iaction] = y_act and ptr_target[pointer] = y_ptr
+//     (qlearnIA_V2.py:279-280), i.e. one non-zero error per head and sample.  The pointer addresses heat[y][x] and
+//     the inputs are the transitions' `state` observations (the reference's [x][y] indexing and its use of
+//     next_state as input, :280-283, are stated in include/ofx.h, not reproduced);
+//   * Adam: beta1 0.9, beta2 0.999, eps 1e-7, bias-corrected step size.
+#include "ofx_internal.h"
+#include <string.h>
+
+#define TPS 400
+
+// ---------------------------------------------------------------- elementwise / layout kernels
+__global__ void t_bits_to_f32(int n, const uint32_t *bits, float *x) {  // bits [n][2][5000] -> x [n][2][400][400]
+  const size_t total = (size_t)n * 2 * TPS * TPS;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const size_t img = e / (TPS * TPS), p = e - img * (TPS * TPS);
+    x[e] = (float)((bits[img * ((TPS * TPS) >> 5) + (p >> 5)] >> (p & 31)) & 1u);
+  }
+}
+
+// z[n][co][H][W] = conv3x3(x[n][ci][H][W], w HWIO [3][3][ci][co]) + b[co], zero padding
+__global__ void t_conv_fwd(int n, int ci_n, int co_n, int H, int W, const float *x, const float *w, const float *b, float *z) {
+  const size_t total = (size_t)n * co_n * H * W;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int xx = e % W, yy = (e / W) % H, co = (e / ((size_t)W * H)) % co_n, s = e / ((size_t)W * H * co_n);
+    float acc = b[co];
+    for (int ci = 0; ci < ci_n; ci++) {
+      const float *xp = x + ((size_t)s * ci_n + ci) * H * W;
+      for (int ky = 0; ky < 3; ky++) {
+        const int y = yy + ky - 1;
+        if (y < 0 || y >= H) continue;
+        for (int kx = 0; kx < 3; kx++) {
+          const int xq = xx + kx - 1;
+          if (xq < 0 || xq >= W) continue;
+          acc += xp[(size_t)y * W + xq] * w[((ky * 3 + kx) * ci_n + ci) * co_n + co];
+        }
+      }
+    }
+    z[e] = acc;
+  }
+}
+
+// dx[n][ci][H][W] = sum_co conv3x3_transposed(dz[n][co], w)
+__global__ void t_conv_bwd_data(int n, int ci_n, int co_n, int H, int W, const float *dz, const float *w, float *dx) {
+  const size_t total = (size_t)n * ci_n * H * W;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int xx = e % W, yy = (e / W) % H, ci = (e / ((size_t)W * H)) % ci_n, s = e / ((size_t)W * H * ci_n);
+    float acc = 0.f;
+    for (int co = 0; co < co_n; co++) {
+      const float *dp = dz + ((size_t)s * co_n + co) * H * W;
+      for (int ky = 0; ky < 3; ky++) {
+        const int y = yy - (ky - 1);  // output pixel that read this input through tap ky
+        if (y < 0 || y >= H) continue;
+        for (int kx = 0; kx < 3; kx++) {
+          const int xq = xx - (kx - 1);
+          if (xq < 0 || xq >= W) continue;
+          acc += dp[(size_t)y * W + xq] * w[((ky * 3 + kx) * ci_n + ci) * co_n + co];
+        }
+      }
+    }
+    dx[e] = acc;
+  }
+}
+
+// dw[(ky,kx,ci,co)] = sum_{n,y,x} x[n][ci][y+ky-1][x+kx-1] dz[n][co][y][x] ; one workgroup per weight, tree reduction
+// (double accumulators: up to 10^7 terms); workgroups 9*ci*co .. +co-1 reduce db[co] = sum dz
+__global__ __launch_bounds__(256) void t_conv_bwd_weight(int n, int ci_n, int co_n, int H, int W, const float *x,
+                                                         const float *dz, float *dw, float *db) {
+  __shared__ double red[256];
+  const int wid = blockIdx.x, nw = 9 * ci_n * co_n;
+  const size_t per = (size_t)H * W, total = (size_t)n * per;
+  double acc = 0.0;
+  if (wid < nw) {
+    const int co = wid % co_n, ci = (wid / co_n) % ci_n, kx = (wid / (co_n * ci_n)) % 3, ky = wid / (co_n * ci_n * 3);
+    for (size_t e = threadIdx.x; e < total; e += 256) {
+      const int s = e / per, yy = (e - (size_t)s * per) / W, xx = e % W;
+      const int y = yy + ky - 1, xq = xx + kx - 1;
+      if (y < 0 || y >= H || xq < 0 || xq >= W) continue;
+      acc += (double)x[(((size_t)s * ci_n + ci) * H + y) * W + xq] * (double)dz[(((size_t)s * co_n + co) * H + yy) * W + xx];
+    }
+  } else {
+    const int co = wid - nw;
+    for (size_t e = threadIdx.x; e < total; e += 256) {
+      const int s = e / per;
+      acc += (double)dz[((size_t)s * co_n + co) * per + (e - (size_t)s * per)];
+    }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (wid < nw) dw[wid] = (float)red[0];
+    else db[wid - nw] = (float)red[0];
+  }
+}
+
+// per-channel sums over (n, H, W): out[c] = {sum a, sum a*b} (b may be null -> sum a*a); double accumulation
+__global__ __launch_bounds__(256) void t_chan_sums(int n, int c_n, size_t per, const float *a, const float *b, double *out) {
+  __shared__ double r0[256], r1[256];
+  const int c = blockIdx.x;
+  const size_t total = (size_t)n * per;
+  double s0 = 0.0, s1 = 0.0;
+  for (size_t e = threadIdx.x; e < total; e += 256) {
+    const size_t s = e / per, idx = (s * c_n + c) * per + (e - s * per);
+    const double va = a[idx], vb = b ? b[idx] : va;
+    s0 += va;
+    s1 += va * vb;
+  }
+  r0[threadIdx.x] = s0; r1[threadIdx.x] = s1;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { r0[threadIdx.x] += r0[threadIdx.x + o]; r1[threadIdx.x] += r1[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[2 * c] = r0[0]; out[2 * c + 1] = r1[0]; }
+}
+
+// batch statistics from the sums: mean, biased variance (stat[c] = {mean, var})
+__global__ void t_bn_finish_stats(int c_n, double count, const double *sums, float *stat) {
+  const int c = threadIdx.x;
+  if (c >= c_n) return;
+  const double m = sums[2 * c] / count, v = sums[2 * c + 1] / count - m * m;
+  stat[2 * c] = (float)m;
+  stat[2 * c + 1] = (float)(v > 0.0 ? v : 0.0);
+}
+
+// a = relu(gamma * (z - mean) / sqrt(var + eps) + beta)
+__global__ void t_bn_relu_fwd(int n, int c_n, size_t per, const float *z, const float *stat, const float *gamma,
+                              const float *beta, float *a) {
+  const size_t total = (size_t)n * c_n * per;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int c = (e / per) % c_n;
+    const float xh = (z[e] - stat[2 * c]) * rsqrtf(stat[2 * c + 1] + 1e-3f);
+    a[e] = fmaxf(gamma[c] * xh + beta[c], 0.f);
+  }
+}
+
+// dy (w.r.t. the BN output, ReLU mask applied) and xhat, in place over da / into xh
+__global__ void t_bn_relu_bwd_pre(int n, int c_n, size_t per, const float *z, const float *a, const float *stat, float *da,
+                                  float *xh) {
+  const size_t total = (size_t)n * c_n * per;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int c = (e / per) % c_n;
+    xh[e] = (z[e] - stat[2 * c]) * rsqrtf(stat[2 * c + 1] + 1e-3f);
+    if (!(a[e] > 0.f)) da[e] = 0.f;
+  }
+}
+
+// dz = gamma / sqrt(var+eps) * (dy - mean(dy) - xhat * mean(dy * xhat)) ; sums[c] = {sum dy, sum dy*xhat}
+__global__ void t_bn_bwd(int n, int c_n, size_t per, const float *dy, const float *xh, const float *stat, const float *gamma,
+                         const double *sums, float *dz, float *dgamma, float *dbeta) {
+  const size_t total = (size_t)n * c_n * per;
+  const double count = (double)n * (double)per;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int c = (e / per) % c_n;
+    const float m0 = (float)(sums[2 * c] / count), m1 = (float)(sums[2 * c + 1] / count);
+    dz[e] = gamma[c] * rsqrtf(stat[2 * c + 1] + 1e-3f) * (dy[e] - m0 - xh[e] * m1);
+    if (e < (size_t)c_n) { dbeta[e] = (float)sums[2 * e]; dgamma[e] = (float)sums[2 * e + 1]; }
+  }
+}
+
+__global__ void t_pool_fwd(int nc, int H, int W, const float *a, float *p) {  // [nc][H][W] -> [nc][H/2][W/2]
+  const int H2 = H / 2, W2 = W / 2;
+  const size_t total = (size_t)nc * H2 * W2;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int x = e % W2, y = (e / W2) % H2;
+    const size_t c = e / ((size_t)W2 * H2);
+    const float *q = a + (c * H + 2 * y) * W + 2 * x;
+    p[e] = fmaxf(fmaxf(q[0], q[1]), fmaxf(q[W], q[W + 1]));
+  }
+}
+
+// routes dp to the first maximum of each window (row-major), zero elsewhere
+__global__ void t_pool_bwd(int nc, int H, int W, const float *a, const float *dp, float *da) {
+  const int H2 = H / 2, W2 = W / 2;
+  const size_t total = (size_t)nc * H2 * W2;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int x = e % W2, y = (e / W2) % H2;
+    const size_t c = e / ((size_t)W2 * H2), base = (c * H + 2 * y) * W + 2 * x;
+    const float v[4] = {a[base], a[base + 1], a[base + W], a[base + W + 1]};
+    int k = 0;
+    for (int i = 1; i < 4; i++) if (v[i] > v[k]) k = i;
+    const size_t off[4] = {base, base + 1, base + W, base + W + 1};
+    for (int i = 0; i < 4; i++) da[off[i]] = i == k ? dp[e] : 0.f;
+  }
+}
+
+// x2 bilinear, half-pixel centres, edge clamp: u[nc][2H][2W]
+__device__ inline void up_taps(int u, int n, int &i0, int &i1, float &w1) {
+  const int k = u >> 1;
+  if (u & 1) { i0 = k; i1 = min(k + 1, n - 1); w1 = 0.25f; }
+  else { i0 = max(k - 1, 0); i1 = k; w1 = 0.75f; }
+}
+__global__ void t_up_fwd(int nc, int H, int W, const float *x, float *u) {
+  const int H2 = 2 * H, W2 = 2 * W;
+  const size_t total = (size_t)nc * H2 * W2;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int ux = e % W2, uy = (e / W2) % H2;
+    const size_t c = e / ((size_t)W2 * H2);
+    int y0, y1, x0, x1; float wy, wx;
+    up_taps(uy, H, y0, y1, wy); up_taps(ux, W, x0, x1, wx);
+    const float *q = x + c * H * W;
+    const float top = q[(size_t)y0 * W + x0] * (1.f - wx) + q[(size_t)y0 * W + x1] * wx;
+    const float bot = q[(size_t)y1 * W + x0] * (1.f - wx) + q[(size_t)y1 * W + x1] * wx;
+    u[e] = top * (1.f - wy) + bot * wy;
+  }
+}
+__global__ void t_up_bwd(int nc, int H, int W, const float *du, float *dx) {  // dx must be zero-filled
+  const int H2 = 2 * H, W2 = 2 * W;
+  const size_t total = (size_t)nc * H2 * W2;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int ux = e % W2, uy = (e / W2) % H2;
+    const size_t c = e / ((size_t)W2 * H2);
+    int y0, y1, x0, x1; float wy, wx;
+    up_taps(uy, H, y0, y1, wy); up_taps(ux, W, x0, x1, wx);
+    float *q = dx + c * H * W;
+    const float g = du[e];
+    if (g == 0.f) continue;
+    atomicAdd(&q[(size_t)y0 * W + x0], g * (1.f - wy) * (1.f - wx));
+    atomicAdd(&q[(size_t)y0 * W + x1], g * (1.f - wy) * wx);
+    atomicAdd(&q[(size_t)y1 * W + x0], g * wy * (1.f - wx));
+    atomicAdd(&q[(size_t)y1 * W + x1], g * wy * wx);
+  }
+}
+
+// y[n][out] = act(x[n][in] W[in][out] + b)
+__global__ void t_dense_fwd(int n, int in_n, int out_n, const float *x, const float *w, const float *b, float *y, int relu) {
+  const size_t total = (size_t)n * out_n;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int o = e % out_n, s = e / out_n;
+    float acc = b[o];
+    for (int k = 0; k < in_n; k++) acc += x[(size_t)s * in_n + k] * w[(size_t)k * out_n + o];
+    y[e] = relu ? fmaxf(acc, 0.f) : acc;
+  }
+}
+// dy masked by the ReLU of y (in place) when relu
+__global__ void t_relu_mask(size_t total, const float *y, float *dy) {
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x)
+    if (!(y[e] > 0.f)) dy[e] = 0.f;
+}
+__global__ void t_dense_bwd_w(int n, int in_n, int out_n, const float *x, const float *dy, float *dw, float *db) {
+  const size_t total = (size_t)(in_n + 1) * out_n;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int o = e % out_n, k = e / out_n;
+    float acc = 0.f;
+    if (k < in_n) {
+      for (int s = 0; s < n; s++) acc += x[(size_t)s * in_n + k] * dy[(size_t)s * out_n + o];
+      dw[e] = acc;
+    } else {
+      for (int s = 0; s < n; s++) acc += dy[(size_t)s * out_n + o];
+      db[o] = acc;
+    }
+  }
+}
+__global__ void t_dense_bwd_x(int n, int in_n, int out_n, const float *dy, const float *w, float *dx, int accumulate) {
+  const size_t total = (size_t)n * in_n;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int k = e % in_n, s = e / in_n;
+    float acc = 0.f;
+    for (int o = 0; o < out_n; o++) acc += dy[(size_t)s * out_n + o] * w[(size_t)k * out_n + o];
+    dx[e] = accumulate ? dx[e] + acc : acc;
+  }
+}
+
+// f[n][5008] = concat(vec8, flatten_hwc(x4 [n][8][25][25])) and its transpose for the gradient
+__global__ void t_concat_fwd(int n, const ofx_transition *rows, const float *x4, float *f) {
+  const size_t total = (size_t)n * 5008;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int k = e % 5008, s = e / 5008;
+    if (k < 8) f[e] = rows[s].head_prev[k];
+    else { const int j = k - 8, c = j % 8, p = j / 8; f[e] = x4[((size_t)s * 8 + c) * 625 + p]; }
+  }
+}
+__global__ void t_concat_bwd(int n, const float *df, float *dx4) {
+  const size_t total = (size_t)n * 5000;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int j = e % 5000, s = e / 5000, c = j % 8, p = j / 8;
+    dx4[((size_t)s * 8 + c) * 625 + p] = df[(size_t)s * 5008 + 8 + j];
+  }
+}
+
+// loss seeds: one non-zero error per head and sample; loss[0] += mse(out1) share, loss[1] += mse(out2) share
+__global__ void t_loss_seed(int n, const ofx_transition *rows, const float *o1, const float *o2, const float *y_act,
+                            const float *y_ptr, float *do1, float *do2, float *loss) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  const ofx_transition r = rows[s];
+  if (r.ship < 0) return;  // padding row: no error
+  const int a = r.iaction ? 1 : 0, px = min(max(r.px, 0), TPS - 1), py = min(max(r.py, 0), TPS - 1);
+  const float e1 = o1[2 * s + a] - y_act[s];
+  const size_t k = (size_t)s * TPS * TPS + (size_t)py * TPS + px;
+  const float e2 = o2[k] - y_ptr[s];
+  do1[2 * s + a] = 2.f * e1 / (2.f * n);
+  do2[k] = 2.f * e2 / ((float)(TPS * TPS) * n);
+  atomicAdd(&loss[0], e1 * e1 / (2.f * n));
+  atomicAdd(&loss[1], e2 * e2 / ((float)(TPS * TPS) * n));
+}
+
+__global__ void t_adam(size_t cnt, float *w, const float *g, float *m, float *v, float lr_t, float b1, float b2, float eps) {
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < cnt; e += (size_t)gridDim.x * blockDim.x) {
+    const float gi = g[e];
+    const float mi = b1 * m[e] + (1.f - b1) * gi, vi = b2 * v[e] + (1.f - b2) * gi * gi;
+    m[e] = mi; v[e] = vi;
+    w[e] -= lr_t * mi / (sqrtf(vi) + eps);
+  }
+}
+__global__ void t_moving(int c_n, float *mean, float *var, const float *stat) {
+  const int c = threadIdx.x;
+  if (c >= c_n) return;
+  mean[c] = 0.99f * mean[c] + 0.01f * stat[2 * c];
+  var[c] = 0.99f * var[c] + 0.01f * stat[2 * c + 1];
+}
+
+// ---------------------------------------------------------------- host orchestration
+#define GRID(total) dim3((unsigned)(((total) + 255) / 256 > 65535 * 16 ? 65535 * 16 : ((total) + 255) / 256)), dim3(256)
+#define K(kern, total, ...) do { hipLaunchKernelGGL(kern, GRID(total), 0, st, __VA_ARGS__); OFX_HIP(hipGetLastError()); } while (0)
+
+struct Arena {  // bump allocator over one hipMalloc
+  char *base; size_t used, cap;
+  float *f(size_t n) { float *p = (float *)(base + used); used += (n * 4 + 255) & ~(size_t)255; return p; }
+  double *d(size_t n) { double *p = (double *)(base + used); used += (n * 8 + 255) & ~(size_t)255; return p; }
+};
+
+static const int kTI[4] = {2, 8, 8, 8}, kUI[4] = {1, 2, 4, 8}, kUO[4] = {2, 4, 8, 1};
+
+extern "C" int ofx_dqn_fit(ofx_handle *h, float *weights, float *adam_m, float *adam_v, int32_t step, float lr, int32_t n,
+                           const ofx_transition *rows, const void *bits_prev, const float *y_act, const float *y_ptr,
+                           float *grad_out, float *loss_host) {
+  if (!h || !weights || !adam_m || !adam_v || !rows || !bits_prev || !y_act || !y_ptr || n < 1 || step < 1) {
+    ofx_set_error("ofx_dqn_fit: bad argument");
+    return OFX_ERR_INVALID;
+  }
+  OFX_HIP(hipSetDevice(h->cfg.device));
+  hipStream_t st = h->stream;
+  ofx_policy_desc L;
+  int rc = ofx_policy_layout(h, &L);
+  if (rc) return rc;
+  const size_t N = (size_t)n;
+  // activations: trunk sizes 400,200,100,50 (z, a per layer + pooled), head-2 sizes 50,100,200 (+ upsampled inputs)
+  size_t need = 0;
+  auto sz = [&](size_t fl) { need += (fl * 4 + 255) & ~(size_t)255; };
+  for (int pass = 0; pass < 1; pass++) {
+    sz(N * 2 * 160000);
+    for (int i = 0, s = 400; i < 4; i++, s /= 2) { sz(N * 8 * s * s); sz(N * 8 * s * s); sz(N * 8 * (s / 2) * (s / 2)); sz(N * 8 * s * s); sz(N * 8 * s * s); }
+    sz(N * 5008); sz(N * 100); sz(N * 50); sz(N * 2); sz(N * 625);
+    for (int j = 0, s = 50; j < 3; j++, s *= 2) { sz(N * kUI[j] * s * s); sz(N * kUO[j] * s * s); sz(N * kUO[j] * s * s); sz(N * kUO[j] * s * s); sz(N * kUO[j] * s * s); }
+    sz(N * 8 * 160000); sz(N * 160000);               // up4, o2
+    sz(N * 8 * 160000); sz(N * 8 * 160000);           // two gradient scratch planes of the largest size
+    sz(N * 5008); sz(N * 100); sz(N * 100); sz(N * 50); sz(N * 2); sz(N * 625); sz(N * 160000);
+    sz(L.n_floats); sz(64); need += 65536 + 16 * 64 * 8;
+  }
+  void *raw = nullptr;
+  OFX_HIP(hipMalloc(&raw, need));
+  Arena A{(char *)raw, 0, need};
+  const float *W_ = weights;
+  auto T = [&](int t) { return weights + L.offset[t]; };
+  float *grad = A.f(L.n_floats);
+  OFX_HIP(hipMemsetAsync(grad, 0, sizeof(float) * L.n_floats, st));
+  float *loss = A.f(64);
+  OFX_HIP(hipMemsetAsync(loss, 0, 64 * sizeof(float), st));
+  double *sums = A.d(16 * 16);
+  auto G = [&](int t) { return grad + L.offset[t]; };
+
+  // ---- forward (training mode) ----
+  float *x0 = A.f(N * 2 * 160000);
+  K(t_bits_to_f32, N * 2 * 160000, n, (const uint32_t *)bits_prev, x0);
+  float *tz[4], *ta[4], *tp[4], *tstat[4];
+  const float *tin = x0;
+  for (int i = 0, s = 400; i < 4; i++, s /= 2) {
+    const size_t per = (size_t)s * s;
+    tz[i] = A.f(N * 8 * per); ta[i] = A.f(N * 8 * per); tp[i] = A.f(N * 8 * per / 4); tstat[i] = A.f(16);
+    K(t_conv_fwd, N * 8 * per, n, kTI[i], 8, s, s, tin, T(6 * i), T(6 * i + 1), tz[i]);
+    hipLaunchKernelGGL(t_chan_sums, dim3(8), dim3(256), 0, st, n, 8, per, tz[i], (const float *)nullptr, sums);
+    hipLaunchKernelGGL(t_bn_finish_stats, dim3(1), dim3(64), 0, st, 8, (double)N * (double)per, sums, tstat[i]);
+    K(t_bn_relu_fwd, N * 8 * per, n, 8, per, tz[i], tstat[i], T(6 * i + 2), T(6 * i + 3), ta[i]);
+    K(t_pool_fwd, N * 8 * per / 4, n * 8, s, s, ta[i], tp[i]);
+    tin = tp[i];
+  }
+  float *f = A.f(N * 5008), *d1 = A.f(N * 100), *d2 = A.f(N * 50), *o1 = A.f(N * 2), *u0 = A.f(N * 625);
+  K(t_concat_fwd, N * 5008, n, rows, tp[3], f);
+  K(t_dense_fwd, N * 100, n, 5008, 100, f, T(24), T(25), d1, 1);
+  K(t_dense_fwd, N * 50, n, 100, 50, d1, T(26), T(27), d2, 1);
+  K(t_dense_fwd, N * 2, n, 50, 2, d2, T(28), T(29), o1, 0);
+  K(t_dense_fwd, N * 625, n, 100, 625, d1, T(30), T(31), u0, 1);
+  float *uu[3], *uz[3], *ua[3], *ustat[3];
+  const float *uin = u0;
+  for (int j = 0, s = 50; j < 3; j++, s *= 2) {
+    const size_t per = (size_t)s * s;
+    uu[j] = A.f(N * kUI[j] * per); uz[j] = A.f(N * kUO[j] * per); ua[j] = A.f(N * kUO[j] * per); ustat[j] = A.f(16);
+    K(t_up_fwd, N * kUI[j] * per, n * kUI[j], s / 2, s / 2, uin, uu[j]);
+    K(t_conv_fwd, N * kUO[j] * per, n, kUI[j], kUO[j], s, s, uu[j], T(32 + 6 * j), T(33 + 6 * j), uz[j]);
+    hipLaunchKernelGGL(t_chan_sums, dim3(kUO[j]), dim3(256), 0, st, n, kUO[j], per, uz[j], (const float *)nullptr, sums);
+    hipLaunchKernelGGL(t_bn_finish_stats, dim3(1), dim3(64), 0, st, kUO[j], (double)N * (double)per, sums, ustat[j]);
+    K(t_bn_relu_fwd, N * kUO[j] * per, n, kUO[j], per, uz[j], ustat[j], T(34 + 6 * j), T(35 + 6 * j), ua[j]);
+    uin = ua[j];
+  }
+  float *up4 = A.f(N * 8 * 160000), *o2 = A.f(N * 160000);
+  K(t_up_fwd, N * 8 * 160000, n * 8, 200, 200, ua[2], up4);
+  K(t_conv_fwd, N * 160000, n, 8, 1, 400, 400, up4, T(50), T(51), o2);
+
+  // ---- loss seeds ----
+  float *do1 = A.f(N * 2), *do2 = A.f(N * 160000);
+  OFX_HIP(hipMemsetAsync(do1, 0, N * 2 * 4, st));
+  OFX_HIP(hipMemsetAsync(do2, 0, N * 160000 * 4, st));
+  K(t_loss_seed, N, n, rows, o1, o2, y_act, y_ptr, do1, do2, loss);
+
+  // ---- backward: head 2 ----
+  float *gA = A.f(N * 8 * 160000), *gB = A.f(N * 8 * 160000);  // gradient scratch (largest tensors)
+  hipLaunchKernelGGL(t_conv_bwd_weight, dim3(9 * 8 * 1 + 1), dim3(256), 0, st, n, 8, 1, 400, 400, up4, do2, G(50), G(51));
+  K(t_conv_bwd_data, N * 8 * 160000, n, 8, 1, 400, 400, do2, T(50), gA);   // d up4
+  float *dcur = gB;                                                          // d ua[2]
+  OFX_HIP(hipMemsetAsync(dcur, 0, N * 8 * 40000 * 4, st));
+  K(t_up_bwd, N * 8 * 160000, n * 8, 200, 200, gA, dcur);
+  for (int j = 2, s = 200; j >= 0; j--, s /= 2) {
+    const size_t per = (size_t)s * s, tot = N * kUO[j] * per;
+    float *xh = gA;                                                          // reuse as xhat
+    K(t_bn_relu_bwd_pre, tot, n, kUO[j], per, uz[j], ua[j], ustat[j], dcur, xh);
+    hipLaunchKernelGGL(t_chan_sums, dim3(kUO[j]), dim3(256), 0, st, n, kUO[j], per, dcur, xh, sums);
+    float *dz = ua[j];                                                       // the activation is dead now: holds dz
+    K(t_bn_bwd, tot, n, kUO[j], per, dcur, xh, ustat[j], T(34 + 6 * j), sums, dz, G(34 + 6 * j), G(35 + 6 * j));
+    hipLaunchKernelGGL(t_conv_bwd_weight, dim3(9 * kUI[j] * kUO[j] + kUO[j]), dim3(256), 0, st, n, kUI[j], kUO[j], s, s,
+                       uu[j], dz, G(32 + 6 * j), G(33 + 6 * j));
+    float *duu = gA;                                                         // d (upsampled input)
+    K(t_conv_bwd_data, N * kUI[j] * per, n, kUI[j], kUO[j], s, s, dz, T(32 + 6 * j), duu);
+    float *dprev = gB;                                                       // d (previous activation / u0)
+    OFX_HIP(hipMemsetAsync(dprev, 0, N * kUI[j] * per / 4 * 4, st));
+    K(t_up_bwd, N * kUI[j] * per, n * kUI[j], s / 2, s / 2, duu, dprev);
+    dcur = dprev;
+  }
+  // dcur = d u0 [n][625] (pre-mask)
+  float *dd1 = A.f(N * 100), *dd1b = A.f(N * 100), *dd2 = A.f(N * 50), *df = A.f(N * 5008);
+  K(t_relu_mask, N * 625, N * 625, u0, dcur);
+  K(t_dense_bwd_w, (size_t)101 * 625, n, 100, 625, d1, dcur, G(30), G(31));
+  K(t_dense_bwd_x, N * 100, n, 100, 625, dcur, T(30), dd1, 0);
+  // ---- backward: head 1 ----
+  K(t_dense_bwd_w, (size_t)51 * 2, n, 50, 2, d2, do1, G(28), G(29));
+  K(t_dense_bwd_x, N * 50, n, 50, 2, do1, T(28), dd2, 0);
+  K(t_relu_mask, N * 50, N * 50, d2, dd2);
+  K(t_dense_bwd_w, (size_t)101 * 50, n, 100, 50, d1, dd2, G(26), G(27));
+  K(t_dense_bwd_x, N * 100, n, 100, 50, dd2, T(26), dd1, 1);
+  (void)dd1b;
+  // ---- dense1 + trunk ----
+  K(t_relu_mask, N * 100, N * 100, d1, dd1);
+  K(t_dense_bwd_w, (size_t)5009 * 100, n, 5008, 100, f, dd1, G(24), G(25));
+  K(t_dense_bwd_x, N * 5008, n, 5008, 100, dd1, T(24), df, 0);
+  float *dp = gB;
+  K(t_concat_bwd, N * 5000, n, df, dp);                                      // d tp[3] [n][8][25][25]
+  for (int i = 3, s = 50; i >= 0; i--, s *= 2) {
+    const size_t per = (size_t)s * s, tot = N * 8 * per;
+    float *da = gA;
+    K(t_pool_bwd, tot / 4, n * 8, s, s, ta[i], dp, da);
+    float *xh = tp[i];                                                       // pooled output is dead: reuse? too small -> use gB tail
+    xh = gB + N * 8 * 40000;                                                 // second half of gB (>= N*8*per for s <= 200)
+    if (s == 400) xh = up4;                                                  // the 400^2 layer: up4 (8 x 400^2) is dead by now
+    K(t_bn_relu_bwd_pre, tot, n, 8, per, tz[i], ta[i], tstat[i], da, xh);
+    hipLaunchKernelGGL(t_chan_sums, dim3(8), dim3(256), 0, st, n, 8, per, da, xh, sums);
+    float *dz = ta[i];
+    K(t_bn_bwd, tot, n, 8, per, da, xh, tstat[i], T(6 * i + 2), sums, dz, G(6 * i + 2), G(6 * i + 3));
+    const float *xin = i == 0 ? x0 : tp[i - 1];
+    hipLaunchKernelGGL(t_conv_bwd_weight, dim3(9 * kTI[i] * 8 + 8), dim3(256), 0, st, n, kTI[i], 8, s, s, xin, dz, G(6 * i),
+                       G(6 * i + 1));
+    if (i > 0) {
+      dp = gB;                                                               // d tp[i-1] [n][8][s][s]
+      K(t_conv_bwd_data, N * 8 * per, n, 8, 8, s, s, dz, T(6 * i), dp);
+    }
+  }
+  if (grad_out) OFX_HIP(hipMemcpyAsync(grad_out, grad, sizeof(float) * L.n_floats, hipMemcpyDeviceToDevice, st));
+
+  // ---- Adam + moving statistics ----
+  const float b1 = 0.9f, b2 = 0.999f;
+  const float lr_t = lr * sqrtf(1.f - powf(b2, (float)step)) / (1.f - powf(b1, (float)step));
+  for (int t = 0; t < L.n_tensors; t++) {
+    const bool conv_bn = t < 24 || (t >= 32 && t < 50);
+    const int k = conv_bn ? (t < 24 ? t % 6 : (t - 32) % 6) : -1;
+    if (k == 4 || k == 5) continue;  // moving mean / variance: not trained
+    K(t_adam, (size_t)L.count[t], (size_t)L.count[t], weights + L.offset[t], grad + L.offset[t], adam_m + L.offset[t],
+      adam_v + L.offset[t], lr_t, b1, b2, 1e-7f);
+  }
+  for (int i = 0; i < 4; i++) hipLaunchKernelGGL(t_moving, dim3(1), dim3(64), 0, st, 8, weights + L.offset[6 * i + 4], weights + L.offset[6 * i + 5], tstat[i]);
+  for (int j = 0; j < 3; j++) hipLaunchKernelGGL(t_moving, dim3(1), dim3(64), 0, st, kUO[j], weights + L.offset[32 + 6 * j + 4], weights + L.offset[32 + 6 * j + 5], ustat[j]);
+  OFX_HIP(hipGetLastError());
+  float lh[2] = {0.f, 0.f};
+  OFX_HIP(hipMemcpyAsync(lh, loss, sizeof(lh), hipMemcpyDeviceToHost, st));
+  OFX_HIP(hipStreamSynchronize(st));
+  if (loss_host) { loss_host[0] = lh[0]; loss_host[1] = lh[1]; }
+  (void)W_;
+  OFX_HIP(hipFree(raw));
+  return OFX_OK;
+}

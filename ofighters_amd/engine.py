@@ -401,6 +401,16 @@ class ArenaBatch:
         self.sync()
         return tuple(b.download(np.float32, (n,)) for b in bufs)
 
+    def dqn_fit(self, weights_buf, adam_m_buf, adam_v_buf, step, lr, n, rows_ptr, bits_prev_ptr, y_act_ptr, y_ptr_ptr,
+                grad_buf=None):
+        """One model.fit step of Trainer.replay on device (qlearnIA_V2.py:284); DeviceBuffers are updated in place.
+        Returns (mse(output1), mse(output2))."""
+        loss = (C.c_float * 2)()
+        nat.check(nat.lib().ofx_dqn_fit(self._h, weights_buf.ptr, adam_m_buf.ptr, adam_v_buf.ptr, int(step), float(lr),
+                                         int(n), rows_ptr, bits_prev_ptr, y_act_ptr, y_ptr_ptr,
+                                         grad_buf.ptr if grad_buf else None, loss))
+        return float(loss[0]), float(loss[1])
+
     def policy_explore(self, epsilon, seed, tick=None, collecting=False, ship_mask_ptr=None, iaction_ptr=None,
                        ipointer_ptr=None):
         """epsilon-greedy / collecting-phase random play over the last forward's results."""

@@ -1,0 +1,123 @@
+"""ofx_dqn_fit (one model.fit step of Trainer.replay) against torch autograd: the same graph in
+training mode (BatchNorm on batch statistics), the same loss (mse on both heads with one non-zero error per head and
+sample), float64 on the CPU as the checker.  Keras itself is absent from the image: parity with it is UNPINNED, the
+conventions are those declared in ofighters_amd/csrc/ofx_train.hip."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch_reference(w, shapes, x0, vec8, iaction, px, py, y_act, y_ptr):
+    import torch
+    import torch.nn.functional as F
+    torch.set_num_threads(8)
+    P = {}
+    for name, (o, shp) in shapes.items():
+        P[name] = torch.tensor(w[o:o + int(np.prod(shp))].reshape(shp), dtype=torch.float64, requires_grad=True)
+    n = x0.shape[0]
+    stats = {}
+
+    def block(x, name, up=False):
+        if up:
+            x = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+        k = P[name + ".kernel"].permute(3, 2, 0, 1)           # HWIO -> OIHW
+        z = F.conv2d(x, k, P[name + ".bias"], padding=1)
+        stats[name] = (z.mean(dim=(0, 2, 3)).detach(), z.var(dim=(0, 2, 3), unbiased=False).detach())
+        return torch.relu(F.batch_norm(z, None, None, P[name + ".gamma"], P[name + ".beta"], training=True, eps=1e-3))
+
+    x = torch.tensor(x0, dtype=torch.float64)
+    for i in (1, 2, 3, 4):
+        x = F.max_pool2d(block(x, "conv%d" % i), 2)
+    flat = x.permute(0, 2, 3, 1).reshape(n, 5000)
+    f = torch.cat([torch.tensor(vec8, dtype=torch.float64), flat], dim=1)
+    d1 = torch.relu(f @ P["dense1.kernel"] + P["dense1.bias"])
+    d2 = torch.relu(d1 @ P["dense2.kernel"] + P["dense2.bias"])
+    o1 = d2 @ P["output1.kernel"] + P["output1.bias"]
+    u = torch.relu(d1 @ P["updense1.kernel"] + P["updense1.bias"]).reshape(n, 1, 25, 25)
+    for j in (1, 2, 3):
+        u = block(u, "upconv%d" % j, up=True)
+    u = F.interpolate(u, scale_factor=2, mode="bilinear", align_corners=False)
+    o2 = F.conv2d(u, P["upconv4.kernel"].permute(3, 2, 0, 1), P["upconv4.bias"], padding=1)
+    idx = torch.arange(n)
+    e1 = o1[idx, torch.tensor(iaction)] - torch.tensor(y_act, dtype=torch.float64)
+    e2 = o2[idx, 0, torch.tensor(py), torch.tensor(px)] - torch.tensor(y_ptr, dtype=torch.float64)
+    l1, l2 = (e1 ** 2).sum() / (2 * n), (e2 ** 2).sum() / (160000 * n)
+    (l1 + l2).backward()
+    g = np.zeros_like(w, dtype=np.float64)
+    for name, (o, shp) in shapes.items():
+        if P[name].grad is not None:
+            g[o:o + int(np.prod(shp))] = P[name].grad.numpy().ravel()
+    return float(l1.detach()), float(l2.detach()), g, stats
+
+
+def test_dqn_fit_vs_torch_autograd():
+    from ofighters_amd import ArenaBatch, DeviceBuffer
+    N, M, seed, batch, lr = 2, 4, 0x0F160001, 2, 1e-4
+    b = ArenaBatch(N, M)
+    b.replay_create(16, 0)
+    b.spawn_random(seed)
+    w, shapes = pyoracle.policy_init(9, trained_like=True)
+    mask = np.zeros((N, M), np.uint8)
+    mask[:, [0, 2]] = 1
+    mask_d = DeviceBuffer(mask.nbytes).upload(mask)
+    ia_d, ip_d = DeviceBuffer(4 * N * M), DeviceBuffer(8 * N * M)
+    for t in range(12):
+        b.bot_actions(["random"] * M, seed, tick=t)
+        b.policy_explore(1.0, seed, tick=t, collecting=True, ship_mask_ptr=mask_d.ptr, iaction_ptr=ia_d.ptr, ipointer_ptr=ip_d.ptr)
+        b.policy_actions(out_ptr=b._actions.ptr, ship_mask_ptr=mask_d.ptr, iaction_ptr=ia_d.ptr, ipointer_ptr=ip_d.ptr)
+        b.replay_capture(t, mask_d.ptr, ia_d.ptr, ip_d.ptr)
+        b.step(actions_ptr=b._actions.ptr)
+    slot, _ = b.replay_sample(3, 0, batch)
+    rows_d, bp_d, bn_d = b.replay_gather_device(slot, batch)
+    n = N * batch
+    rows = rows_d.download(b.TRANSITION_DTYPE, (n,))
+    assert (rows["ship"] >= 0).all()
+    rs = np.random.RandomState(1)
+    y_act, y_ptr = rs.uniform(-1, 2, n).astype(np.float32), rs.uniform(-1, 2, n).astype(np.float32)
+    b.sync()
+    ya_d, yp_d = DeviceBuffer(4 * n).upload(y_act), DeviceBuffer(4 * n).upload(y_ptr)
+    w_d = DeviceBuffer(w.nbytes).upload(w)
+    zeros = np.zeros_like(w)
+    m_d, v_d, g_d = DeviceBuffer(w.nbytes).upload(zeros), DeviceBuffer(w.nbytes).upload(zeros), DeviceBuffer(w.nbytes)
+    l1, l2 = b.dqn_fit(w_d, m_d, v_d, 1, lr, n, rows_d.ptr, bp_d.ptr, ya_d.ptr, yp_d.ptr, g_d)
+    g = g_d.download(np.float32, w.shape).astype(np.float64)
+    w_new = w_d.download(np.float32, w.shape)
+
+    bits = bp_d.download(np.uint32, (n, 2, 5000))
+    x0 = np.unpackbits(bits.view(np.uint8), bitorder="little").reshape(n, 2, 400, 400).astype(np.float64)
+    rl1, rl2, rg, stats = _torch_reference(w.astype(np.float64), shapes, x0, rows["head_prev"], rows["iaction"].astype(np.int64),
+                                           rows["px"].astype(np.int64), rows["py"].astype(np.int64), y_act, y_ptr)
+    assert abs(l1 - rl1) <= 1e-4 * max(1.0, abs(rl1)) and abs(l2 - rl2) <= 1e-4 * max(1e-9, abs(rl2)) + 1e-12
+    # gradients tensor by tensor: fp32 kernels vs the float64 checker
+    # (the bias of a convolution that feeds a BatchNorm has an exactly zero gradient: only rounding noise is left, so
+    # the absolute part of the tolerance is tied to the layer's kernel gradient)
+    report = []
+    for name, (o, shp) in shapes.items():
+        c = int(np.prod(shp))
+        layer, kind = name.split(".")
+        if kind in ("mean", "var"):
+            continue
+        ref, got = rg[o:o + c], g[o:o + c]
+        ko, kshp = shapes[layer + ".kernel"]
+        kscale = float(np.abs(rg[ko:ko + int(np.prod(kshp))]).max())
+        scale, err = float(np.abs(ref).max()), float(np.abs(got - ref).max())
+        report.append((name, scale, err, err <= 1e-4 * scale + 5e-5 * kscale))
+    print("\n".join("%-18s scale %.3e  err %.3e  %s" % r for r in report))
+    assert all(r[3] for r in report), [r for r in report if not r[3]]
+    # Adam step 1 from the device's own gradient, and the moving statistics
+    lr_t = lr * np.sqrt(1 - 0.999) / (1 - 0.9)
+    for name, (o, shp) in shapes.items():
+        c = int(np.prod(shp))
+        layer, kind = name.split(".")
+        if kind in ("mean", "var"):
+            bm, bv = stats[layer]
+            want = 0.99 * w[o:o + c] + 0.01 * (bm if kind == "mean" else bv).numpy()
+            np.testing.assert_allclose(w_new[o:o + c], want, rtol=1e-4, atol=1e-6)
+        else:
+            gi = g[o:o + c]
+            want = w[o:o + c] - lr_t * (0.1 * gi) / (np.sqrt(0.001 * gi * gi) + 1e-7)
+            np.testing.assert_allclose(w_new[o:o + c], want, rtol=0, atol=2e-7 + 1e-6 * np.abs(w[o:o + c]).max())
+    b.close()
