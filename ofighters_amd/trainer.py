@@ -1,0 +1,59 @@
+"""DeviceTrainer - the batched, device-resident counterpart of the reference's `Trainer` (agents/qlearnIA_V2.py:46-298)
+for an ArenaBatch: weights, Adam state and the replay memory live in HBM; `get_best_action` is
+ArenaBatch.policy_forward + policy_explore, `remember` is ArenaBatch.replay_capture, and `replay(batch_size)`
+(:240-285) is sample -> gather -> targets -> one fit step, all through the C-ABI (ofx_replay_sample, ofx_replay_gather,
+ofx_dqn_targets, ofx_dqn_fit)."""
+import numpy as np
+
+from .engine import DeviceBuffer
+from .lib.epsilon import Epsilon_cos
+
+
+class DeviceTrainer:
+    def __init__(self, batch, weights, learning_rate=0.0001, epsilon=None, batch_size=8, memory_size=400, frames=0,
+                 seed=0x0F160003):
+        self.batch = batch                                  # the ArenaBatch this trainer plays and learns on
+        w = np.ascontiguousarray(weights, np.float32)
+        self.n_floats = w.size
+        self.weights = DeviceBuffer(w.nbytes).upload(w)
+        zeros = np.zeros_like(w)
+        self.adam_m = DeviceBuffer(w.nbytes).upload(zeros)
+        self.adam_v = DeviceBuffer(w.nbytes).upload(zeros)
+        self.learning_rate = learning_rate                  # lr = 0.0001 (qlearnIA_V2.py:306)
+        self.gamma = 0.9                                    # :51
+        self.epsilon = epsilon if epsilon is not None else Epsilon_cos(period=110 * 400)
+        self.batch_size = batch_size                        # 8 (:307)
+        self.seed = seed
+        self.fit_steps = 0
+        self.draws = 0
+        self.losses = []
+        batch.replay_create(memory_size, frames)
+
+    def decay_epsilon(self):
+        self.epsilon.next()
+
+    def weights_host(self):
+        self.batch.sync()
+        return self.weights.download(np.float32, (self.n_floats,))
+
+    def replay(self, batch_size=None):
+        """One Trainer.replay: a minibatch of min(batch_size, len(memory)) rows per arena, targets, one fit step.
+        Returns (mse(output1), mse(output2)) or None while every memory is still empty."""
+        b = self.batch
+        bs = int(batch_size or self.batch_size)
+        cnt, _ = b.replay_count()
+        if int(cnt.max()) == 0:
+            return None
+        slot, _ = b.replay_sample(self.seed, self.draws, bs)
+        self.draws += 1
+        rows, bits_prev, bits_next = b.replay_gather_device(slot, bs)
+        n = b.N * bs
+        outs = [DeviceBuffer(4 * n) for _ in range(4)]     # q_sa, p_sp, y_act, y_ptr
+        from . import _native as nat
+        nat.check(nat.lib().ofx_dqn_targets(b.handle, self.weights.ptr, n, rows.ptr, bits_prev.ptr, bits_next.ptr,
+                                             float(self.gamma), *[o.ptr for o in outs]))
+        self.fit_steps += 1
+        loss = b.dqn_fit(self.weights, self.adam_m, self.adam_v, self.fit_steps, self.learning_rate, n, rows.ptr,
+                         bits_prev.ptr, outs[2].ptr, outs[3].ptr)
+        self.losses.append(loss)
+        return loss
