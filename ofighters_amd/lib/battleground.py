@@ -84,7 +84,7 @@ class Laser:
 
 class Battleground:
     def __init__(self, state=None, ships=2, largeur=DEFAULT_WIDTH, hauteur=DEFAULT_HEIGHT, networks=[],
-                 engine=None, laser_cap=512):
+                 engine=None, laser_cap=512, spawn_draws=None):
         default_behavior = "random"
         if isinstance(ships, dict):
             self.ships_map = ships
@@ -104,7 +104,10 @@ class Battleground:
         draws = []
         for behavior, number in self.ships_map.items():
             for _ in range(number):
-                x, y = randint(0, largeur), randint(0, hauteur)   # battleground.py:81 (inclusive upper bound)
+                if spawn_draws is not None:                        # replaying a record: the logged draws
+                    x, y = (int(v) for v in spawn_draws[len(draws)])
+                else:
+                    x, y = randint(0, largeur), randint(0, hauteur)   # battleground.py:81 (inclusive upper bound)
                 draws.append((x, y))
                 bot = behavior if hasattr(behavior, "play") else None
                 self.ships.append(Ship(x, y, self, behavior=None if bot else behavior, bot=bot))
@@ -113,7 +116,8 @@ class Battleground:
             from ..engine import ArenaBatch
             engine = ArenaBatch(1, M, width=largeur, height=hauteur, laser_cap=laser_cap)
         self._e = engine
-        self._e.spawn(np.array(draws, np.int32).reshape(1, M, 2))
+        self.spawn_draws = np.array(draws, np.int32).reshape(M, 2)
+        self._e.spawn(self.spawn_draws.reshape(1, M, 2))
         self._maps_cache = None
         self._pull()
         self.absolute_state = Observation(battleground=self)
@@ -179,7 +183,7 @@ class Battleground:
         self.generate_frame(self.actions)
         self.absolute_state = Observation(battleground=self)
 
-    def restart(self):
+    def restart(self, reset_draws=None):
         self.time = 0
         self.actions = []
         M = len(self.ships)
@@ -187,7 +191,11 @@ class Battleground:
         for i, ship in enumerate(self.ships):
             ship.agent.reset()
             ship.time = 0
-            draws[0, i] = (randint(0, self.dim.x), randint(0, self.dim.y))   # battleground.py:115
+            if reset_draws is not None:                                      # replaying a record
+                draws[0, i] = reset_draws[i]
+            else:
+                draws[0, i] = (randint(0, self.dim.x), randint(0, self.dim.y))   # battleground.py:115
+        self.last_reset_draws = draws[0].copy()
         self._e.restart(draws)
         self._pull()
         for ship in self.ships:
