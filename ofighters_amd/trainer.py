@@ -11,7 +11,7 @@ from .lib.epsilon import Epsilon_cos
 
 class DeviceTrainer:
     def __init__(self, batch, weights, learning_rate=0.0001, epsilon=None, batch_size=8, memory_size=400, frames=0,
-                 seed=0x0F160003):
+                 seed=0x0F160003, fit_batch=64):
         self.batch = batch                                  # the ArenaBatch this trainer plays and learns on
         w = np.ascontiguousarray(weights, np.float32)
         self.n_floats = w.size
@@ -24,6 +24,8 @@ class DeviceTrainer:
         self.epsilon = epsilon if epsilon is not None else Epsilon_cos(period=110 * 400)
         self.batch_size = batch_size                        # 8 (:307)
         self.seed = seed
+        self.fit_batch = fit_batch                          # rows per optimisation step (the reference fits on 8; the
+                                                            # fit kernels are reference-quality, keep this small)
         self.fit_steps = 0
         self.draws = 0
         self.losses = []
@@ -47,13 +49,19 @@ class DeviceTrainer:
         slot, _ = b.replay_sample(self.seed, self.draws, bs)
         self.draws += 1
         rows, bits_prev, bits_next = b.replay_gather_device(slot, bs)
-        n = b.N * bs
+        # every arena contributed bs rows ([N][bs], -1 padded); one optimisation step takes a window of them that
+        # moves with the draw counter
+        total = b.N * bs
+        n = min(total, int(self.fit_batch))
+        start = ((self.draws - 1) * n) % (total - n + 1)
+        row_b, map_b = b.TRANSITION_DTYPE.itemsize, 2 * (b.W * b.H // 32) * 4
+        rows_p, prev_p, next_p = rows.ptr + start * row_b, bits_prev.ptr + start * map_b, bits_next.ptr + start * map_b
         outs = [DeviceBuffer(4 * n) for _ in range(4)]     # q_sa, p_sp, y_act, y_ptr
         from . import _native as nat
-        nat.check(nat.lib().ofx_dqn_targets(b.handle, self.weights.ptr, n, rows.ptr, bits_prev.ptr, bits_next.ptr,
-                                             float(self.gamma), *[o.ptr for o in outs]))
+        nat.check(nat.lib().ofx_dqn_targets(b.handle, self.weights.ptr, n, rows_p, prev_p, next_p, float(self.gamma),
+                                             *[o.ptr for o in outs]))
         self.fit_steps += 1
-        loss = b.dqn_fit(self.weights, self.adam_m, self.adam_v, self.fit_steps, self.learning_rate, n, rows.ptr,
-                         bits_prev.ptr, outs[2].ptr, outs[3].ptr)
+        loss = b.dqn_fit(self.weights, self.adam_m, self.adam_v, self.fit_steps, self.learning_rate, n, rows_p, prev_p,
+                         outs[2].ptr, outs[3].ptr)
         self.losses.append(loss)
         return loss
