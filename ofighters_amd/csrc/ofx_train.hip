@@ -105,13 +105,14 @@ __global__ __launch_bounds__(256) void t_conv_bwd_weight(int n, int ci_n, int co
   }
 }
 
-// per-channel sums over (n, H, W): out[c] = {sum a, sum a*b} (b may be null -> sum a*a); double accumulation
+// per-channel sums over (n, H, W): out[c] += {sum a, sum a*b} (b may be null -> sum a*a); double accumulation,
+// gridDim.y slices per channel combined with double atomics (out must be zeroed)
 __global__ __launch_bounds__(256) void t_chan_sums(int n, int c_n, size_t per, const float *a, const float *b, double *out) {
   __shared__ double r0[256], r1[256];
   const int c = blockIdx.x;
   const size_t total = (size_t)n * per;
   double s0 = 0.0, s1 = 0.0;
-  for (size_t e = threadIdx.x; e < total; e += 256) {
+  for (size_t e = (size_t)blockIdx.y * 256 + threadIdx.x; e < total; e += (size_t)gridDim.y * 256) {
     const size_t s = e / per, idx = (s * c_n + c) * per + (e - s * per);
     const double va = a[idx], vb = b ? b[idx] : va;
     s0 += va;
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256) void t_chan_sums(int n, int c_n, size_t per, c
     if ((int)threadIdx.x < o) { r0[threadIdx.x] += r0[threadIdx.x + o]; r1[threadIdx.x] += r1[threadIdx.x + o]; }
     __syncthreads();
   }
-  if (threadIdx.x == 0) { out[2 * c] = r0[0]; out[2 * c + 1] = r1[0]; }
+  if (threadIdx.x == 0) { atomicAdd(&out[2 * c], r0[0]); atomicAdd(&out[2 * c + 1], r1[0]); }
 }
 
 // batch statistics from the sums: mean, biased variance (stat[c] = {mean, var})
@@ -381,7 +382,8 @@ extern "C" int ofx_dqn_fit(ofx_handle *h, float *weights, float *adam_m, float *
     const size_t per = (size_t)s * s;
     tz[i] = A.f(N * 8 * per); ta[i] = A.f(N * 8 * per); tp[i] = A.f(N * 8 * per / 4); tstat[i] = A.f(16);
     K(t_conv_fwd, N * 8 * per, n, kTI[i], 8, s, s, tin, T(6 * i), T(6 * i + 1), tz[i]);
-    hipLaunchKernelGGL(t_chan_sums, dim3(8), dim3(256), 0, st, n, 8, per, tz[i], (const float *)nullptr, sums);
+    OFX_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 32, st));
+    hipLaunchKernelGGL(t_chan_sums, dim3(8, 64), dim3(256), 0, st, n, 8, per, tz[i], (const float *)nullptr, sums);
     hipLaunchKernelGGL(t_bn_finish_stats, dim3(1), dim3(64), 0, st, 8, (double)N * (double)per, sums, tstat[i]);
     K(t_bn_relu_fwd, N * 8 * per, n, 8, per, tz[i], tstat[i], T(6 * i + 2), T(6 * i + 3), ta[i]);
     K(t_pool_fwd, N * 8 * per / 4, n * 8, s, s, ta[i], tp[i]);
@@ -400,7 +402,8 @@ extern "C" int ofx_dqn_fit(ofx_handle *h, float *weights, float *adam_m, float *
     uu[j] = A.f(N * kUI[j] * per); uz[j] = A.f(N * kUO[j] * per); ua[j] = A.f(N * kUO[j] * per); ustat[j] = A.f(16);
     K(t_up_fwd, N * kUI[j] * per, n * kUI[j], s / 2, s / 2, uin, uu[j]);
     K(t_conv_fwd, N * kUO[j] * per, n, kUI[j], kUO[j], s, s, uu[j], T(32 + 6 * j), T(33 + 6 * j), uz[j]);
-    hipLaunchKernelGGL(t_chan_sums, dim3(kUO[j]), dim3(256), 0, st, n, kUO[j], per, uz[j], (const float *)nullptr, sums);
+    OFX_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 32, st));
+    hipLaunchKernelGGL(t_chan_sums, dim3(kUO[j], 64), dim3(256), 0, st, n, kUO[j], per, uz[j], (const float *)nullptr, sums);
     hipLaunchKernelGGL(t_bn_finish_stats, dim3(1), dim3(64), 0, st, kUO[j], (double)N * (double)per, sums, ustat[j]);
     K(t_bn_relu_fwd, N * kUO[j] * per, n, kUO[j], per, uz[j], ustat[j], T(34 + 6 * j), T(35 + 6 * j), ua[j]);
     uin = ua[j];
@@ -426,7 +429,8 @@ extern "C" int ofx_dqn_fit(ofx_handle *h, float *weights, float *adam_m, float *
     const size_t per = (size_t)s * s, tot = N * kUO[j] * per;
     float *xh = gA;                                                          // reuse as xhat
     K(t_bn_relu_bwd_pre, tot, n, kUO[j], per, uz[j], ua[j], ustat[j], dcur, xh);
-    hipLaunchKernelGGL(t_chan_sums, dim3(kUO[j]), dim3(256), 0, st, n, kUO[j], per, dcur, xh, sums);
+    OFX_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 32, st));
+    hipLaunchKernelGGL(t_chan_sums, dim3(kUO[j], 64), dim3(256), 0, st, n, kUO[j], per, dcur, xh, sums);
     float *dz = ua[j];                                                       // the activation is dead now: holds dz
     K(t_bn_bwd, tot, n, kUO[j], per, dcur, xh, ustat[j], T(34 + 6 * j), sums, dz, G(34 + 6 * j), G(35 + 6 * j));
     hipLaunchKernelGGL(t_conv_bwd_weight, dim3(9 * kUI[j] * kUO[j] + kUO[j]), dim3(256), 0, st, n, kUI[j], kUO[j], s, s,
@@ -464,7 +468,8 @@ extern "C" int ofx_dqn_fit(ofx_handle *h, float *weights, float *adam_m, float *
     xh = gB + N * 8 * 40000;                                                 // second half of gB (>= N*8*per for s <= 200)
     if (s == 400) xh = up4;                                                  // the 400^2 layer: up4 (8 x 400^2) is dead by now
     K(t_bn_relu_bwd_pre, tot, n, 8, per, tz[i], ta[i], tstat[i], da, xh);
-    hipLaunchKernelGGL(t_chan_sums, dim3(8), dim3(256), 0, st, n, 8, per, da, xh, sums);
+    OFX_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 32, st));
+    hipLaunchKernelGGL(t_chan_sums, dim3(8, 64), dim3(256), 0, st, n, 8, per, da, xh, sums);
     float *dz = ta[i];
     K(t_bn_bwd, tot, n, 8, per, da, xh, tstat[i], T(6 * i + 2), sums, dz, G(6 * i + 2), G(6 * i + 3));
     const float *xin = i == 0 ? x0 : tp[i - 1];
