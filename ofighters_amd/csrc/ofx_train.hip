@@ -73,36 +73,54 @@ __global__ void t_conv_bwd_data(int n, int ci_n, int co_n, int H, int W, const f
 // dw[(ky,kx,ci,co)] = sum_{n,y,x} x[n][ci][y+ky-1][x+kx-1] dz[n][co][y][x] ; one workgroup per weight, tree reduction
 // (double accumulators: up to 10^7 terms); workgroups 9*ci*co .. +co-1 reduce db[co] = sum dz
 __global__ __launch_bounds__(256) void t_conv_bwd_weight(int n, int ci_n, int co_n, int H, int W, const float *x,
-                                                         const float *dz, float *dw, float *db) {
-  __shared__ double red[256];
-  const int wid = blockIdx.x, nw = 9 * ci_n * co_n;
-  const size_t per = (size_t)H * W, total = (size_t)n * per;
-  double acc = 0.0;
-  if (wid < nw) {
-    const int co = wid % co_n, ci = (wid / co_n) % ci_n, kx = (wid / (co_n * ci_n)) % 3, ky = wid / (co_n * ci_n * 3);
-    for (size_t e = threadIdx.x; e < total; e += 256) {
-      const int s = e / per, yy = (e - (size_t)s * per) / W, xx = e % W;
-      const int y = yy + ky - 1, xq = xx + kx - 1;
-      if (y < 0 || y >= H || xq < 0 || xq >= W) continue;
-      acc += (double)x[(((size_t)s * ci_n + ci) * H + y) * W + xq] * (double)dz[(((size_t)s * co_n + co) * H + yy) * W + xx];
-    }
-  } else {
-    const int co = wid - nw;
-    for (size_t e = threadIdx.x; e < total; e += 256) {
-      const int s = e / per;
-      acc += (double)dz[((size_t)s * co_n + co) * per + (e - (size_t)s * per)];
+                                                         const float *dz, double *part) {
+  // block = one (ci, co) pair x one of gridDim.y slices of the (n, H, W) sum: dz is read once for the nine taps (and the
+  // bias, by the ci == 0 blocks); part[slice][wid], combined in fixed order by t_conv_bwd_finish
+  __shared__ double red[4][10];
+  const int co = blockIdx.x % co_n, ci = blockIdx.x / co_n, nw = 9 * ci_n * co_n;
+  const size_t per = (size_t)H * W, total = (size_t)n * per, stride = (size_t)gridDim.y * 256;
+  double acc[10];
+#pragma unroll
+  for (int k = 0; k < 10; k++) acc[k] = 0.0;
+  for (size_t e = (size_t)blockIdx.y * 256 + threadIdx.x; e < total; e += stride) {
+    const int s = e / per, yy = (e - (size_t)s * per) / W, xx = e % W;
+    const double g = dz[((size_t)s * co_n + co) * per + (size_t)yy * W + xx];
+    const float *xs = x + ((size_t)s * ci_n + ci) * per;
+    acc[9] += g;
+#pragma unroll
+    for (int ky = 0; ky < 3; ky++) {
+      const int y = yy + ky - 1;
+      if (y < 0 || y >= H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; kx++) {
+        const int xq = xx + kx - 1;
+        if (xq >= 0 && xq < W) acc[ky * 3 + kx] += (double)xs[(size_t)y * W + xq] * g;
+      }
     }
   }
-  red[threadIdx.x] = acc;
+#pragma unroll
+  for (int k = 0; k < 10; k++) {
+    double v = acc[k];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
+  }
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-    __syncthreads();
+  if (threadIdx.x < 10) {
+    const int k = threadIdx.x;
+    const double v = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+    double *row = part + (size_t)blockIdx.y * (nw + co_n);
+    if (k < 9) row[(k * ci_n + ci) * co_n + co] = v;
+    else if (ci == 0) row[nw + co] = v;
   }
-  if (threadIdx.x == 0) {
-    if (wid < nw) dw[wid] = (float)red[0];
-    else db[wid - nw] = (float)red[0];
-  }
+}
+
+__global__ void t_conv_bwd_finish(int nw, int nb, int slices, const double *part, float *dw, float *db) {
+  const int wid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (wid >= nw + nb) return;
+  double acc = 0.0;
+  for (int k = 0; k < slices; k++) acc += part[(size_t)k * (nw + nb) + wid];
+  if (wid < nw) dw[wid] = (float)acc;
+  else db[wid - nw] = (float)acc;
 }
 
 // per-channel sums over (n, H, W): out[c] += {sum a, sum a*b} (b may be null -> sum a*a); double accumulation,
@@ -329,11 +347,31 @@ __global__ void t_moving(int c_n, float *mean, float *var, const float *stat) {
 
 struct Arena {  // bump allocator over one hipMalloc
   char *base; size_t used, cap;
-  float *f(size_t n) { float *p = (float *)(base + used); used += (n * 4 + 255) & ~(size_t)255; return p; }
-  double *d(size_t n) { double *p = (double *)(base + used); used += (n * 8 + 255) & ~(size_t)255; return p; }
+  bool over = false;
+  char *take(size_t bytes) {
+    char *p = base + used;
+    used += (bytes + 255) & ~(size_t)255;
+    if (used > cap) { over = true; used = 0; p = base; }   // never hand out memory past the block; the caller checks `over`
+    return p;
+  }
+  float *f(size_t n) { return (float *)take(n * 4); }
+  double *d(size_t n) { return (double *)take(n * 8); }
 };
 
 static const int kTI[4] = {2, 8, 8, 8}, kUI[4] = {1, 2, 4, 8}, kUO[4] = {2, 4, 8, 1};
+
+static const int kWSlices = 64;
+
+static void conv_bwd_weight(hipStream_t st, int n, int ci, int co, int H, int W, const float *x, const float *dz,
+                            double *part, float *dw, float *db) {
+  const int nw = 9 * ci * co;
+  // few weights over many pixels (out2, upconv3) need the slices to fill the chip; small maps do not
+  const size_t total = (size_t)n * H * W;
+  int slices = (int)((total + 16383) / 16384);
+  slices = slices < 1 ? 1 : slices > kWSlices ? kWSlices : slices;
+  hipLaunchKernelGGL(t_conv_bwd_weight, dim3(ci * co, slices), dim3(256), 0, st, n, ci, co, H, W, x, dz, part);
+  hipLaunchKernelGGL(t_conv_bwd_finish, dim3((nw + co + 255) / 256), dim3(256), 0, st, nw, co, slices, part, dw, db);
+}
 
 extern "C" int ofx_dqn_fit(ofx_handle *h, float *weights, float *adam_m, float *adam_v, int32_t step, float lr, int32_t n,
                            const ofx_transition *rows, const void *bits_prev, const float *y_act, const float *y_ptr,
@@ -359,7 +397,7 @@ extern "C" int ofx_dqn_fit(ofx_handle *h, float *weights, float *adam_m, float *
     sz(N * 8 * 160000); sz(N * 160000);               // up4, o2
     sz(N * 8 * 160000); sz(N * 8 * 160000);           // two gradient scratch planes of the largest size
     sz(N * 5008); sz(N * 100); sz(N * 100); sz(N * 50); sz(N * 2); sz(N * 625); sz(N * 160000);
-    sz(L.n_floats); sz(64); need += 65536 + 16 * 64 * 8;
+    sz(L.n_floats); sz(64); need += 65536 + 16 * 64 * 8 + (size_t)kWSlices * 600 * 8;
   }
   void *raw = nullptr;
   OFX_HIP(hipMalloc(&raw, need));
@@ -371,6 +409,7 @@ extern "C" int ofx_dqn_fit(ofx_handle *h, float *weights, float *adam_m, float *
   float *loss = A.f(64);
   OFX_HIP(hipMemsetAsync(loss, 0, 64 * sizeof(float), st));
   double *sums = A.d(16 * 16);
+  double *wpart = A.d((size_t)kWSlices * 600);
   auto G = [&](int t) { return grad + L.offset[t]; };
 
   // ---- forward (training mode) ----
@@ -420,7 +459,7 @@ extern "C" int ofx_dqn_fit(ofx_handle *h, float *weights, float *adam_m, float *
 
   // ---- backward: head 2 ----
   float *gA = A.f(N * 8 * 160000), *gB = A.f(N * 8 * 160000);  // gradient scratch (largest tensors)
-  hipLaunchKernelGGL(t_conv_bwd_weight, dim3(9 * 8 * 1 + 1), dim3(256), 0, st, n, 8, 1, 400, 400, up4, do2, G(50), G(51));
+  conv_bwd_weight(st, n, 8, 1, 400, 400, up4, do2, wpart, G(50), G(51));
   K(t_conv_bwd_data, N * 8 * 160000, n, 8, 1, 400, 400, do2, T(50), gA);   // d up4
   float *dcur = gB;                                                          // d ua[2]
   OFX_HIP(hipMemsetAsync(dcur, 0, N * 8 * 40000 * 4, st));
@@ -433,8 +472,7 @@ extern "C" int ofx_dqn_fit(ofx_handle *h, float *weights, float *adam_m, float *
     hipLaunchKernelGGL(t_chan_sums, dim3(kUO[j], 64), dim3(256), 0, st, n, kUO[j], per, dcur, xh, sums);
     float *dz = ua[j];                                                       // the activation is dead now: holds dz
     K(t_bn_bwd, tot, n, kUO[j], per, dcur, xh, ustat[j], T(34 + 6 * j), sums, dz, G(34 + 6 * j), G(35 + 6 * j));
-    hipLaunchKernelGGL(t_conv_bwd_weight, dim3(9 * kUI[j] * kUO[j] + kUO[j]), dim3(256), 0, st, n, kUI[j], kUO[j], s, s,
-                       uu[j], dz, G(32 + 6 * j), G(33 + 6 * j));
+    conv_bwd_weight(st, n, kUI[j], kUO[j], s, s, uu[j], dz, wpart, G(32 + 6 * j), G(33 + 6 * j));
     float *duu = gA;                                                         // d (upsampled input)
     K(t_conv_bwd_data, N * kUI[j] * per, n, kUI[j], kUO[j], s, s, dz, T(32 + 6 * j), duu);
     float *dprev = gB;                                                       // d (previous activation / u0)
@@ -473,12 +511,17 @@ extern "C" int ofx_dqn_fit(ofx_handle *h, float *weights, float *adam_m, float *
     float *dz = ta[i];
     K(t_bn_bwd, tot, n, 8, per, da, xh, tstat[i], T(6 * i + 2), sums, dz, G(6 * i + 2), G(6 * i + 3));
     const float *xin = i == 0 ? x0 : tp[i - 1];
-    hipLaunchKernelGGL(t_conv_bwd_weight, dim3(9 * kTI[i] * 8 + 8), dim3(256), 0, st, n, kTI[i], 8, s, s, xin, dz, G(6 * i),
-                       G(6 * i + 1));
+    conv_bwd_weight(st, n, kTI[i], 8, s, s, xin, dz, wpart, G(6 * i), G(6 * i + 1));
     if (i > 0) {
       dp = gB;                                                               // d tp[i-1] [n][8][s][s]
       K(t_conv_bwd_data, N * 8 * per, n, 8, 8, s, s, dz, T(6 * i), dp);
     }
+  }
+  if (A.over) {  // sizing bug guard: nothing has touched the weights yet
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(raw);
+    ofx_set_error("ofx_dqn_fit: internal workspace sized too small");
+    return OFX_ERR_STATE;
   }
   if (grad_out) OFX_HIP(hipMemcpyAsync(grad_out, grad, sizeof(float) * L.n_floats, hipMemcpyDeviceToDevice, st));
 
