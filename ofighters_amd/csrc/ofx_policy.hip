@@ -24,12 +24,35 @@
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
+#include <utility>
+
+#ifndef OFX_HTB_UNROLL
+#define OFX_HTB_UNROLL 1  // stage B of k_head_tail: unroll factor of the M-tile pair loop
+#endif
+#ifndef OFX_HTC_H64
+#define OFX_HTC_H64 0     // stage C: second LDS read of a row as b64 instead of b128
+#endif
+#ifndef OFX_HTC_FENCE
+#define OFX_HTC_FENCE 1   // stage C of k_head_tail: hard scheduling fences between the pipeline steps
+#endif
+#ifndef OFX_HTC_GROUP
+#define OFX_HTC_GROUP 0   // ... and the read / MFMA order inside a step (measured slower with the fences)
+#endif
 
 #include "ofx_internal.h"
 
 #define PS 400 /* the model's fixed input side: Input((DEFAULT_WIDTH, DEFAULT_HEIGHT, 2)) */
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int N, class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &f) {
+  static_for_impl<N>(f, std::make_integer_sequence<int, N>{});
+}
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static const int kTrunkCin[4] = {2, 8, 8, 8};
@@ -545,11 +568,14 @@ __global__ __launch_bounds__(((TH / 2) * (TW / 4) + 63) / 64 * 64) void k_conv8(
 }
 
 // max without the canonicalising v_max(x, x) the compiler puts in front of fmaxf() in IEEE mode (x is an MFMA
-// result here, never a signalling NaN)
+// result here, never a signalling NaN): med3(x, floor, +inf).  NOT inline assembly: the compiler's hazard recogniser
+// does not look inside an asm statement, so an asm v_max placed right behind the MFMA that produces x reads the
+// register before the matrix pipe has written it (seen as wrong cells under one scheduling variant).
+// The +inf comes out of an opaque scalar move: with a literal the optimiser folds med3 back into the canonicalising max.
 __device__ __forceinline__ float max_raw(float x, float floor) {
-  float r;
-  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(floor), "v"(x));
-  return r;
+  float pinf;
+  asm("s_mov_b32 %0, 0x7f800000" : "=s"(pinf));
+  return __builtin_amdgcn_fmed3f(x, floor, pinf);
 }
 
 // ---- trunk convolution on the matrix cores ---------------------------------------------------------------------
@@ -721,14 +747,14 @@ __global__ __launch_bounds__(256) void k_convm(ConvParams p) {
     __syncthreads();
     if (i + 1 < TPW) fetch(t + 1);
 
-    // epilogue of an M-tile: x-pool + ReLU in one v_max3, y-pool = max with the DPP quad swap [1,0,3,2] (rows r = 0 / 1
+    // epilogue of an M-tile: x-pool + ReLU (two v_med3), y-pool = max with the DPP quad swap [1,0,3,2] (rows r = 0 / 1
     // sit in lanes n, n ^ 1), one 8-byte store from the r = 0 lanes
     float *const obase = OUT_HWC ? p.out + (((size_t)img * H2 + (ty0 >> 1)) * W2 + (tx0 >> 1) + 2 * kq) * 8 + co
                                  : p.out + (((size_t)img * 8 + co) * H2 + (ty0 >> 1)) * W2 + (tx0 >> 1) + 2 * kq;
     auto finish = [&](const f32x4 d, int g, int tt) {
       float q0, q1;
-      asm("v_max3_f32 %0, %1, %2, 0" : "=v"(q0) : "v"(d[0]), "v"(d[1]));
-      asm("v_max3_f32 %0, %1, %2, 0" : "=v"(q1) : "v"(d[2]), "v"(d[3]));
+      q0 = max_raw(max_raw(d[0], 0.f), d[1]);  // compiler-visible reads of the MFMA result (see max_raw)
+      q1 = max_raw(max_raw(d[2], 0.f), d[3]);
       q0 = max_raw(q0, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, q0), 0xB1, 0xF, 0xF, true)));
       q1 = max_raw(q1, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, q1), 0xB1, 0xF, 0xF, true)));
       const int px = ((tx0 + 16 * g) >> 1) + 2 * kq;
@@ -852,7 +878,7 @@ __global__ __launch_bounds__(256) void k_conv1_lut(ConvParams p, const float *lu
     const unsigned off = (unsigned)(py * W2 + pxx);
 #pragma unroll
     for (int co = 0; co < 8; co++) {
-      float m;
+      float m;  // the operands are ordinary VALU results (interlocked), not MFMA results: asm is safe here
       asm("v_max3_f32 %0, %1, %2, 0" : "=v"(m) : "v"(acc[0][co >> 2][co & 3]), "v"(acc[1][co >> 2][co & 3]));
       asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(acc[2][co >> 2][co & 3]), "v"(acc[3][co >> 2][co & 3]), "v"(m));
       if (!(p.ablate & 4)) (obase + (size_t)co * (H / 2) * W2)[off] = m;
@@ -1214,7 +1240,7 @@ constexpr int HT_LB1 = HT_L2 + 2;           // level-2 frame-line length (x' in 
 __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
   __shared__ __align__(16) float l2[4 * HT_L2P];
   __shared__ __align__(16) float u3f[4 * HT_U3PL];
-  __shared__ __align__(16) float w4s[8][36];
+  __shared__ __align__(16) float w4s[8][4][12];       // [channel][phase][tap, padded to 12: three aligned b128 per lane]
   __shared__ float wfr[192 + 288 + 72 + 72];        // border passes: efr | w3raw [9][4][8] | w4raw [9][8] | w2raw [9][2][4]
   __shared__ float l1[2 * HT_L1P];                  // uprelu1 patch 14 x 14 x 2, clamp-extended
   __shared__ float hb1[2][HT_LB1], vb1[2][HT_LB1];  // U1[0|99][x'] , U1[y'][0|99]: level-2 frame lines (border tiles)
@@ -1232,8 +1258,8 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
   const bool top = r0 == 0, bot = r0 + HT_T == HT_S3, hline = top || bot;
   {
     const float wa = p.w4eff[tid], wb = tid < 32 ? p.w4eff[256 + tid] : 0.f;
-    (&w4s[0][0])[tid] = wa;
-    if (tid < 32) (&w4s[0][0])[256 + tid] = wb;
+    w4s[tid / 36][(tid % 36) / 9][tid % 9] = wa;
+    if (tid < 32) w4s[(256 + tid) / 36][((256 + tid) % 36) / 9][(256 + tid) % 9] = wb;
     if (tid < 192) wfr[tid] = p.efr[tid];
     for (int e = tid; e < 288 + 72 + 72; e += 256)
       wfr[192 + e] = e < 288 ? p.w3raw[e] : e < 360 ? p.w4raw[e - 288] : p.w2raw[e - 360];
@@ -1456,7 +1482,7 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
             f[0] = (cf && fc_i == 0) ? -INFINITY : rf; f[1] = (cf && fc_i == 1) ? -INFINITY : rf; f[2] = f[3] = rf;
           }
         };
-#pragma unroll 1
+#pragma unroll OFX_HTB_UNROLL
         for (int it = 0; it < 4; it++) {
           const int mt0 = wv + 8 * it, mt1 = mt0 + 4;
           const float *a0 = arow + atab[mt0 * 16 + n16];  // A row = quad m + (lane & 15), k = 4 j + kq
@@ -1584,26 +1610,62 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
     // D[phase][pixel] += W[k][phase] * in[pixel][k] -- an M = 4, N = 64, K = 1 step with N = 4 phases exactly (no
     // padding) and not a single VALU instruction.  36 steps per half and group.
     if (!(p.ablate & 4)) {
-      float wa[36];  // A operands: lane i < 4 holds phase i
-#pragma unroll
-      for (int k = 0; k < 36; k++) wa[k] = w4s[4 * half + k / 9][(lane & 3) * 9 + k % 9];
+      // Software pipeline: the two LDS rows of step t + 2 (step = channel, tap row: 12 MFMAs = 96 matrix-pipe cycles)
+      // and the 3 x b128 weights of the next channel are requested before the MFMAs of step t; the scheduling groups
+      // pin that order (left alone the compiler issues each read right before its first use and waits for it).
+      const f32x4 *wrow = reinterpret_cast<const f32x4 *>(&w4s[4 * half][lane & 3][0]);  // A: lane i < 4 = phase i
 #pragma unroll
       for (int q = 0; q < 2; q++) {
         if (q == 1 && !pass1) break;
+        const float *base = u3f + coff[q];
+        f32x4 L[3], H[3];
+        f32x4 W[2][3];
+        auto ldrow = [&](int t) {  // two b128 (of the second only .xy is used: a b64 would get merged across steps)
+          const float *row = base + (t / 3) * HT_U3PL + (t % 3) * HT_U3S;
+          L[t % 3] = *reinterpret_cast<const f32x4 *>(row);
+#if OFX_HTC_H64
+          const f32x2 h2 = *reinterpret_cast<const f32x2 *>(row + 4);
+          H[t % 3][0] = h2[0];
+          H[t % 3][1] = h2[1];
+#else
+          H[t % 3] = *reinterpret_cast<const f32x4 *>(row + 4);
+#endif
+        };
+        auto ldw = [&](int cl) {
 #pragma unroll
-        for (int cl = 0; cl < 4; cl++)
+          for (int i = 0; i < 3; i++) W[cl & 1][i] = wrow[cl * 12 + i];
+        };
+        ldw(0);
+        ldrow(0);
+        ldrow(1);
+#if OFX_HTC_FENCE
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        auto step = [&](auto TT) {
+          constexpr int t = decltype(TT)::value, cl = t / 3, a = t % 3;
+          if (t + 2 < 12) ldrow(t + 2);
+          if (a == 0 && cl + 1 < 4) ldw(cl + 1);
+          const float v[6] = {L[a][0], L[a][1], L[a][2], L[a][3], H[a][0], H[a][1]};
 #pragma unroll
-          for (int a = 0; a < 3; a++) {
-            const float *row = u3f + coff[q] + cl * HT_U3PL + a * HT_U3S;
-            const float4 lo = *reinterpret_cast<const float4 *>(row);
-            const float4 hi = *reinterpret_cast<const float4 *>(row + 4);
-            const float v[6] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y};
+          for (int b = 0; b < 3; b++) {
+            const int k = a * 3 + b;
+            const float w = W[cl & 1][k >> 2][k & 3];
 #pragma unroll
-            for (int b = 0; b < 3; b++)
-#pragma unroll
-              for (int g = 0; g < 4; g++)  // 4 independent accumulator chains
-                cacc[q][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[cl * 9 + a * 3 + b], v[g + b], cacc[q][g], 4, 0, 0);
+            for (int g = 0; g < 4; g++)  // 4 independent accumulator chains
+              cacc[q][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(w, v[g + b], cacc[q][g], 4, 0, 0);
           }
+#if OFX_HTC_GROUP
+          constexpr int nread = (t + 2 < 12 ? 2 : 0) + (a == 0 && cl + 1 < 4 ? 3 : 0);
+          if constexpr (nread > 0) __builtin_amdgcn_sched_group_barrier(0x100, nread, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+#endif
+#if OFX_HTC_FENCE == 1
+          __builtin_amdgcn_sched_barrier(0);
+#elif OFX_HTC_FENCE == 2
+          if constexpr (a == 2) __builtin_amdgcn_sched_barrier(0);  // one fence per channel
+#endif
+        };
+        static_for<12>(step);
       }
     }
     if (!(p.ablate & 16)) __syncthreads();  // the tile is overwritten by the next half
