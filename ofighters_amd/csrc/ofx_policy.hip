@@ -30,7 +30,10 @@
 #define OFX_HTB_UNROLL 1  // stage B of k_head_tail: unroll factor of the M-tile pair loop
 #endif
 #ifndef OFX_HTC_H64
-#define OFX_HTC_H64 0     // stage C: second LDS read of a row as b64 instead of b128
+#define OFX_HTC_H64 1     // stage C: second LDS read of a row as b64 instead of b128
+#endif
+#ifndef OFX_HTB_WEARLY
+#define OFX_HTB_WEARLY 0  // stage B weights: 0 loaded at the top of stage B, 1 at the top of the tile, 2 behind stage A
 #endif
 #ifndef OFX_HTC_FENCE
 #define OFX_HTC_FENCE 1   // stage C of k_head_tail: hard scheduling fences between the pipeline steps
@@ -1337,6 +1340,17 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
   // tensor never exists either ----
   const int jb1 = c0 / 4 - 2;
   const int fc2_q0 = (lef && pb3 == 0) ? 0 : (rig && pb3 == 1) ? 8 : -1, fc2_i = lef ? 1 : 2;
+  // stage-B weights of the first channel half: requested here, a whole stage A ahead of their use (they come from
+  // global memory / L2; loaded at the top of stage B the first MFMAs of every half waited for them)
+  float bw[9], bias3;
+  auto load_bw = [&](int half) {
+#pragma unroll
+    for (int j = 0; j < 9; j++) bw[j] = p.w3mf[(half * 36 + 4 * j + kq) * 16 + n16];
+    bias3 = p.b3[4 * half + cl3];
+  };
+#if OFX_HTB_WEARLY == 1
+  load_bw(0);
+#endif
   {
 #pragma unroll
     for (int u = 0; u < 2; u++)
@@ -1367,6 +1381,9 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
       for (int i = 0; i < 4; i++) w[2 * i] = max_raw(d[i], (cf && fc2_i == i) ? -INFINITY : rf);
     }
   }
+#if OFX_HTB_WEARLY == 2
+  load_bw(0);  // in flight across the barrier (and the level-2 border passes)
+#endif
   __syncthreads();
   if (border) {
     // level-2 frame: lines of the upsampled uprelu1 plane, then the zero-padding correction of the frame cells of
@@ -1465,10 +1482,9 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
   for (int half = 0; half < 2; half++) {
     // ---- stage B: 4 channels of the uprelu3 tile on the matrix cores ----
     if (!(p.ablate & 2)) {
-      float bw[9];
-#pragma unroll
-      for (int j = 0; j < 9; j++) bw[j] = p.w3mf[(half * 36 + 4 * j + kq) * 16 + n16];
-      const float bias3 = p.b3[4 * half + cl3];
+#if OFX_HTB_WEARLY == 0
+      load_bw(half);
+#endif
       const f32x4 binit = {bias3, bias3, bias3, bias3};
       // two M-tiles per iteration, their MFMA chains interleaved (16x16x4: 32-cycle issue, 40-cycle dependent
       // latency -> two independent accumulators keep the matrix pipe full)
@@ -1668,6 +1684,9 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
         static_for<12>(step);
       }
     }
+#if OFX_HTB_WEARLY
+    if (half == 0) load_bw(1);  // in flight across the barrier
+#endif
     if (!(p.ablate & 16)) __syncthreads();  // the tile is overwritten by the next half
   }
 
