@@ -40,6 +40,25 @@ class Trainer:
     def decay_epsilon(self):
         self.epsilon.next()
 
+    def save(self, id=None, overwrite=False, folder="networks", name=None):
+        """qlearnIA_V2.py:289-298 (`keras-model-<name>[-<id>]` under the networks folder).  The file is an .npz of
+        the tensors in `model.get_weights()` order (policy_weights.to_keras): h5py / Keras are not needed to write
+        it and `model.set_weights(list(np.load(f).values()))` reads it back on the Keras side."""
+        import os
+        from .policy_weights import save_npz
+        fname = "keras-model-" + (name or "ofx") + ("-" + str(id) if id else "") + ".npz"
+        os.makedirs(folder, exist_ok=True)
+        path = os.path.join(folder, fname)
+        if os.path.exists(path) and not overwrite:
+            raise Exception("%s exists (overwrite=False)" % path)
+        save_npz(path, self.weights)
+        return path
+
+    def load(self, path):
+        """Weights exported from the reference's Keras model: np.savez(path, *model.get_weights())."""
+        from .policy_weights import load_npz
+        self.weights = load_npz(path)
+
     def remember(self, state, iaction, ipointer, reward, next_state, done):
         """qlearnIA_V2.py:237-238"""
         self.memory.append([state, iaction, ipointer, reward, next_state, done])
