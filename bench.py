@@ -92,7 +92,13 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # OFX_DIST_BACKEND=gloo: rehearsal of the launch path with several ranks on ONE card (RCCL refuses two ranks
+        # on the same device); the measured runs use RCCL
+        backend = os.environ.get("OFX_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from ofighters_amd import ArenaBatch, _native as nat
 
