@@ -35,6 +35,9 @@
 #ifndef OFX_HTB_WEARLY
 #define OFX_HTB_WEARLY 0  // stage B weights: 0 loaded at the top of stage B, 1 at the top of the tile, 2 behind stage A
 #endif
+#ifndef OFX_HTC_MINI
+#define OFX_HTC_MINI 0    // stage C: the last 16 lane-tasks of a tile as 64 one-pixel lanes instead of a 7th wave-pass (passes the tests; measured neutral: 26.6-26.8 vs 26.6 ms)
+#endif
 #ifndef OFX_HTC_FENCE
 #define OFX_HTC_FENCE 1   // stage C of k_head_tail: hard scheduling fences between the pipeline steps
 #endif
@@ -1466,11 +1469,23 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
   // MFMA B operands); 400 such lane-tasks per tile = pass 0 (all 256 lanes) + pass 1 (144 lanes of the three
   // non-light waves).  cacc[pass][pixel] = the 4 output phases of that pixel's heat-map quad, bias pre-loaded.
   constexpr int CT = (HT_T * HT_T) / 4;          // 400 lane-tasks
+  const int hrank = wv - (wv > light ? 1 : 0);   // rank of a non-light wave: 0, 1, 2
+#if OFX_HTC_MINI
+  // pass 1 = tasks 256..383 on the non-light waves of rank 0 and 1 (all lanes busy); the last 16 tasks (64 pixels, tile
+  // rows 38 / 39) go to the rank-2 wave as one pixel per lane: 36 MFMAs per half instead of the 144 of a wave-pass
+  // with 48 idle lanes
+  const bool pass1 = wv != light && hrank < 2;   // wave-uniform
+  const bool mini = wv != light && hrank == 2;
+  const int mtask = 6 * 64 + (lane >> 2), mrow = mtask / (HT_T / 4), mcol = 4 * (mtask % (HT_T / 4)) + (lane & 3);
+  const int moff = u3o(0, mrow, mcol);
+  f32x4 macc = {bias4, bias4, bias4, bias4};
+#else
   const bool pass1 = wv != light;                // wave-uniform
+#endif
   int ctask[2], coff[2];                         // task, LDS offset of its window origin inside a channel plane
   f32x4 cacc[2][4];
   ctask[0] = tid;
-  ctask[1] = min(256 + (wv - (wv > light ? 1 : 0)) * 64 + lane, CT - 1);
+  ctask[1] = min(256 + hrank * 64 + lane, CT - 1);
 #pragma unroll
   for (int q = 0; q < 2; q++) {
     coff[q] = u3o(0, ctask[q] / (HT_T / 4), 4 * (ctask[q] % (HT_T / 4)));
@@ -1683,6 +1698,22 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
         };
         static_for<12>(step);
       }
+#if OFX_HTC_MINI
+      if (mini) {  // one pixel per lane: three taps of a row are three consecutive floats (unaligned: b32 reads)
+        const float *base = u3f + moff;
+#pragma unroll
+        for (int cl = 0; cl < 4; cl++) {
+          f32x4 Wm[3];
+#pragma unroll
+          for (int i = 0; i < 3; i++) Wm[i] = wrow[cl * 12 + i];
+          float v[9];
+#pragma unroll
+          for (int k = 0; k < 9; k++) v[k] = base[cl * HT_U3PL + (k / 3) * HT_U3S + (k % 3)];
+#pragma unroll
+          for (int k = 0; k < 9; k++) macc = __builtin_amdgcn_mfma_f32_4x4x1f32(Wm[k >> 2][k & 3], v[k], macc, 4, 0, 0);
+        }
+      }
+#endif
     }
 #if OFX_HTB_WEARLY
     if (half == 0) load_bw(1);  // in flight across the barrier
@@ -1713,11 +1744,36 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
       }
     }
   }
+#if OFX_HTC_MINI
+  if (border && mini) {
+    if (hline && mrow == (top ? 0 : HT_T - 1)) {
+#pragma unroll
+      for (int b = 0; b < 2; b++) {
+        const float c = facc[0][2 * mcol + b];
+        if (top) macc[b] -= c; else macc[2 + b] -= c;
+      }
+    }
+    if (vline && mcol == (lef ? 0 : HT_T - 1)) {
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        const float c = facc[1][2 * mrow + r];
+        if (lef) macc[2 * r] -= c; else macc[2 * r + 1] -= c;
+      }
+    }
+  }
+#endif
   if (p.heat) {
+#if OFX_HTC_MINI
+    if (mini) {
+#pragma unroll
+      for (int ph = 0; ph < 4; ph++)
+        p.heat[(size_t)s * PS * PS + (size_t)(2 * (r0 + mrow) + (ph >> 1)) * PS + 2 * (c0 + mcol) + (ph & 1)] = macc[ph];
+    }
+#endif
 #pragma unroll
     for (int q = 0; q < 2; q++) {
       const int task = q * 256 + tid;  // a light wave's q = 1 registers hold nothing
-      const bool mine = q == 0 ? true : (pass1 && 256 + (wv - (wv > light ? 1 : 0)) * 64 + lane < CT);
+      const bool mine = q == 0 ? true : (pass1 && 256 + hrank * 64 + lane < CT);
       if (!mine) continue;
       (void)task;
       const int li = r0 + ctask[q] / (HT_T / 4), lj0 = c0 + 4 * (ctask[q] % (HT_T / 4));
@@ -1730,6 +1786,13 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
   }
   if (p.ptr_probe) {  // block-uniform; one pixel per ship: the lane that owns it stores it
     const int pk = p.probe[2 * s + 1] * PS + p.probe[2 * s];
+#if OFX_HTC_MINI
+    if (mini) {
+#pragma unroll
+      for (int ph = 0; ph < 4; ph++)
+        if ((2 * (r0 + mrow) + (ph >> 1)) * PS + 2 * (c0 + mcol) + (ph & 1) == pk) p.ptr_probe[s] = macc[ph];
+    }
+#endif
 #pragma unroll
     for (int q = 0; q < 2; q++) {
       if (q == 1 && !pass1) break;
@@ -1761,9 +1824,23 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
             ts = gt ? (q * 16 + r * 8 + g * 2 + b) : ts;
           }
     }
+#if OFX_HTC_MINI
+    if (mini) {  // the one-pixel task lies in tile rows 38 / 39, behind every pass-0 task of this wave in C order
+#pragma unroll
+      for (int ph = 0; ph < 4; ph++) {
+        const float val = macc[ph];
+        const bool gt = val > tv;
+        tv = gt ? val : tv;
+        ts = gt ? 32 + ph : ts;
+      }
+    }
+#endif
     const int task = (ts & 16) ? ctask[1] : ctask[0];
     const int lt = task / (HT_T / 4), c4 = task - lt * (HT_T / 4);
-    const int y = 2 * (r0 + lt) + ((ts >> 3) & 1), x = 2 * (c0 + 4 * c4 + ((ts >> 1) & 3)) + (ts & 1);
+    int y = 2 * (r0 + lt) + ((ts >> 3) & 1), x = 2 * (c0 + 4 * c4 + ((ts >> 1) & 3)) + (ts & 1);
+#if OFX_HTC_MINI
+    if (ts & 32) { y = 2 * (r0 + mrow) + ((ts >> 1) & 1); x = 2 * (c0 + mcol) + (ts & 1); }
+#endif
     const unsigned k = (unsigned)(y * PS + x);
     if (tv > bestv || (tv == bestv && k < bestk)) { bestv = tv; bestk = k; }
   }
