@@ -401,6 +401,10 @@ extern "C" int ofx_dqn_fit(ofx_handle *h, float *weights, float *adam_m, float *
   }
   void *raw = nullptr;
   OFX_HIP(hipMalloc(&raw, need));
+  struct Release {  // the error paths below return early: the block must not leak (and must not be freed under running kernels)
+    void *p; hipStream_t st;
+    ~Release() { if (p) { (void)hipStreamSynchronize(st); (void)hipFree(p); } }
+  } release{raw, st};
   Arena A{(char *)raw, 0, need};
   const float *W_ = weights;
   auto T = [&](int t) { return weights + L.offset[t]; };
@@ -518,8 +522,6 @@ extern "C" int ofx_dqn_fit(ofx_handle *h, float *weights, float *adam_m, float *
     }
   }
   if (A.over) {  // sizing bug guard: nothing has touched the weights yet
-    (void)hipStreamSynchronize(st);
-    (void)hipFree(raw);
     ofx_set_error("ofx_dqn_fit: internal workspace sized too small");
     return OFX_ERR_STATE;
   }
@@ -543,6 +545,5 @@ extern "C" int ofx_dqn_fit(ofx_handle *h, float *weights, float *adam_m, float *
   OFX_HIP(hipStreamSynchronize(st));
   if (loss_host) { loss_host[0] = lh[0]; loss_host[1] = lh[1]; }
   (void)W_;
-  OFX_HIP(hipFree(raw));
-  return OFX_OK;
+  return OFX_OK;  // `release` frees the block (the stream is idle: synchronised above)
 }
