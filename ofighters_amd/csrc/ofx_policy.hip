@@ -38,6 +38,9 @@
 #ifndef OFX_HTC_MINI
 #define OFX_HTC_MINI 0    // stage C: the last 16 lane-tasks of a tile as 64 one-pixel lanes instead of a 7th wave-pass (passes the tests; measured neutral: 26.6-26.8 vs 26.6 ms)
 #endif
+#ifndef OFX_XCD_SWIZZLE
+#define OFX_XCD_SWIZZLE 0  // k_convm: contiguous tile ranges per XCD (measured neutral: conv2 2.79 ms either way)
+#endif
 #ifndef OFX_HTC_FENCE
 #define OFX_HTC_FENCE 1   // stage C of k_head_tail: hard scheduling fences between the pipeline steps
 #endif
@@ -608,7 +611,13 @@ __global__ __launch_bounds__(256) void k_convm(ConvParams p) {
   constexpr int ROWS = CIN * (TH + 2);
   constexpr bool VEC = MODE == 0 && !OUT_HWC;                // rows of W floats are 16-byte aligned (W % 4 == 0)
   __shared__ __align__(16) float tile[CIN * PLS];
-  const int first = blockIdx.x * TPW;                        // p.tiles % TPW == 0: all tiles of a workgroup share the image
+  // XCD-aware tile order: workgroup b runs on XCD b % 8 (each XCD has its own L2), so the eight XCDs take contiguous
+  // eighths of the tile list and neighbouring row tiles -- which share their halo rows -- meet in one L2
+  unsigned bid = blockIdx.x;
+#if OFX_XCD_SWIZZLE
+  if ((gridDim.x & 7u) == 0) bid = (bid & 7u) * (gridDim.x >> 3) + (bid >> 3);
+#endif
+  const int first = (int)bid * TPW;                          // p.tiles % TPW == 0: all tiles of a workgroup share the image
   const int img = first / p.tiles, t_first = first - img * p.tiles;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
