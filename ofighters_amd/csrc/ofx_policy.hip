@@ -41,6 +41,9 @@
 #ifndef OFX_XCD_SWIZZLE
 #define OFX_XCD_SWIZZLE 0  // k_convm: contiguous tile ranges per XCD (measured neutral: conv2 2.79 ms either way)
 #endif
+#ifndef OFX_CONV1_V4
+#define OFX_CONV1_V4 1    // k_conv1_lut: four pooled pixels per thread, 16-byte stores
+#endif
 #ifndef OFX_HTC_FENCE
 #define OFX_HTC_FENCE 1   // stage C of k_head_tail: hard scheduling fences between the pipeline steps
 #endif
@@ -869,6 +872,50 @@ __global__ __launch_bounds__(256) void k_conv1_lut(ConvParams p, const float *lu
   }
   __syncthreads();
   float *const obase = p.out + ((size_t)img * 8 * (H / 2) + (ty0 >> 1)) * W2;  // wave-uniform: scalar base + 32-bit offsets
+#if OFX_CONV1_V4
+  // a thread owns FOUR horizontally adjacent pooled pixels: the kernel is bound by its 5.2 GB of output, and 16-byte
+  // stores (1 KB contiguous per wave and channel plane) use the write path better than 4-byte ones (256 B)
+  constexpr int NQ = NPX / 4, QR = W2 / 4;                       // quads of the tile, quads per pooled row
+  for (int qd = tid; qd < NQ; qd += 256) {
+    const int py = qd / QR, pq = qd - py * QR;
+    const int x0 = 8 * pq;                                        // window = staged bits x0 .. x0 + 9 of rows 2 py .. 2 py + 3
+    unsigned f[2][4];
+#pragma unroll
+    for (int ci = 0; ci < 2; ci++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const unsigned *rw = &rows[ci][2 * py + r][x0 >> 5];
+        f[ci][r] = __funnelshift_r(rw[0], rw[1], (unsigned)(x0 & 31)) & 1023u;
+      }
+    f32x4 m4[8];                                                  // [channel] = the 4 pixels
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      f32x4 acc[4][2];                                            // [2x2 pixel][channels 0-3 | 4-7]
+#pragma unroll
+      for (int ci = 0; ci < 2; ci++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int dy = q >> 1, sh = 2 * j + (q & 1);
+          const unsigned pat = ((f[ci][dy] >> sh) & 7u) | (((f[ci][dy + 1] >> sh) & 7u) << 3) | (((f[ci][dy + 2] >> sh) & 7u) << 6);
+          const f32x4 *e = reinterpret_cast<const f32x4 *>(&slut[(ci * 512 + pat) * 8]);
+          if (ci == 0) { acc[q][0] = e[0]; acc[q][1] = e[1]; }    // the table of channel 0 carries the bias
+          else { acc[q][0] += e[0]; acc[q][1] += e[1]; }
+        }
+#pragma unroll
+      for (int co = 0; co < 8; co++) {
+        float m;  // the operands are ordinary VALU results (interlocked), not MFMA results: asm is safe here
+        asm("v_max3_f32 %0, %1, %2, 0" : "=v"(m) : "v"(acc[0][co >> 2][co & 3]), "v"(acc[1][co >> 2][co & 3]));
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(acc[2][co >> 2][co & 3]), "v"(acc[3][co >> 2][co & 3]), "v"(m));
+        m4[co][j] = m;
+      }
+    }
+    const unsigned off = (unsigned)(py * W2 + 4 * pq);
+    if (!(p.ablate & 4)) {
+#pragma unroll
+      for (int co = 0; co < 8; co++) *reinterpret_cast<f32x4 *>(obase + (size_t)co * (H / 2) * W2 + off) = m4[co];
+    }
+  }
+#else
   for (int px = tid; px < NPX; px += 256) {
     const int py = px / W2, pxx = px - py * W2;                   // pooled pixel of the tile
     const int x0 = 2 * pxx;                                       // window = staged bits x0 .. x0 + 3 of rows 2 py .. 2 py + 3
@@ -899,6 +946,7 @@ __global__ __launch_bounds__(256) void k_conv1_lut(ConvParams p, const float *lu
       if (!(p.ablate & 4)) (obase + (size_t)co * (H / 2) * W2)[off] = m;
     }
   }
+#endif
 }
 
 // ---- fp32 MFMA GEMM for the dense layers -------------------------------------------
