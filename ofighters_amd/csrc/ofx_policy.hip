@@ -50,6 +50,9 @@
 #ifndef OFX_HT_PIPE
 #define OFX_HT_PIPE 0     // k_head_tail: next tile patch committed at the end of the tile, two barriers per tile fewer (measured 0.15 ms SLOWER)
 #endif
+#ifndef OFX_CONVM_VOLA
+#define OFX_CONVM_VOLA 0  // k_convm: single ds_read_b32 per A operand, no ds_read2 pairing (measured SLOWER: conv2 2.84 vs 2.74 ms)
+#endif
 #ifndef OFX_HTC_FENCE
 #define OFX_HTC_FENCE 1   // stage C of k_head_tail: hard scheduling fences between the pipeline steps
 #endif
@@ -762,6 +765,17 @@ __global__ __launch_bounds__(256) void k_convm(ConvParams p) {
     return aoff[j];
   };
 
+  // One ds_read_b32 with a 16-bit immediate per operand: left alone the compiler pairs the reads into ds_read2_b32,
+  // whose 8-bit offsets cost a v_add per pair -- and VALU instructions are what this kernel is short of (they share
+  // the issue port with the MFMAs; the LDS port is idle).  volatile keeps the reads single.
+  auto lda = [&](const float *a, int j) -> float {
+#if OFX_CONVM_VOLA
+    typedef const volatile __attribute__((address_space(3))) float lds_cvf;  // stay in the LDS address space
+    return *(lds_cvf *)(a + aof(j));
+#else
+    return a[aof(j)];
+#endif
+  };
   fetch(t_first);
 #pragma unroll 1
   for (int i = 0; i < TPW; i++) {
@@ -803,11 +817,36 @@ __global__ __launch_bounds__(256) void k_convm(ConvParams p) {
         const float *a1 = abase + (2 * t1) * LS + 16 * g1;
         f32x4 d0 = binit, d1 = binit;
         if (!(p.ablate & 2)) {
+#if OFX_CONVM_VOLA
+          // volatile reads stay in program order: three batches, the reads of batch b + 2 behind the MFMAs of batch b
+          constexpr int NB = NK / 3;
+          static_assert(NK % 3 == 0, "three batches");
+          float A0[3][NB], A1[3][NB];
+          auto ldb = [&](int b) {
+#pragma unroll
+            for (int j = 0; j < NB; j++) { A0[b][j] = lda(a0, b * NB + j); A1[b][j] = lda(a1, b * NB + j); }
+          };
+          auto mmb = [&](int b) {
+#pragma unroll
+            for (int j = 0; j < NB; j++) {
+              d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[b][j], bw[b * NB + j], d0, 0, 0, 0);
+              d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[b][j], bw[b * NB + j], d1, 0, 0, 0);
+            }
+          };
+          ldb(0); ldb(1);
+          __builtin_amdgcn_sched_barrier(0);  // or the scheduler sinks every read next to its MFMA again
+          mmb(0);
+          ldb(2);
+          __builtin_amdgcn_sched_barrier(0);
+          mmb(1);
+          mmb(2);
+#else
 #pragma unroll
           for (int j = 0; j < NK; j++) {
-            d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[aof(j)], bw[j], d0, 0, 0, 0);
-            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[aof(j)], bw[j], d1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(lda(a0, j), bw[j], d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(lda(a1, j), bw[j], d1, 0, 0, 0);
           }
+#endif
         }
         finish(d0, g0, t0);
         finish(d1, g1, t1);
@@ -815,7 +854,7 @@ __global__ __launch_bounds__(256) void k_convm(ConvParams p) {
         f32x4 d0 = binit;
         if (!(p.ablate & 2)) {
 #pragma unroll
-          for (int j = 0; j < NK; j++) d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[aof(j)], bw[j], d0, 0, 0, 0);
+          for (int j = 0; j < NK; j++) d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(lda(a0, j), bw[j], d0, 0, 0, 0);
         }
         finish(d0, g0, t0);
       }
