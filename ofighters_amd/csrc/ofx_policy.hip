@@ -53,6 +53,14 @@
 #ifndef OFX_CONVM_VOLA
 #define OFX_CONVM_VOLA 0  // k_convm: single ds_read_b32 per A operand, no ds_read2 pairing (measured SLOWER: conv2 2.84 vs 2.74 ms)
 #endif
+#ifndef OFX_ABLATE_HOOKS
+#define OFX_ABLATE_HOOKS 0  // 1: the diagnostic OFX_CONV_ABLATE / OFX_HT_ABLATE switches are compiled into the kernels
+#endif
+#if OFX_ABLATE_HOOKS
+#define OFX_ABL(p) ((p).ablate)
+#else
+#define OFX_ABL(p) 0       // the hooks cost branches and, in k_convm, eight accumulator copies per M-tile pair
+#endif
 #ifndef OFX_HTC_FENCE
 #define OFX_HTC_FENCE 1   // stage C of k_head_tail: hard scheduling fences between the pipeline steps
 #endif
@@ -329,7 +337,7 @@ __global__ __launch_bounds__(((TH / 2) * (TW / 2) + 63) / 64 * 64) void k_conv(C
         const int gy = ty0 - 1 + r, gx = tx0 - 1 + c;
         if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
           if (MODE == 0) {
-            v = (p.ablate & 1) ? 1.f : p.in[(((size_t)img * CIN + ci) * H + gy) * W + gx];
+            v = (OFX_ABL(p) & 1) ? 1.f : p.in[(((size_t)img * CIN + ci) * H + gy) * W + gx];
           } else if (MODE == 1) {
             const int cell = gy * W + gx;
             v = (float)((p.bits[ci][(size_t)img * p.bits_stride + (cell >> 5)] >> (cell & 31)) & 1u);
@@ -383,7 +391,7 @@ __global__ __launch_bounds__(((TH / 2) * (TW / 2) + 63) / 64 * 64) void k_conv(C
     }
     skip = __all(flat);
   }
-  if (!skip && !(p.ablate & 2)) {
+  if (!skip && !(OFX_ABL(p) & 2)) {
 #pragma unroll
   for (int ci = 0; ci < CIN; ci++) {
     float v[4][4];
@@ -416,7 +424,7 @@ __global__ __launch_bounds__(((TH / 2) * (TW / 2) + 63) / 64 * 64) void k_conv(C
     float o00 = fmaxf(acc[0][0][co] + bias, 0.f), o01 = fmaxf(acc[0][1][co] + bias, 0.f);
     float o10 = fmaxf(acc[1][0][co] + bias, 0.f), o11 = fmaxf(acc[1][1][co] + bias, 0.f);
     if (skip) o00 = o01 = o10 = o11 = p.bg_out[co];
-    if ((p.ablate & 4) && o00 != 12345.f) continue;
+    if ((OFX_ABL(p) & 4) && o00 != 12345.f) continue;
     if (POOL) {
       const float m = fmaxf(fmaxf(o00, o01), fmaxf(o10, o11));
       const int Ho = H >> 1, Wo = W >> 1, py = oy >> 1, px = ox >> 1;
@@ -532,7 +540,7 @@ __global__ __launch_bounds__(((TH / 2) * (TW / 4) + 63) / 64 * 64) void k_conv8(
     skip = __all(flat);
   }
 #pragma unroll 1
-  for (int ci = 0; ci < ((skip || (p.ablate & 2)) ? 0 : CIN); ci++) {
+  for (int ci = 0; ci < ((skip || (OFX_ABL(p) & 2)) ? 0 : CIN); ci++) {
     float v[4][8];
 #pragma unroll
     for (int r = 0; r < 4; r++) {  // cols 4tc .. 4tc+5 of the tile: two aligned b128 reads (conflict free)
@@ -569,7 +577,7 @@ __global__ __launch_bounds__(((TH / 2) * (TW / 4) + 63) / 64 * 64) void k_conv8(
     for (int i = 0; i < 2; i++)
 #pragma unroll
       for (int j = 0; j < 4; j++) o[i][j] = skip ? p.bg_out[co] : fmaxf(acc[i][j][co] + bias, 0.f);
-    if ((p.ablate & 4) && o[0][0] != 12345.f) continue;
+    if ((OFX_ABL(p) & 4) && o[0][0] != 12345.f) continue;
     if (POOL) {
       const float m0 = fmaxf(fmaxf(o[0][0], o[0][1]), fmaxf(o[1][0], o[1][1]));
       const float m1 = fmaxf(fmaxf(o[0][2], o[0][3]), fmaxf(o[1][2], o[1][3]));
@@ -679,7 +687,7 @@ __global__ __launch_bounds__(256) void k_convm(ConvParams p) {
       // a wave moves one tile row per step: lane i < V4 the i-th float4 of the interior, lanes V4 / V4+1 the float4
       // that holds the left / right halo column
       const int gxl = lane < V4 ? tx0 + 4 * lane : (lane == V4 ? tx0 - 4 : tx0 + TW);
-      const bool colok = lane < V4 + 2 && gxl >= 0 && gxl < W && !(p.ablate & 1);
+      const bool colok = lane < V4 + 2 && gxl >= 0 && gxl < W && !(OFX_ABL(p) & 1);
       const float *imgbase = p.in + (size_t)img * CIN * H * W;
 #pragma unroll
       for (int u = 0; u < RPW; u++) {
@@ -796,7 +804,7 @@ __global__ __launch_bounds__(256) void k_convm(ConvParams p) {
       q0 = max_raw(q0, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, q0), 0xB1, 0xF, 0xF, true)));
       q1 = max_raw(q1, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, q1), 0xB1, 0xF, 0xF, true)));
       const int px = ((tx0 + 16 * g) >> 1) + 2 * kq;
-      if (r == 0 && px < W2 && !(p.ablate & 4)) {
+      if (r == 0 && px < W2 && !(OFX_ABL(p) & 4)) {
         if (OUT_HWC) {
           float *op = obase + ((size_t)tt * W2 + 8 * g) * 8;
           op[0] = q0;
@@ -816,7 +824,7 @@ __global__ __launch_bounds__(256) void k_convm(ConvParams p) {
         const int g1 = job1 % NG, t1 = job1 / NG;
         const float *a1 = abase + (2 * t1) * LS + 16 * g1;
         f32x4 d0 = binit, d1 = binit;
-        if (!(p.ablate & 2)) {
+        if (!(OFX_ABL(p) & 2)) {
 #if OFX_CONVM_VOLA
           // volatile reads stay in program order: three batches, the reads of batch b + 2 behind the MFMAs of batch b
           constexpr int NB = NK / 3;
@@ -852,7 +860,7 @@ __global__ __launch_bounds__(256) void k_convm(ConvParams p) {
         finish(d1, g1, t1);
       } else {
         f32x4 d0 = binit;
-        if (!(p.ablate & 2)) {
+        if (!(OFX_ABL(p) & 2)) {
 #pragma unroll
           for (int j = 0; j < NK; j++) d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(lda(a0, j), bw[j], d0, 0, 0, 0);
         }
@@ -955,7 +963,7 @@ __global__ __launch_bounds__(256) void k_conv1_lut(ConvParams p, const float *lu
       }
     }
     const unsigned off = (unsigned)(py * W2 + 4 * pq);
-    if (!(p.ablate & 4)) {
+    if (!(OFX_ABL(p) & 4)) {
 #pragma unroll
       for (int co = 0; co < 8; co++) *reinterpret_cast<f32x4 *>(obase + (size_t)co * (H / 2) * W2 + off) = m4[co];
     }
@@ -988,7 +996,7 @@ __global__ __launch_bounds__(256) void k_conv1_lut(ConvParams p, const float *lu
       float m;  // the operands are ordinary VALU results (interlocked), not MFMA results: asm is safe here
       asm("v_max3_f32 %0, %1, %2, 0" : "=v"(m) : "v"(acc[0][co >> 2][co & 3]), "v"(acc[1][co >> 2][co & 3]));
       asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(acc[2][co >> 2][co & 3]), "v"(acc[3][co >> 2][co & 3]), "v"(m));
-      if (!(p.ablate & 4)) (obase + (size_t)co * (H / 2) * W2)[off] = m;
+      if (!(OFX_ABL(p) & 4)) (obase + (size_t)co * (H / 2) * W2)[off] = m;
     }
   }
 #endif
@@ -1622,7 +1630,7 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
 #pragma unroll 1
   for (int half = 0; half < 2; half++) {
     // ---- stage B: 4 channels of the uprelu3 tile on the matrix cores ----
-    if (!(p.ablate & 2)) {
+    if (!(OFX_ABL(p) & 2)) {
 #if OFX_HTB_WEARLY == 0
       load_bw(half);
 #endif
@@ -1678,8 +1686,8 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
       };
       if (border) run(std::true_type{}); else run(std::false_type{});
     }
-    if (!(p.ablate & 32)) __syncthreads();
-    if (border && !(p.ablate & 8)) {
+    if (!(OFX_ABL(p) & 32)) __syncthreads();
+    if (border && !(OFX_ABL(p) & 8)) {
       // Frame cells (row/col 0 or 199 of the plane) hold G + bias without ReLU: subtract the taps that fall
       // into the conv's zero padding, sum w[tap][ci] U2[clamp] from the frame lines, then apply the ReLU.
       // Wave = local channel, lane = cell of the line: the weights are wave-uniform LDS broadcasts.
@@ -1771,7 +1779,7 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
     // A block of lanes 0-3 (the 4 phase weights of tap k) to all 16 blocks, B = one input value per lane (pixel):
     // D[phase][pixel] += W[k][phase] * in[pixel][k] -- an M = 4, N = 64, K = 1 step with N = 4 phases exactly (no
     // padding) and not a single VALU instruction.  36 steps per half and group.
-    if (!(p.ablate & 4)) {
+    if (!(OFX_ABL(p) & 4)) {
       // Software pipeline: the two LDS rows of step t + 2 (step = channel, tap row: 12 MFMAs = 96 matrix-pipe cycles)
       // and the 3 x b128 weights of the next channel are requested before the MFMAs of step t; the scheduling groups
       // pin that order (left alone the compiler issues each read right before its first use and waits for it).
@@ -1855,7 +1863,7 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
       if (tcol + 2 < tiles_x) fetch_patch(tcol + 2);
     }
 #endif
-    if (!(p.ablate & 16)) __syncthreads();  // the tile is overwritten by the next half
+    if (!(OFX_ABL(p) & 16)) __syncthreads();  // the tile is overwritten by the next half
   }
 
   // ---- outputs + arg-max (first maximum in C order) ----

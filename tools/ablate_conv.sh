@@ -1,3 +1,4 @@
+# NOTE: the hooks are compiled out of the production build: rebuild ofx_policy.o with -DOFX_ABLATE_HOOKS=1 first.
 # Stage ablation of the trunk convolutions (diagnostic): OFX_CONV_ABLATE bits 1 no global loads, 2 no MFMAs / FMAs,
 # 4 no stores.  Usage (GPU box): bash tools/ablate_conv.sh "0 1 2 4 7"
 export TMPDIR=/tmp

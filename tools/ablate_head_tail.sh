@@ -1,3 +1,4 @@
+# NOTE: the hooks are compiled out of the production build: rebuild ofx_policy.o with -DOFX_ABLATE_HOOKS=1 first.
 # Stage ablation of k_head_tail (diagnostic): OFX_HT_ABLATE bits 1 no stage-A loads, 2 no stage B, 4 no stage C,
 # 8 no border passes.  Usage (GPU box): bash tools/ablate_head_tail.sh "0 8 2 4"
 export TMPDIR=/tmp
