@@ -61,6 +61,9 @@
 #else
 #define OFX_ABL(p) 0       // the hooks cost branches and, in k_convm, eight accumulator copies per M-tile pair
 #endif
+#ifndef OFX_CONV2_SHAPE
+#define OFX_CONV2_SHAPE 0  // conv2 tile: 0 = 4 rows x 208, 1 = 4 rows x 112, 2 = 8 rows x 112
+#endif
 #ifndef OFX_HTC_FENCE
 #define OFX_HTC_FENCE 1   // stage C of k_head_tail: hard scheduling fences between the pipeline steps
 #endif
@@ -2170,7 +2173,13 @@ static int policy_forward_impl(ofx_handle *h, const float *weights, int N, int M
   cp.in = ws.p1; cp.w = ws.prep + L.tw[1]; cp.b = ws.prep + L.tb[1]; cp.out = ws.p2; cp.wbm = ws.prep + L.wbm[0];
   if (bgskip) { cp.bg_in = ws.prep + L.bg[0]; cp.bg_out = ws.prep + L.bg[1]; }
   if (trunk_valu) rc = launch_conv<8, 8, 10, 100, 0, true, false>(h, cp, N, 200);
+#if OFX_CONV2_SHAPE == 1
+  else rc = launch_convm<8, 2, 7, 0, false, 1>(h, cp, N, 200);   // half-width tiles: more, shorter workgroups
+#elif OFX_CONV2_SHAPE == 2
+  else rc = launch_convm<8, 4, 7, 0, false, 1>(h, cp, N, 200);
+#else
   else rc = launch_convm<8, 2, 13, 0, false, 1>(h, cp, N, 200);  // 29 KB of LDS: five workgroups per CU
+#endif
   if (rc) return rc;
   cp.in = ws.p2; cp.w = ws.prep + L.tw[2]; cp.b = ws.prep + L.tb[2]; cp.out = ws.p3; cp.wbm = ws.prep + L.wbm[1];
   if (bgskip) { cp.bg_in = ws.prep + L.bg[1]; cp.bg_out = ws.prep + L.bg[2]; }
