@@ -1,6 +1,6 @@
 # A/B of k_head_tail stage-C scheduling variants (diagnostic; rebuilds libofx.so on the GPU box, one variant per line)
 export TMPDIR=/tmp
-BASE="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=fast -fno-slp-vectorize -fPIC -I../../include"
+BASE="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=fast -fno-slp-vectorize -fPIC -I../../include -mllvm -amdgpu-sched-strategy=iterative-maxocc -mllvm -amdgpu-mfma-vgpr-form=true"
 i=0
 while IFS= read -r extra; do
   i=$((i+1))
