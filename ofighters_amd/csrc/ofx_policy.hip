@@ -36,7 +36,7 @@
 #define OFX_HTB_WEARLY 0  // stage B weights: 0 loaded at the top of stage B, 1 at the top of the tile, 2 behind stage A
 #endif
 #ifndef OFX_HTC_MINI
-#define OFX_HTC_MINI 0    // stage C: the last 16 lane-tasks of a tile as 64 one-pixel lanes instead of a 7th wave-pass (passes the tests; measured neutral: 26.6-26.8 vs 26.6 ms)
+#define OFX_HTC_MINI 0    // stage C: 1 = the last 16 lane-tasks of a tile as 64 one-pixel lanes instead of a 7th wave-pass (measured neutral); 2 = all of pass 1 as nine one-pixel quarter passes (1.5 ms SLOWER: four times the LDS reads per MFMA)
 #endif
 #ifndef OFX_XCD_SWIZZLE
 #define OFX_XCD_SWIZZLE 0  // k_convm: contiguous tile ranges per XCD (measured neutral: conv2 2.79 ms either way)
@@ -63,6 +63,12 @@
 #endif
 #ifndef OFX_CONV2_SHAPE
 #define OFX_CONV2_SHAPE 0  // conv2 tile: 0 = 4 rows x 208, 1 = 4 rows x 112, 2 = 8 rows x 112
+#endif
+#ifndef OFX_HT_FACC_LIGHT
+#define OFX_HT_FACC_LIGHT 1  // heat-map frame corrections of a half computed by the light wave
+#endif
+#ifndef OFX_HTA_ILP
+#define OFX_HTA_ILP 0     // k_head_tail stage A: M-tiles of a wave as interleaved MFMA chains (measured neutral)
 #endif
 #ifndef OFX_HTC_FENCE
 #define OFX_HTC_FENCE 1   // stage C of k_head_tail: hard scheduling fences between the pipeline steps
@@ -1511,13 +1517,11 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
 #endif
   {
     const f32x4 binit2 = {bias2, bias2, bias2, bias2};
-#pragma unroll 1
-    for (int mt = wv; mt < 9; mt += 4) {
+    auto arow2 = [&](int mt) -> const float * {
       const int m = 16 * mt + n16, qi = m / 12, qj = m - qi * 12;
-      const float *a = &l1[qi * HT_L1 + qj];
-      f32x4 d = binit2;
-#pragma unroll
-      for (int j = 0; j < 5; j++) d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[a2off[j]], bw2[j], d, 0, 0, 0);
+      return &l1[qi * HT_L1 + qj];
+    };
+    auto epi2 = [&](int mt, const f32x4 d) {
       // D: the 4 consecutive low-res pixels of group 16 mt + 4 kq (one row: 12 = 3 groups), column n = (phase, co)
       const int g = 16 * mt + 4 * kq, gi = g / 12, gj0 = g - gi * 12;
       const float rf = gi == fr2_qi ? -INFINITY : 0.f;  // -inf keeps a frame cell raw for the border pass
@@ -1525,7 +1529,40 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
       float *w = &l2[cl3 * HT_L2P + (2 * gi + pa3) * HT_L2 + 2 * gj0 + pb3];
 #pragma unroll
       for (int i = 0; i < 4; i++) w[2 * i] = max_raw(d[i], (cf && fc2_i == i) ? -INFINITY : rf);
+    };
+#if OFX_HTA_ILP
+    {  // M-tiles wv and wv + 4 as two interleaved chains (a lone chain of 5 dependent MFMAs is latency bound), then wave
+       // 0's third one: the wave with three M-tiles sets the length of the stage
+      const float *a0 = arow2(wv), *a1 = arow2(wv + 4);
+      f32x4 d0 = binit2, d1 = binit2;
+#pragma unroll
+      for (int j = 0; j < 5; j++) {
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[a2off[j]], bw2[j], d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[a2off[j]], bw2[j], d1, 0, 0, 0);
+      }
+      if (wv == 0) {
+        const float *a2 = arow2(8);
+        f32x4 d2 = binit2;
+#pragma unroll
+        for (int j = 0; j < 5; j++) d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[a2off[j]], bw2[j], d2, 0, 0, 0);
+        epi2(0, d0);
+        epi2(4, d1);
+        epi2(8, d2);
+      } else {
+        epi2(wv, d0);
+        epi2(wv + 4, d1);
+      }
     }
+#else
+#pragma unroll 1
+    for (int mt = wv; mt < 9; mt += 4) {
+      const float *a = arow2(mt);
+      f32x4 d = binit2;
+#pragma unroll
+      for (int j = 0; j < 5; j++) d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[a2off[j]], bw2[j], d, 0, 0, 0);
+      epi2(mt, d);
+    }
+#endif
   }
 #if OFX_HTB_WEARLY == 2
   load_bw(0);  // in flight across the barrier (and the level-2 border passes)
@@ -1607,17 +1644,32 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
   // non-light waves).  cacc[pass][pixel] = the 4 output phases of that pixel's heat-map quad, bias pre-loaded.
   constexpr int CT = (HT_T * HT_T) / 4;          // 400 lane-tasks
   const int hrank = wv - (wv > light ? 1 : 0);   // rank of a non-light wave: 0, 1, 2
-#if OFX_HTC_MINI
+#if OFX_HTC_MINI == 2
+  // no second wave-pass at all: tasks 256..399 are nine "quarter passes" of 16 tasks = 64 pixels, one pixel per lane
+  // (36 MFMAs per half each).  Ranks 0 / 1 take three, rank 2 two, the light wave one next to its 33rd M-tile and the
+  // frame lines: the longest wave runs 1.75 pass-times of stage C instead of 2
+  const bool pass1 = false;
+  const int nq = wv == light ? 1 : (hrank < 2 ? 3 : 2), k0 = wv == light ? 8 : 3 * hrank;  // wave-uniform
+#elif OFX_HTC_MINI
   // pass 1 = tasks 256..383 on the non-light waves of rank 0 and 1 (all lanes busy); the last 16 tasks (64 pixels, tile
   // rows 38 / 39) go to the rank-2 wave as one pixel per lane: 36 MFMAs per half instead of the 144 of a wave-pass
   // with 48 idle lanes
   const bool pass1 = wv != light && hrank < 2;   // wave-uniform
-  const bool mini = wv != light && hrank == 2;
-  const int mtask = 6 * 64 + (lane >> 2), mrow = mtask / (HT_T / 4), mcol = 4 * (mtask % (HT_T / 4)) + (lane & 3);
-  const int moff = u3o(0, mrow, mcol);
-  f32x4 macc = {bias4, bias4, bias4, bias4};
+  const int nq = (wv != light && hrank == 2) ? 1 : 0, k0 = 8;
 #else
   const bool pass1 = wv != light;                // wave-uniform
+#endif
+#if OFX_HTC_MINI
+  int mrow[3], mcol[3], moff[3];                 // quarter-pass slot i < nq: tasks 256 + 16 (k0 + i) .. + 15
+  f32x4 macc[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const int mt = min(256 + 16 * (k0 + i) + (lane >> 2), CT - 1);
+    mrow[i] = mt / (HT_T / 4);
+    mcol[i] = 4 * (mt % (HT_T / 4)) + (lane & 3);
+    moff[i] = u3o(0, mrow[i], mcol[i]);
+    macc[i] = (f32x4){bias4, bias4, bias4, bias4};
+  }
 #endif
   int ctask[2], coff[2];                         // task, LDS offset of its window origin inside a channel plane
   f32x4 cacc[2][4];
@@ -1742,12 +1794,20 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
       // In phase form along the line (PrepLayout::efr): pixel 2j + b gets sum_o E[b][o] L[j + o - 1] of the
       // clamp-extended low-res frame row / column L of the tile.  Wave 0 = horizontal line, wave 1 = vertical line,
       // lane = j; the other two waves go straight to stage C.
-      if (wv < 2 && lane < HT_T && (wv ? vline : hline)) {
-        const int side = wv ? (lef ? 0 : 1) : (top ? 0 : 1);
-        const float *E = &wfr[(wv * 2 + side) * 48 + 4 * half];  // [b][o][ci]
+#if OFX_HT_FACC_LIGHT
+      // both lines on the LIGHT wave: it runs one stage-C pass where the others run two, so the lines ride in its slack
+      // instead of lengthening the chain of waves 0 and 1
+      for (int ln = 0; ln < 2; ln++) {
+        if (!(wv == light && lane < HT_T && (ln ? vline : hline))) continue;
+#else
+      for (int ln = 0; ln < 2; ln++) {  // wave 0 = horizontal line, wave 1 = vertical line
+        if (!(wv == ln && lane < HT_T && (ln ? vline : hline))) continue;
+#endif
+        const int side = ln ? (lef ? 0 : 1) : (top ? 0 : 1);
+        const float *E = &wfr[(ln * 2 + side) * 48 + 4 * half];  // [b][o][ci]
         const int R = (top ? 0 : HT_S3 - 1) - (r0 - 1), Cc = (lef ? 0 : HT_S3 - 1) - (c0 - 1);
-        const float *L = u3f + (wv ? u3o(0, lane, Cc) : u3o(0, R, lane));  // sample j - 1
-        const int st = wv ? HT_U3S : 1;
+        const float *L = u3f + (ln ? u3o(0, lane, Cc) : u3o(0, R, lane));  // sample j - 1
+        const int st = ln ? HT_U3S : 1;
         float e0 = 0.f, e1 = 0.f;
 #pragma unroll
         for (int cl = 0; cl < 4; cl++)
@@ -1757,7 +1817,7 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
             e0 += E[o * 8 + cl] * v;
             e1 += E[(3 + o) * 8 + cl] * v;
           }
-        if (wv == 1) {  // corner pixels: the conv row outside the image is counted with the horizontal line
+        if (ln == 1) {  // corner pixels: the conv row outside the image is counted with the horizontal line
           const float *w4 = &wfr[192 + 288 + 4 * half];
           const int tcol = lef ? 0 : 2;
           if (top && lane == 0)
@@ -1768,11 +1828,11 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
             for (int cl = 0; cl < 4; cl++) e1 -= w4[(2 * 3 + tcol) * 8 + cl] * u3f[u3o(cl, HT_T, Cc)];
         }
         if (half == 0) {  // every entry a tile reads is written in both halves: no zeroing pass
-          facc[wv][2 * lane] = e0;
-          facc[wv][2 * lane + 1] = e1;
+          facc[ln][2 * lane] = e0;
+          facc[ln][2 * lane + 1] = e1;
         } else {
-          facc[wv][2 * lane] += e0;
-          facc[wv][2 * lane + 1] += e1;
+          facc[ln][2 * lane] += e0;
+          facc[ln][2 * lane + 1] += e1;
         }
       }
     }
@@ -1841,20 +1901,33 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
         static_for<12>(step);
       }
 #if OFX_HTC_MINI
-      if (mini) {  // one pixel per lane: three taps of a row are three consecutive floats (unaligned: b32 reads)
-        const float *base = u3f + moff;
+      // one pixel per lane: three taps of a row are three consecutive floats (unaligned: b32 reads); the slots of a
+      // wave are independent MFMA chains and share the weights
+      auto quarters = [&](auto NQ) {
+        constexpr int nqc = decltype(NQ)::value;
 #pragma unroll
         for (int cl = 0; cl < 4; cl++) {
           f32x4 Wm[3];
 #pragma unroll
           for (int i = 0; i < 3; i++) Wm[i] = wrow[cl * 12 + i];
-          float v[9];
 #pragma unroll
-          for (int k = 0; k < 9; k++) v[k] = base[cl * HT_U3PL + (k / 3) * HT_U3S + (k % 3)];
+          for (int a = 0; a < 3; a++) {
+            float v[nqc][3];
 #pragma unroll
-          for (int k = 0; k < 9; k++) macc = __builtin_amdgcn_mfma_f32_4x4x1f32(Wm[k >> 2][k & 3], v[k], macc, 4, 0, 0);
+            for (int i = 0; i < nqc; i++)
+#pragma unroll
+              for (int b = 0; b < 3; b++) v[i][b] = u3f[moff[i] + cl * HT_U3PL + a * HT_U3S + b];
+#pragma unroll
+            for (int b = 0; b < 3; b++)
+#pragma unroll
+              for (int i = 0; i < nqc; i++)
+                macc[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(Wm[(3 * a + b) >> 2][(3 * a + b) & 3], v[i][b], macc[i], 4, 0, 0);
+          }
         }
-      }
+      };
+      if (nq == 3) quarters(std::integral_constant<int, 3>{});
+      else if (nq == 2) quarters(std::integral_constant<int, 2>{});
+      else if (nq == 1) quarters(std::integral_constant<int, 1>{});
 #endif
     }
 #if OFX_HTB_WEARLY
@@ -1893,29 +1966,35 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
     }
   }
 #if OFX_HTC_MINI
-  if (border && mini) {
-    if (hline && mrow == (top ? 0 : HT_T - 1)) {
+  if (border) {
 #pragma unroll
-      for (int b = 0; b < 2; b++) {
-        const float c = facc[0][2 * mcol + b];
-        if (top) macc[b] -= c; else macc[2 + b] -= c;
+    for (int i = 0; i < 3; i++) {
+      if (i >= nq) break;  // wave-uniform
+      if (hline && mrow[i] == (top ? 0 : HT_T - 1)) {
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+          const float c = facc[0][2 * mcol[i] + b];
+          if (top) macc[i][b] -= c; else macc[i][2 + b] -= c;
+        }
       }
-    }
-    if (vline && mcol == (lef ? 0 : HT_T - 1)) {
+      if (vline && mcol[i] == (lef ? 0 : HT_T - 1)) {
 #pragma unroll
-      for (int r = 0; r < 2; r++) {
-        const float c = facc[1][2 * mrow + r];
-        if (lef) macc[2 * r] -= c; else macc[2 * r + 1] -= c;
+        for (int r = 0; r < 2; r++) {
+          const float c = facc[1][2 * mrow[i] + r];
+          if (lef) macc[i][2 * r] -= c; else macc[i][2 * r + 1] -= c;
+        }
       }
     }
   }
 #endif
   if (p.heat) {
 #if OFX_HTC_MINI
-    if (mini) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      if (i >= nq) break;
 #pragma unroll
       for (int ph = 0; ph < 4; ph++)
-        p.heat[(size_t)s * PS * PS + (size_t)(2 * (r0 + mrow) + (ph >> 1)) * PS + 2 * (c0 + mcol) + (ph & 1)] = macc[ph];
+        p.heat[(size_t)s * PS * PS + (size_t)(2 * (r0 + mrow[i]) + (ph >> 1)) * PS + 2 * (c0 + mcol[i]) + (ph & 1)] = macc[i][ph];
     }
 #endif
 #pragma unroll
@@ -1935,10 +2014,12 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
   if (p.ptr_probe) {  // block-uniform; one pixel per ship: the lane that owns it stores it
     const int pk = p.probe[2 * s + 1] * PS + p.probe[2 * s];
 #if OFX_HTC_MINI
-    if (mini) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      if (i >= nq) break;
 #pragma unroll
       for (int ph = 0; ph < 4; ph++)
-        if ((2 * (r0 + mrow) + (ph >> 1)) * PS + 2 * (c0 + mcol) + (ph & 1) == pk) p.ptr_probe[s] = macc[ph];
+        if ((2 * (r0 + mrow[i]) + (ph >> 1)) * PS + 2 * (c0 + mcol[i]) + (ph & 1) == pk) p.ptr_probe[s] = macc[i][ph];
     }
 #endif
 #pragma unroll
@@ -1973,13 +2054,16 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
           }
     }
 #if OFX_HTC_MINI
-    if (mini) {  // the one-pixel task lies in tile rows 38 / 39, behind every pass-0 task of this wave in C order
+    // the one-pixel tasks (>= 256, in increasing order) lie behind every pass-0 / pass-1 task of this lane in C order
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      if (i >= nq) break;
 #pragma unroll
       for (int ph = 0; ph < 4; ph++) {
-        const float val = macc[ph];
+        const float val = macc[i][ph];
         const bool gt = val > tv;
         tv = gt ? val : tv;
-        ts = gt ? 32 + ph : ts;
+        ts = gt ? 32 + 4 * i + ph : ts;
       }
     }
 #endif
@@ -1987,7 +2071,12 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
     const int lt = task / (HT_T / 4), c4 = task - lt * (HT_T / 4);
     int y = 2 * (r0 + lt) + ((ts >> 3) & 1), x = 2 * (c0 + 4 * c4 + ((ts >> 1) & 3)) + (ts & 1);
 #if OFX_HTC_MINI
-    if (ts & 32) { y = 2 * (r0 + mrow) + ((ts >> 1) & 1); x = 2 * (c0 + mcol) + (ts & 1); }
+    if (ts & 32) {
+      const int i = (ts >> 2) & 3;
+      const int mr = i == 0 ? mrow[0] : i == 1 ? mrow[1] : mrow[2], mc = i == 0 ? mcol[0] : i == 1 ? mcol[1] : mcol[2];
+      y = 2 * (r0 + mr) + ((ts >> 1) & 1);
+      x = 2 * (c0 + mc) + (ts & 1);
+    }
 #endif
     const unsigned k = (unsigned)(y * PS + x);
     if (tv > bestv || (tv == bestv && k < bestk)) { bestv = tv; bestk = k; }
