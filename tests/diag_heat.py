@@ -1,7 +1,7 @@
 """Diagnostic: where does the GPU heat map differ from the CPU restatement?  (uses oracle/ as the checker)"""
 import sys, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # repo root
 from ofighters_amd import ArenaBatch, _native as nat
 from oracle import pyoracle
 
