@@ -70,6 +70,9 @@
 #ifndef OFX_HTA_ILP
 #define OFX_HTA_ILP 0     // k_head_tail stage A: M-tiles of a wave as interleaved MFMA chains (measured neutral)
 #endif
+#ifndef OFX_HTB_TRIPLE
+#define OFX_HTB_TRIPLE 0  // stage B: the 33rd M-tile as a third chain of the light wave last iteration (measured 0.15 ms slower)
+#endif
 #ifndef OFX_HTC_FENCE
 #define OFX_HTC_FENCE 1   // stage C of k_head_tail: hard scheduling fences between the pipeline steps
 #endif
@@ -1702,8 +1705,16 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
             f[0] = (cf && fc_i == 0) ? -INFINITY : rf; f[1] = (cf && fc_i == 1) ? -INFINITY : rf; f[2] = f[3] = rf;
           }
         };
-#pragma unroll OFX_HTB_UNROLL
-        for (int it = 0; it < 4; it++) {
+        auto epiB = [&](int mt, const f32x4 d) {
+          // D: col = lane & 15, row = 4 (lane >> 4) + reg -> the 4 consecutive quads of group mt * 4 + kq
+          const unsigned g = gtab[mt * 4 + kq];
+          float f[4];
+          floors(g, f);
+          float *w = (float *)(wbase + (g & 0xFFFFu));
+#pragma unroll
+          for (int i = 0; i < 4; i++) w[2 * i] = max_raw(d[i], f[i]);
+        };
+        auto pairB = [&](int it) {
           const int mt0 = wv + 8 * it, mt1 = mt0 + 4;
           const float *a0 = arow + atab[mt0 * 16 + n16];  // A row = quad m + (lane & 15), k = 4 j + kq
           const float *a1 = arow + atab[mt1 * 16 + n16];
@@ -1713,31 +1724,44 @@ __global__ __launch_bounds__(256, 3) void k_head_tail(HeadTailParams p) {
             d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[(j / 3) * HT_L2 + (j % 3)], bw[j], d0, 0, 0, 0);
             d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[(j / 3) * HT_L2 + (j % 3)], bw[j], d1, 0, 0, 0);
           }
-          // D: col = lane & 15, row = 4 (lane >> 4) + reg -> the 4 consecutive quads of group mt * 4 + kq
-          const unsigned g0 = gtab[mt0 * 4 + kq], g1 = gtab[mt1 * 4 + kq];
-          float f0[4], f1[4];
-          floors(g0, f0);
-          floors(g1, f1);
-          float *w0 = (float *)(wbase + (g0 & 0xFFFFu));
-          float *w1 = (float *)(wbase + (g1 & 0xFFFFu));
+          epiB(mt0, d0);
+          epiB(mt1, d1);
+        };
+#if OFX_HTB_TRIPLE
+        // the light wave's odd 33rd M-tile rides as a third chain in its last iteration instead of a lone chain of
+        // nine dependent MFMAs behind the loop: the wave with nine M-tiles sets the length of stage B
+#pragma unroll 1
+        for (int it = 0; it < 3; it++) pairB(it);
+        if (wv == light) {
+          const int mt0 = wv + 24, mt1 = mt0 + 4, mt2 = HT_MT - 1;
+          const float *a0 = arow + atab[mt0 * 16 + n16];
+          const float *a1 = arow + atab[mt1 * 16 + n16];
+          const float *a2 = arow + atab[mt2 * 16 + n16];
+          f32x4 d0 = binit, d1 = binit, d2 = binit;
 #pragma unroll
-          for (int i = 0; i < 4; i++) w0[2 * i] = max_raw(d0[i], f0[i]);
-#pragma unroll
-          for (int i = 0; i < 4; i++) w1[2 * i] = max_raw(d1[i], f1[i]);
+          for (int j = 0; j < 9; j++) {
+            d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[(j / 3) * HT_L2 + (j % 3)], bw[j], d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[(j / 3) * HT_L2 + (j % 3)], bw[j], d1, 0, 0, 0);
+            d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[(j / 3) * HT_L2 + (j % 3)], bw[j], d2, 0, 0, 0);
+          }
+          epiB(mt0, d0);
+          epiB(mt1, d1);
+          epiB(mt2, d2);
+        } else {
+          pairB(3);
         }
+#else
+#pragma unroll OFX_HTB_UNROLL
+        for (int it = 0; it < 4; it++) pairB(it);
         if (wv == light) {  // the odd 33rd M-tile: one chain
           const float *a0 = arow + atab[(HT_MT - 1) * 16 + n16];
           f32x4 d0 = binit;
 #pragma unroll
           for (int j = 0; j < 9; j++)
             d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[(j / 3) * HT_L2 + (j % 3)], bw[j], d0, 0, 0, 0);
-          const unsigned g0 = gtab[(HT_MT - 1) * 4 + kq];
-          float f0[4];
-          floors(g0, f0);
-          float *w0 = (float *)(wbase + (g0 & 0xFFFFu));
-#pragma unroll
-          for (int i = 0; i < 4; i++) w0[2 * i] = max_raw(d0[i], f0[i]);
+          epiB(HT_MT - 1, d0);
         }
+#endif
       };
       if (border) run(std::true_type{}); else run(std::false_type{});
     }
