@@ -1,0 +1,28 @@
+// ofx_head.h - head-2 tail of the bi-head policy (upconv2 -> upconv3 -> upconv4 -> arg-max) as a row-streaming
+// kernel pair (ofx_head.hip); called by policy_forward_impl (ofx_policy.hip).
+#pragma once
+#include "ofx_internal.h"
+
+struct HeadParams2 {
+  int S;                        // policy samples (ships)
+  const float *up1;             // planar [S][2][50][50] uprelu1
+  const float *w2mf, *b2;       // upconv2 phase weights [20][16] (PrepLayout::w2mf), folded bias [4]
+  const float *w2raw;           // BN-folded upconv2 kernel [9][2][4]
+  const float *w3mf, *b3;       // upconv3 phase weights [2][36][16] (PrepLayout::w3mf), folded bias [8]
+  const float *w3raw;           // BN-folded upconv3 kernel [9][4][8]
+  const float *w4eff_c, *b4;    // upconv4 phase weights [ci 8][phase 4][tap 9], bias [1]
+  const float *w4raw;           // upconv4 kernel [9][8]
+  float *u2fr;                  // [S][4][100][4] exact frame lines of uprelu2: row 0, row 99, col 0, col 99
+  float *u3fr;                  // [S][4][200][8] exact frame lines of uprelu3
+  float *c4;                    // [S][4][400]   zero-padding corrections of the heat-map frame pixels
+  const uint8_t *mask;          // [S] or null
+  unsigned long long *best;     // [S] packed (ordered value << 32) | ~index, zeroed by the caller
+  float *heat;                  // [S][400][400] or null
+  const int32_t *probe;         // [S][2] (x, y) or null
+  float *ptr_probe;             // [S] heat-map value at the probe
+};
+
+// bytes of the three frame buffers for S samples
+size_t ofx_head_frame_bytes(size_t S, size_t *u2fr, size_t *u3fr, size_t *c4);
+// k_head_frames + k_head_stream on the handle's stream
+int ofx_launch_head(ofx_handle *h, const HeadParams2 &p);

@@ -1,0 +1,591 @@
+// ofx_head.hip - head-2 tail of the bi-head "pointer_model" (agents/qlearnIA_V2.py:170-188 + the arg-max glue of
+// :218-220): [bilinear x2 + conv 2->4 + BN + ReLU] -> [bilinear x2 + conv 4->8 + BN + ReLU] -> [bilinear x2 +
+// conv 8->1] -> arg-max, per policy ship, as a ROW-STREAMING kernel for gfx950.  fp32 (exact f32 MFMAs).
+//
+// A x2 bilinear upsample followed by a 3x3 convolution is, per output parity (phase), a 3x3 convolution on the
+// low-resolution grid with pre-combined weights (k_policy_prepare), so no upsampled tensor is ever formed:
+//   stage A  uprelu2 (100x100x4) from uprelu1: GEMM  [pixel][phase*4+co] , K = 9 taps x 2 ci      v_mfma_f32_16x16x4
+//   stage B  uprelu3 (200x200x8) from uprelu2: GEMM  [quad][phase*4+co] x 2 channel halves, K = 36  v_mfma_f32_16x16x4
+//   stage C  heat map (400x400)  from uprelu3: per pixel out[phase] = sum_k W[k][phase] in[k], K = 72: v_mfma_f32_4x4x1
+//            (16 blocks, the A block broadcast with CBSZ / ABID: M = 4 phases, N = 64 pixels, no padded dimension)
+//
+// k_head_stream: one 512-thread workgroup streams a 100-column half of one ship's plane top to bottom.  uprelu3 and
+// uprelu2 live only as ROLLING WINDOWS of rows in LDS (16-row rings); waves 0-3 produce (stage A + B), waves 4-7
+// consume (stage C + arg-max) two sub-steps behind, ONE barrier per sub-step of 5 uprelu3 rows.  Nothing of the
+// 42 GB uprelu3 tensor or the 5 GB uprelu2 tensor (32768 ships) touches HBM.  The schedule (lags, ring sizes) is
+// checked by tools/head_schedule.py.
+//
+// Zero padding: the phase form sees the clamp-extended low-resolution plane, which differs from Keras' zero padding
+// only on the 1-pixel frame of each layer's output.  k_head_frames computes those thin lines exactly (frame lines of
+// uprelu2 / uprelu3, correction lines of the heat map) in a small pre-pass; k_head_stream overwrites the frame cells
+// of its rings with the exact values and starts the heat-map accumulators of frame pixels at bias - correction.
+#include "ofx_head.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define HD_PS 400
+
+// max without the canonicalising v_max(x, x) of fmaxf(); compiler-visible (never feed an MFMA result to inline asm:
+// the hazard recogniser does not look inside an asm statement)
+__device__ __forceinline__ float hd_max_raw(float x, float floor) {
+  float pinf;
+  asm("s_mov_b32 %0, 0x7f800000" : "=s"(pinf));
+  return __builtin_amdgcn_fmed3f(x, floor, pinf);
+}
+
+__device__ __forceinline__ unsigned hd_ordered_f32(float v) {
+  const unsigned u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_head_frames: exact frame lines.  One workgroup per ship.
+// ---------------------------------------------------------------------------------------------------------------
+
+// x2 half-pixel bilinear with edge clamp along a line of n samples, at up-res index u in [-1, 2n]:
+// even u = 2k -> L[k-1] + (L[k] - L[k-1]) * .75 ; odd u = 2k+1 -> L[k] + (L[k+1] - L[k]) * .25  (oracle: upsample2)
+__device__ __forceinline__ void hf_taps(int u, int n, int &ka, int &kb, float &w) {
+  const int k = u >> 1;  // arithmetic: u = -1 -> k = -1
+  if (u & 1) { ka = k; kb = k + 1; w = 0.25f; } else { ka = k - 1; kb = k; w = 0.75f; }
+  ka = min(max(ka, 0), n - 1);
+  kb = min(max(kb, 0), n - 1);
+}
+__device__ __forceinline__ float hf_up(const float *L, int stride, int n, int u) {
+  int ka, kb; float w;
+  hf_taps(u, n, ka, kb, w);
+  const float a = L[ka * stride], b = L[kb * stride];
+  return a + (b - a) * w;
+}
+
+constexpr int HF_THREADS = 512;
+// LDS map of k_head_frames (floats).  Region A is used twice: uprelu1 + its up-sampled bands, later the up-sampled
+// bands of uprelu2.
+constexpr int HF_L1 = 0;                       // l1[2][50][50]
+constexpr int HF_U1R = HF_L1 + 5000;           // U1r[6][2][102]: up-res rows {0,1,2,97,98,99}, zero-extended columns (index x + 1)
+constexpr int HF_U1C = HF_U1R + 6 * 2 * 102;   // U1c[6][2][102]: up-res columns, zero-extended rows (index y + 1)
+constexpr int HF_A_END = HF_U1C + 6 * 2 * 102; // 7448
+constexpr int HF_U2R = 0;                      // U2r[4][4][202]: up-res rows {0,1,198,199} of uprelu2 (index x + 1)
+constexpr int HF_U2C = HF_U2R + 4 * 4 * 202;   // U2c[4][4][202]
+static_assert(HF_U2C + 4 * 4 * 202 <= HF_A_END, "region A");
+constexpr int HF_B2R = HF_A_END;               // u2rb[4][100][4]: uprelu2 rows {0,1,98,99}
+constexpr int HF_B2C = HF_B2R + 1600;          // u2cb[4][100][4]: uprelu2 columns {0,1,98,99}, [band][y][ch]
+constexpr int HF_U3L = HF_B2C + 1600;          // u3l[4][200][8]: exact frame lines of uprelu3 (top, bottom, left, right)
+constexpr int HF_TOTAL = HF_U3L + 6400;        // 17048 floats = 68 KB
+
+__global__ __launch_bounds__(HF_THREADS) void k_head_frames(HeadParams2 p) {
+  __shared__ __align__(16) float sm[HF_TOTAL];
+  const int s = blockIdx.x, tid = threadIdx.x;
+  if (p.mask && !p.mask[s]) return;  // block-uniform
+  float *l1 = sm + HF_L1, *U1r = sm + HF_U1R, *U1c = sm + HF_U1C, *U2r = sm + HF_U2R, *U2c = sm + HF_U2C;
+  float *u2rb = sm + HF_B2R, *u2cb = sm + HF_B2C, *u3l = sm + HF_U3L;
+
+  for (int e = tid; e < 5000; e += HF_THREADS) l1[e] = p.up1[(size_t)s * 5000 + e];
+  __syncthreads();
+
+  // ---- up-sampled bands of uprelu1 (100x100 domain), zero outside the image ----
+  for (int e = tid; e < 2 * 6 * 2 * 102; e += HF_THREADS) {
+    const int t = e % 102 - 1, ci = (e / 102) % 2, b = (e / 204) % 6, isc = e / 1224;
+    const int f = b < 3 ? b : b + 94;  // the band's fixed up-res coordinate
+    float v = 0.f;
+    if (t >= 0 && t < 100) {
+      const int Y = isc ? t : f, X = isc ? f : t;
+      int ya, yb, xa, xb; float wy, wx;
+      hf_taps(Y, 50, ya, yb, wy);
+      hf_taps(X, 50, xa, xb, wx);
+      const float *pl = l1 + ci * 2500;
+      const float a = pl[ya * 50 + xa], bq = pl[ya * 50 + xb], d = pl[yb * 50 + xa], g = pl[yb * 50 + xb];
+      const float top = a + (bq - a) * wx, bot = d + (g - d) * wx;
+      v = top + (bot - top) * wy;
+    }
+    (isc ? U1c : U1r)[(b * 2 + ci) * 102 + t + 1] = v;
+  }
+  __syncthreads();
+
+  // ---- uprelu2 on its 2-wide frame bands, from the definition (zero padding) ----
+  for (int e = tid; e < 2 * 4 * 100 * 4; e += HF_THREADS) {
+    const int co = e % 4, t = (e / 4) % 100, b = (e / 400) % 4, isc = e / 1600;
+    const int f = b < 2 ? b : b + 96;  // row (or column) of the band
+    float acc = p.b2[co];
+#pragma unroll
+    for (int d0 = 0; d0 < 3; d0++) {   // offset along the band's fixed axis
+      const int u = f + d0 - 1;         // up-res coordinate on that axis
+      if (u < 0 || u > 99) continue;    // zero padding
+      const int ub = u < 3 ? u : u - 94;
+#pragma unroll
+      for (int d1 = 0; d1 < 3; d1++)
+#pragma unroll
+        for (int ci = 0; ci < 2; ci++) {
+          const int dy = isc ? d1 : d0, dx = isc ? d0 : d1;
+          const float uv = (isc ? U1c : U1r)[(ub * 2 + ci) * 102 + t + d1];  // index (t + d1 - 1) + 1
+          acc += p.w2raw[((dy * 3 + dx) * 2 + ci) * 4 + co] * uv;
+        }
+    }
+    (isc ? u2cb : u2rb)[(b * 100 + t) * 4 + co] = fmaxf(acc, 0.f);
+  }
+  __syncthreads();
+  if (tid < 16) {  // the corner cells exist in both bands: one value (row band wins)
+    const int co = tid & 3, c = tid >> 2;  // corners: (row 0 | 99) x (col 0 | 99)
+    const int rb = (c & 1) ? 3 : 0, x = (c & 2) ? 99 : 0;
+    const int cb = (c & 2) ? 3 : 0, y = (c & 1) ? 99 : 0;
+    u2cb[(cb * 100 + y) * 4 + co] = u2rb[(rb * 100 + x) * 4 + co];
+  }
+  __syncthreads();
+  for (int e = tid; e < 4 * 100 * 4; e += HF_THREADS) {  // lines: row 0, row 99, col 0, col 99
+    const int ln = e / 400, r = e - ln * 400;
+    p.u2fr[(size_t)s * 1600 + e] = ln < 2 ? u2rb[(ln ? 3 : 0) * 400 + r] : u2cb[(ln == 3 ? 3 : 0) * 400 + r];
+  }
+
+  // ---- up-sampled bands of uprelu2 (200x200 domain), zero outside: rows / columns {0,1,198,199} ----
+  // (region A is dead: every read of l1 / U1 was in front of the barriers above)
+  for (int e = tid; e < 2 * 4 * 4 * 202; e += HF_THREADS) {
+    const int t = e % 202 - 1, ci = (e / 202) % 4, b = (e / 808) % 4, isc = e / 3232;
+    const int f = b < 2 ? b : b + 196;
+    float v = 0.f;
+    if (t >= 0 && t < 200) {
+      int fa, fb, ta, tb; float wf, wt;
+      hf_taps(f, 100, fa, fb, wf);  // band axis: source rows (columns) fa, fb are inside the 2-wide band
+      hf_taps(t, 100, ta, tb, wt);
+      const int ba = fa < 2 ? fa : fa - 96, bb = fb < 2 ? fb : fb - 96;
+      const float *src = isc ? u2cb : u2rb;
+      const float a = src[(ba * 100 + ta) * 4 + ci], bq = src[(ba * 100 + tb) * 4 + ci];
+      const float d = src[(bb * 100 + ta) * 4 + ci], g = src[(bb * 100 + tb) * 4 + ci];
+      // oracle order: x first, then y
+      if (!isc) {  // rows: band axis = y
+        const float top = a + (bq - a) * wt, bot = d + (g - d) * wt;
+        v = top + (bot - top) * wf;
+      } else {     // columns: band axis = x ; a = (x fa, y ta), bq = (fa, tb), d = (fb, ta), g = (fb, tb)
+        const float top = a + (d - a) * wf, bot = bq + (g - bq) * wf;
+        v = top + (bot - top) * wt;
+      }
+    }
+    (isc ? U2c : U2r)[(b * 4 + ci) * 202 + t + 1] = v;
+  }
+  __syncthreads();
+
+  // ---- exact frame lines of uprelu3: top (y = 0), bottom (y = 199), left (x = 0), right (x = 199) ----
+  for (int e = tid; e < 4 * 200 * 8; e += HF_THREADS) {
+    const int co = e % 8, t = (e / 8) % 200, ln = e / 1600, isc = ln >> 1;
+    const int f = (ln & 1) ? 199 : 0;
+    float acc = p.b3[co];
+#pragma unroll
+    for (int d0 = 0; d0 < 3; d0++) {
+      const int u = f + d0 - 1;
+      if (u < 0 || u > 199) continue;
+      const int ub = u < 2 ? u : u - 196;
+#pragma unroll
+      for (int d1 = 0; d1 < 3; d1++)
+#pragma unroll
+        for (int ci = 0; ci < 4; ci++) {
+          const int dy = isc ? d1 : d0, dx = isc ? d0 : d1;
+          const float uv = (isc ? U2c : U2r)[(ub * 4 + ci) * 202 + t + d1];
+          acc += p.w3raw[((dy * 3 + dx) * 4 + ci) * 8 + co] * uv;
+        }
+    }
+    u3l[(ln * 200 + t) * 8 + co] = fmaxf(acc, 0.f);
+  }
+  __syncthreads();
+  if (tid < 32) {  // corners: the row lines win
+    const int co = tid & 7, c = tid >> 3;
+    const int rl = (c & 1) ? 1 : 0, x = (c & 2) ? 199 : 0;
+    const int cl = (c & 2) ? 3 : 2, y = (c & 1) ? 199 : 0;
+    u3l[(cl * 200 + y) * 8 + co] = u3l[(rl * 200 + x) * 8 + co];
+  }
+  __syncthreads();
+  for (int e = tid; e < 6400; e += HF_THREADS) p.u3fr[(size_t)s * 6400 + e] = u3l[e];
+
+  // ---- corrections of the heat-map frame pixels: the taps of upconv4 that fall into the zero padding, evaluated
+  // on the clamp-extended up-sampled plane the phase form sees there ----
+  for (int e = tid; e < 4 * 400; e += HF_THREADS) {
+    const int ln = e / 400, t = e - ln * 400, isc = ln >> 1, side = ln & 1;
+    float acc = 0.f;
+    if (!isc || (t > 0 && t < 399)) {  // the corner pixels are counted with the row lines
+      const int d0 = side ? 2 : 0;      // the tap row (column) outside the image
+#pragma unroll
+      for (int d1 = 0; d1 < 3; d1++)
+#pragma unroll
+        for (int ci = 0; ci < 8; ci++) {
+          const int tap = isc ? d1 * 3 + d0 : d0 * 3 + d1;
+          acc += p.w4raw[tap * 8 + ci] * hf_up(u3l + ln * 1600 + ci, 8, 200, t + d1 - 1);
+        }
+      if (!isc && (t == 0 || t == 399)) {  // corner: the two taps of the column outside the image, rows inside
+        const int cl = t ? 3 : 2, dx = t ? 2 : 0;
+        for (int dy = 0; dy < 3; dy++) {
+          if (dy == d0) continue;            // already counted with the row
+          const int yy = (side ? 399 : 0) + dy - 1;
+          if (yy < 0 || yy > 399) continue;  // cannot happen (dy == d0 covers it)
+          for (int ci = 0; ci < 8; ci++) acc += p.w4raw[(dy * 3 + dx) * 8 + ci] * hf_up(u3l + cl * 1600 + ci, 8, 200, yy);
+        }
+      }
+    }
+    p.c4[(size_t)s * 1600 + e] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_head_stream
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int HS_GPR = 13;               // groups of 4 quads per quad row: 50 quads + 1 halo + 1 pad
+constexpr int HS_NTILES = 325;           // 16-quad M-tiles of a strip (100 quad rows x 13 groups / 4)
+constexpr int HS_NS = 42;                // sub-steps
+constexpr int HS_NR3 = 16, HS_P3 = 106;  // uprelu3 ring: rows, row pitch (column x at index x - c0 + 1 + 4 side)
+constexpr int HS_PL3 = HS_NR3 * HS_P3 + 4;   // channel plane stride (floats)
+// uprelu2 ring (column c at index c - (side ? 46 : -1)): 16 row slots + 2 mirror slots (16, 17 repeat 0, 1), so the
+// three rows of a window are always contiguous and the A gather of stage B is one base address + immediates
+constexpr int HS_NR2 = 16, HS_P2 = 56;
+constexpr int HS_PL2 = (HS_NR2 + 2) * HS_P2 + 16;  // +16: the channel planes of the MFMA A-gather land on different banks
+// uprelu2 row pairs finished by the end of sub-step s - 1 (index s; index 0 = prologue): tools/head_schedule.py
+__device__ const unsigned char kStageADone[HS_NS + 1] = {2, 3, 5, 6, 7, 8, 10, 11, 12, 13, 15, 16, 17, 18, 20, 21, 22, 23, 25, 26, 27, 28, 30,
+                                                        31, 32, 33, 35, 36, 37, 38, 40, 41, 42, 43, 45, 46, 47, 48, 50, 50, 50, 50, 50};
+
+__device__ __forceinline__ int hs_tiles_done(int s) {  // tiles finished by the end of sub-step s
+  return s < 0 ? 0 : min(HS_NTILES, 8 * (s + 1) + ((s + 1) >> 3));
+}
+
+// LDS reads of stage C: two 8-byte reads of one row.  volatile keeps them apart (merged into one ds_read2_b64 they
+// take 8 LDS cycles instead of 2 + 2, MI355X_MICROARCH.md) and in program order (the pipeline below is explicit)
+typedef const volatile __attribute__((address_space(3))) f32x2 hs_lds_v2;
+
+// uprelu2 store: row slot + its mirror
+__device__ __forceinline__ void hs_u2_store(float *u2r, int ch, int row, int col, float v) {
+  const int slot = (row + 1) & (HS_NR2 - 1);
+  float *q = &u2r[ch * HS_PL2 + slot * HS_P2 + col];
+  q[0] = v;
+  if (slot < 2) q[HS_NR2 * HS_P2] = v;
+}
+
+__global__ __launch_bounds__(512, 4) void k_head_stream(HeadParams2 p) {
+  __shared__ __align__(16) float u3r[8 * HS_PL3];
+  __shared__ __align__(16) float u2r[4 * HS_PL2];
+  // blocks b and b + 8 (same XCD under round-robin placement) are the two halves of one ship
+  const int blk = blockIdx.x;
+  const int s = (blk >> 4) * 8 + (blk & 7), side = (blk >> 3) & 1;
+  if (s >= p.S) return;
+  if (p.mask && !p.mask[s]) return;  // block-uniform
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // Both roles run the same number of barriers (1 + HS_NS); each has its own loop so that the register allocator
+  // sees only one role's long-lived state at a time.
+  if (wv < 4) {
+    // ================================================================ producer waves (stage A + stage B)
+    const int n16 = lane & 15, kq = lane >> 4;
+    const int ph = n16 >> 2, cl = n16 & 3, pa = ph >> 1, pb = ph & 1;
+    float bw[2][9], bw2[5], bias3[2];  // B operands, constant over the strip
+#pragma unroll
+    for (int hf = 0; hf < 2; hf++) {
+#pragma unroll
+      for (int j = 0; j < 9; j++) bw[hf][j] = p.w3mf[(hf * 36 + 4 * j + kq) * 16 + n16];
+      bias3[hf] = p.b3[4 * hf + cl];
+    }
+#pragma unroll
+    for (int j = 0; j < 5; j++) bw2[j] = p.w2mf[(4 * j + kq) * 16 + n16];
+    const float bias2 = p.b2[cl];
+    const float *up1s = p.up1 + (size_t)s * 5000;
+    const float *fr2 = p.u2fr + (size_t)s * 1600, *fr3 = p.u3fr + (size_t)s * 6400;
+
+    // ---- stage A: one M-tile = 16 uprelu1 pixels of row pair `pr` -> 2 x 32 cells x 4 channels of uprelu2 ----
+    // A[pixel][k = 4 j + kq]: tap = 2 j + (kq >> 1), ci = kq & 1 (K = 18, padded to 20)
+    auto stageA_load = [&](int pr, int hh, float *av) {
+      const int px0 = side ? (hh ? 34 : 23) : (hh ? 11 : 0);
+      const int j1 = px0 + n16;
+#pragma unroll
+      for (int j = 0; j < 5; j++) {
+        const int tap = min(2 * j + (kq >> 1), 8);
+        const int yy = min(max(pr + tap / 3 - 1, 0), 49), xx = min(max(j1 + tap % 3 - 1, 0), 49);
+        av[j] = up1s[((kq & 1) * 50 + yy) * 50 + xx];
+      }
+    };
+    auto stageA_compute = [&](int pr, int hh, const float *av) {
+      const int px0 = side ? (hh ? 34 : 23) : (hh ? 11 : 0);
+      f32x4 d = {bias2, bias2, bias2, bias2};
+#pragma unroll
+      for (int j = 0; j < 5; j++) d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bw2[j], d, 0, 0, 0);
+      // D: rows = pixels px0 + 4 kq + i, column n16 = (phase, channel)
+      const int col = 2 * (px0 + 4 * kq) + pb - (side ? 46 : -1);
+#pragma unroll
+      for (int i = 0; i < 4; i++) hs_u2_store(u2r, cl, 2 * pr + pa, col + 2 * i, hd_max_raw(d[i], 0.f));
+      // exact frame cells + the clamp copies outside the plane (same wave: LDS operations of a wave stay in order)
+      if ((side == 0 && hh == 0) || (side == 1 && hh == 1)) {  // the strip's frame column: 2 rows x 4 channels
+        if (lane < 8) {
+          const int yp = lane >> 2, ch = lane & 3, y = 2 * pr + yp;
+          const float v = fr2[((side ? 3 : 2) * 100 + y) * 4 + ch];
+          const int cf = side ? 53 : 1, cc = side ? 54 : 0;
+          hs_u2_store(u2r, ch, y, cf, v);
+          hs_u2_store(u2r, ch, y, cc, v);
+          if (y == 0) { hs_u2_store(u2r, ch, -1, cf, v); hs_u2_store(u2r, ch, -1, cc, v); }
+          if (y == 99) { hs_u2_store(u2r, ch, 100, cf, v); hs_u2_store(u2r, ch, 100, cc, v); }
+        }
+      }
+      if (pr == 0 || pr == 49) {  // frame row of the plane (and its clamp copy) over the tile's 32 columns
+        const int c = lane >> 1, chh = lane & 1, x = 2 * px0 + c;
+        const int y = pr ? 99 : 0, yc = pr ? 100 : -1;
+        const f32x2 v = *reinterpret_cast<const f32x2 *>(fr2 + ((pr ? 1 : 0) * 100 + x) * 4 + 2 * chh);
+        const int ci2 = x - (side ? 46 : -1);
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+          hs_u2_store(u2r, 2 * chh + k, y, ci2, v[k]);
+          hs_u2_store(u2r, 2 * chh + k, yc, ci2, v[k]);
+        }
+      }
+    };
+
+    // ---- stage B: M-tile T = groups 4 T .. 4 T + 3 (flat over quad rows), both channel halves from one A gather ----
+    struct TileB {
+      const float *a;   // A: cell (row qi - 1, column of the lane's quad - 1) of channel kq; rows + P2, columns + 1
+      float *w;         // D: first of the 4 cells of the lane group's quads (channel cl of half 0, phase row / column)
+      int qi_d, g_d;    // quad row and group of the lane group (D side)
+      float fv;         // exact frame-column cell of this lane (requested in front of the MFMAs)
+      bool hasf;        // wave-uniform: the tile touches the frame of the plane
+    };
+    auto tile_setup = [&](int T, TileB &t) {
+      const int ga = 4 * T + (n16 >> 2), qa = (ga * 5042) >> 16, ql = 4 * (ga - HS_GPR * qa) + (n16 & 3);
+      t.a = &u2r[kq * HS_PL2 + (qa & (HS_NR2 - 1)) * HS_P2 + ql + side];
+      const int gd = 4 * T + kq;
+      t.qi_d = (gd * 5042) >> 16;
+      t.g_d = gd - HS_GPR * t.qi_d;
+      t.w = &u3r[cl * HS_PL3 + ((2 * t.qi_d + pa) & (HS_NR3 - 1)) * HS_P3 + 8 * t.g_d + pb + 1];
+      // the strip's outer group (0 | 12) among groups g0 .. g0 + 3 (mod 13), or the first / last quad row
+      const int g0 = (4 * T) % HS_GPR;
+      t.hasf = 4 * T < HS_GPR || 4 * T + 3 >= 99 * HS_GPR || (side ? g0 >= 9 : (g0 == 0 || g0 >= 10));
+      t.fv = 0.f;
+      if (t.hasf && (side ? t.g_d == 12 : t.g_d == 0))
+        t.fv = fr3[((side ? 3 : 2) * 200 + 2 * t.qi_d + (n16 >> 3)) * 8 + (n16 & 7)];
+    };
+    auto tile_epilogue = [&](const TileB &t, const f32x4 d0, const f32x4 d1) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) t.w[2 * i] = hd_max_raw(d0[i], 0.f);
+#pragma unroll
+      for (int i = 0; i < 4; i++) t.w[4 * HS_PL3 + 2 * i] = hd_max_raw(d1[i], 0.f);
+    };
+    // exact frame cells of uprelu3 (and the clamp copies around the plane) for a tile that touches the frame
+    auto tile_frames = [&](const TileB &t) {
+      if (side ? t.g_d == 12 : t.g_d == 0) {  // lane group: 2 rows x 8 channels of the frame column + the clamp column
+        const int yp = n16 >> 3, ch = n16 & 7, y = 2 * t.qi_d + yp;
+        const float v = t.fv;
+        const int cf = side ? 104 : 1, cc = side ? 105 : 0;
+        float *q = &u3r[ch * HS_PL3 + (y & (HS_NR3 - 1)) * HS_P3];
+        q[cf] = v; q[cc] = v;
+        if (y == 0) { float *q2 = &u3r[ch * HS_PL3 + (HS_NR3 - 1) * HS_P3]; q2[cf] = v; q2[cc] = v; }             // row -1
+        if (y == 199) { float *q2 = &u3r[ch * HS_PL3 + (200 & (HS_NR3 - 1)) * HS_P3]; q2[cf] = v; q2[cc] = v; }  // row 200
+      }
+      if (t.qi_d == 0 || t.qi_d == 99) {  // frame row over the group's 8 columns: lane = (column, channel half)
+        const int c = n16 >> 1, chh = n16 & 1;
+        const int ci3 = 8 * t.g_d + 1 + c, x = ci3 - 1 - 4 * side + 100 * side;
+        const int y = t.qi_d ? 199 : 0, yc = t.qi_d ? 200 : -1;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(fr3 + ((t.qi_d ? 1 : 0) * 200 + x) * 8 + 4 * chh);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          u3r[(4 * chh + k) * HS_PL3 + (y & (HS_NR3 - 1)) * HS_P3 + ci3] = v[k];
+          u3r[(4 * chh + k) * HS_PL3 + (yc & (HS_NR3 - 1)) * HS_P3 + ci3] = v[k];
+        }
+      }
+    };
+    auto run_pair = [&](int T0, int T1) {
+      TileB t0, t1;
+      tile_setup(T0, t0);
+      tile_setup(T1, t1);
+      f32x4 d00 = {bias3[0], bias3[0], bias3[0], bias3[0]}, d01 = {bias3[1], bias3[1], bias3[1], bias3[1]};
+      f32x4 d10 = d00, d11 = d01;
+#pragma unroll
+      for (int j = 0; j < 9; j++) {
+        const float a0 = t0.a[(j / 3) * HS_P2 + j % 3], a1 = t1.a[(j / 3) * HS_P2 + j % 3];
+        d00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bw[0][j], d00, 0, 0, 0);
+        d01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bw[1][j], d01, 0, 0, 0);
+        d10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bw[0][j], d10, 0, 0, 0);
+        d11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bw[1][j], d11, 0, 0, 0);
+      }
+      tile_epilogue(t0, d00, d01);
+      tile_epilogue(t1, d10, d11);
+      if (t0.hasf) tile_frames(t0);
+      if (t1.hasf) tile_frames(t1);
+    };
+    auto run_single = [&](int T0) {
+      TileB t0;
+      tile_setup(T0, t0);
+      f32x4 d00 = {bias3[0], bias3[0], bias3[0], bias3[0]}, d01 = {bias3[1], bias3[1], bias3[1], bias3[1]};
+#pragma unroll
+      for (int j = 0; j < 9; j++) {
+        const float a0 = t0.a[(j / 3) * HS_P2 + j % 3];
+        d00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bw[0][j], d00, 0, 0, 0);
+        d01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bw[1][j], d01, 0, 0, 0);
+      }
+      tile_epilogue(t0, d00, d01);
+      if (t0.hasf) tile_frames(t0);
+    };
+
+    {  // prologue: uprelu2 row pairs 0 and 1, one tile per producer wave
+      float av[5];
+      stageA_load(wv >> 1, wv & 1, av);
+      stageA_compute(wv >> 1, wv & 1, av);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int st = 0; st < HS_NS; st++) {
+      // stage-A tile of this wave for the NEXT sub-step (tile (pair, half) belongs to wave (2 pair + half) & 3): its
+      // global loads fly while the M-tiles of stage B run
+      const int p0 = kStageADone[st], p1 = kStageADone[st + 1];
+      int apr = -1, ahh = 0;
+      for (int pr = p0; pr < p1; pr++)
+        for (int hh = 0; hh < 2; hh++)
+          if (((2 * pr + hh) & 3) == wv) { apr = pr; ahh = hh; }
+      float av[5];
+      if (apr >= 0) stageA_load(apr, ahh, av);
+      const int t0 = hs_tiles_done(st - 1), n = hs_tiles_done(st) - t0;
+      if (n > 0) {
+        run_pair(t0 + wv, t0 + wv + 4);
+        if (n == 9 && wv == 0) run_single(t0 + 8);
+      }
+      if (apr >= 0) stageA_compute(apr, ahh, av);
+      __syncthreads();
+    }
+  } else {
+    // ================================================================ consumer waves (stage C + arg-max)
+    // stage-C weights: register r, lane L holds W[k = 16 r + (L >> 2)][phase L & 3]; an MFMA picks its k with ABID
+    float wreg[5];
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+      const int k = 16 * r + (lane >> 2);
+      wreg[r] = k < 72 ? p.w4eff_c[((k / 9) * 4 + (lane & 3)) * 9 + (k % 9)] : 0.f;
+    }
+    const int task = 64 * (wv - 4) + lane;           // 250 two-pixel tasks per sub-step: 5 rows x 50
+    const bool task_ok = task < 250;
+    const int tk = task_ok ? task : 249;
+    const int r_in = tk / 50, jx = tk - 50 * r_in;   // row of the block, pixel pair of the row
+    const float bias4 = p.b4[0];
+    const bool fcol = side ? jx == 49 : jx == 0;     // the lane owns pixels of the strip's frame column
+    const float *c4s = p.c4 + (size_t)s * 1600;
+    const int x0 = 100 * side + 2 * jx;              // uprelu3 column of the lane's first pixel
+    float tv = -INFINITY;
+    int ts = 0;
+
+    __syncthreads();  // the producers' prologue
+#pragma unroll 1
+    for (int st = 0; st < HS_NS; st++) {
+      const int R = 5 * st - 8 + r_in;               // uprelu3 row of the lane's two pixels
+      const bool ok = task_ok && R >= 0 && R < 200;
+      if (__builtin_amdgcn_ballot_w64(ok) != 0) {    // wave-uniform
+        const int Rc = min(max(R, 0), 199);
+        // zero-padding corrections of frame pixels (global memory: requested up front, zero for the other lanes)
+        f32x2 ccol = {0.f, 0.f};
+        f32x4 crow = {0.f, 0.f, 0.f, 0.f};
+        if (fcol) ccol = *reinterpret_cast<const f32x2 *>(c4s + (side ? 3 : 2) * 400 + 2 * Rc);
+        const bool edge = st < 3 || st > 38;         // wave-uniform: the block may hold row 0 or row 199
+        if (edge && (Rc == 0 || Rc == 199)) crow = *reinterpret_cast<const f32x4 *>(c4s + (Rc ? 1 : 0) * 400 + 2 * x0);
+        const float *rowp[3];
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++) rowp[dy] = &u3r[((Rc + dy - 1) & (HS_NR3 - 1)) * HS_P3 + 2 * jx + 4 * side];
+        // accumulators [pixel][channel half]: 4 independent MFMA chains, combined at the end
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int px = 0; px < 2; px++) {
+          acc[px][0] = (f32x4){bias4, bias4, bias4, bias4};
+          acc[px][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        // software pipeline over 12 steps (step = channel pair (c, c + 4), row dy): the 4 reads of step t + 2 are
+        // requested before the 12 MFMAs of step t
+        f32x2 V[3][2][2];
+        auto ldv = [&](int t) {
+          const int c = t / 3, dy = t % 3;
+#pragma unroll
+          for (int hf = 0; hf < 2; hf++) {
+            const float *q = rowp[dy] + (c + 4 * hf) * HS_PL3;
+            V[t % 3][hf][0] = *(hs_lds_v2 *)(q);
+            V[t % 3][hf][1] = *(hs_lds_v2 *)(q + 2);
+          }
+        };
+        ldv(0);
+        ldv(1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 12; t++) {
+          if (t + 2 < 12) ldv(t + 2);
+          const int c = t / 3, dy = t % 3;
+#pragma unroll
+          for (int dx = 0; dx < 3; dx++)
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++) {
+              const int k = (c + 4 * hf) * 9 + dy * 3 + dx;
+#pragma unroll
+              for (int px = 0; px < 2; px++) {
+                // D[phase][pixel] += W[k][phase] * in[pixel][k]; A = block (k & 15) of register k >> 4, broadcast
+                const float v = V[t % 3][hf][(dx + px) >> 1][(dx + px) & 1];
+                switch (k & 15) {
+#define HS_CASE(B) case B: acc[px][hf] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[k >> 4], v, acc[px][hf], 4, B, 0); break;
+                  HS_CASE(0) HS_CASE(1) HS_CASE(2) HS_CASE(3) HS_CASE(4) HS_CASE(5) HS_CASE(6) HS_CASE(7)
+                  HS_CASE(8) HS_CASE(9) HS_CASE(10) HS_CASE(11) HS_CASE(12) HS_CASE(13) HS_CASE(14) HS_CASE(15)
+#undef HS_CASE
+                }
+              }
+            }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        f32x4 o[2];
+#pragma unroll
+        for (int px = 0; px < 2; px++) o[px] = acc[px][0] + acc[px][1];
+        // frame pixels: phase (a, b) of pixel px is heat-map pixel (2 R + a, 2 x + b); the corrections are zero elsewhere
+        if (side) { o[1][1] -= ccol[0]; o[1][3] -= ccol[1]; }  // block-uniform
+        else { o[0][0] -= ccol[0]; o[0][2] -= ccol[1]; }
+        if (edge) {
+          if (st < 3) { o[0][0] -= crow[0]; o[0][1] -= crow[1]; o[1][0] -= crow[2]; o[1][1] -= crow[3]; }
+          else { o[0][2] -= crow[0]; o[0][3] -= crow[1]; o[1][2] -= crow[2]; o[1][3] -= crow[3]; }
+        }
+        if (p.heat && ok) {
+          float *hp = p.heat + (size_t)s * HD_PS * HD_PS + (size_t)(2 * R) * HD_PS + 2 * x0;
+          *reinterpret_cast<f32x4 *>(hp) = (f32x4){o[0][0], o[0][1], o[1][0], o[1][1]};
+          *reinterpret_cast<f32x4 *>(hp + HD_PS) = (f32x4){o[0][2], o[0][3], o[1][2], o[1][3]};
+        }
+        if (p.ptr_probe && ok) {
+          const int qx = p.probe[2 * s] - 2 * x0, qy = p.probe[2 * s + 1] - 2 * R;
+          if (qx >= 0 && qx < 4 && qy >= 0 && qy < 2) p.ptr_probe[s] = o[qx >> 1][2 * qy + (qx & 1)];
+        }
+        // the lane visits its values in increasing flat index (rows grow with the sub-step): strict > keeps the first
+        float tvn = tv;
+        int tsn = ts;
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+          for (int px = 0; px < 2; px++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+              const float val = o[px][2 * a + b];
+              const bool gt = val > tvn;
+              tvn = gt ? val : tvn;
+              tsn = gt ? st * 8 + (a * 4 + px * 2 + b) : tsn;
+            }
+        tv = ok ? tvn : tv;
+        ts = ok ? tsn : ts;
+      }
+      __syncthreads();
+    }
+
+    // ---- arg-max of the strip (first maximum in C order) ----
+    const int sst = ts >> 3, slot = ts & 7;
+    const int Rb = 5 * sst - 8 + r_in;
+    const int y = 2 * Rb + (slot >> 2), x = 2 * x0 + (slot & 3);
+    unsigned long long key = 0ull;
+    if (tv > -INFINITY) key = ((unsigned long long)hd_ordered_f32(tv) << 32) | (unsigned long long)(~(unsigned)(y * HD_PS + x));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long other = __shfl_xor(key, o);
+      key = other > key ? other : key;
+    }
+    if (lane == 0 && key) atomicMax(&p.best[s], key);
+  }
+}
+
+size_t ofx_head_frame_bytes(size_t S, size_t *u2fr, size_t *u3fr, size_t *c4) {
+  *u2fr = 4 * S * 1600;
+  *u3fr = 4 * S * 6400;
+  *c4 = 4 * S * 1600;
+  return *u2fr + *u3fr + *c4;
+}
+
+int ofx_launch_head(ofx_handle *h, const HeadParams2 &p) {
+  hipLaunchKernelGGL(k_head_frames, dim3((unsigned)p.S), dim3(HF_THREADS), 0, h->stream, p);
+  OFX_HIP(hipGetLastError());
+  const unsigned blocks = (unsigned)(((p.S + 7) / 8) * 16);
+  hipLaunchKernelGGL(k_head_stream, dim3(blocks), dim3(512), 0, h->stream, p);
+  OFX_HIP(hipGetLastError());
+  return OFX_OK;
+}

@@ -81,6 +81,7 @@
 #endif
 
 #include "ofx_internal.h"
+#include "ofx_head.h"
 
 #define PS 400 /* the model's fixed input side: Input((DEFAULT_WIDTH, DEFAULT_HEIGHT, 2)) */
 
@@ -2151,7 +2152,7 @@ __global__ void k_policy_actions(int S, const ofx_state st, const int32_t *iacti
 
 // ---- workspace -----------------------------------------------------------------------
 struct PolicyWs {
-  float *prep, *p1, *p2, *p3, *p4, *g1, *d1, *u0, *up1, *up2, *up3;
+  float *prep, *p1, *p2, *p3, *p4, *g1, *d1, *u0, *up1, *up2, *up3, *u2fr, *u3fr, *c4;
   unsigned long long *best;
   int32_t *iaction, *ipointer;
 };
@@ -2169,11 +2170,13 @@ constexpr int kDense1Chunks = 25;  // split-K of dense1: 5000 = 25 x 200
 // (ofx_policy_forward_obs) invalidates the results a previous forward left in the workspace
 static int policy_workspace(ofx_handle *h, PolicyWs *ws, size_t N, size_t S) {
   const PrepLayout L = prep_layout();
+  size_t f2, f3, f4;
+  ofx_head_frame_bytes(S, &f2, &f3, &f4);
   const size_t sz[] = {al(4ull * L.total),          al(4ull * N * 8 * 200 * 200), al(4ull * N * 8 * 100 * 100),
                        al(4ull * N * 8 * 50 * 50),   al(4ull * N * 5000),          al(4ull * N * 100 * kDense1Chunks),
                        al(4ull * S * 100),           al(4ull * S * 625),           al(4ull * S * 2 * 50 * 50),
                        al(4ull * S * 4 * 100 * 100), al(policy_unfused() ? 4ull * S * 8 * 200 * 200 : 256), al(8ull * S),
-                       al(4ull * S),                 al(8ull * S)};
+                       al(4ull * S),                 al(8ull * S),                 al(f2), al(f3), al(f4)};
   size_t total = 0;
   for (size_t b : sz) total += b;
   int rc = ofx_ensure_scratch(h, total);
@@ -2181,8 +2184,9 @@ static int policy_workspace(ofx_handle *h, PolicyWs *ws, size_t N, size_t S) {
   char *base = (char *)h->scratch;
   void **dst[] = {(void **)&ws->prep, (void **)&ws->p1, (void **)&ws->p2, (void **)&ws->p3, (void **)&ws->p4,
                   (void **)&ws->g1,   (void **)&ws->d1, (void **)&ws->u0, (void **)&ws->up1, (void **)&ws->up2,
-                  (void **)&ws->up3,  (void **)&ws->best, (void **)&ws->iaction, (void **)&ws->ipointer};
-  for (int i = 0; i < 14; i++) { *dst[i] = base; base += sz[i]; }
+                  (void **)&ws->up3,  (void **)&ws->best, (void **)&ws->iaction, (void **)&ws->ipointer,
+                  (void **)&ws->u2fr, (void **)&ws->u3fr, (void **)&ws->c4};
+  for (int i = 0; i < 17; i++) { *dst[i] = base; base += sz[i]; }
   return OFX_OK;
 }
 
@@ -2337,7 +2341,22 @@ static int policy_forward_impl(ofx_handle *h, const float *weights, int N, int M
   if (policy_unfused())
     if ((rc = launch_conv<2, 4, 10, 100, 2, false, false>(h, up, S, 100))) return rc;
   OFX_HIP(hipMemsetAsync(ws.best, 0, sizeof(unsigned long long) * S, h->stream));
-  if (!policy_unfused()) {
+  if (!policy_unfused() && !getenv("OFX_HEAD_OLD")) {
+    HeadParams2 hp2;
+    hp2.S = S; hp2.up1 = ws.up1;
+    hp2.w2mf = ws.prep + L.w2mf; hp2.b2 = ws.prep + L.ub[1]; hp2.w2raw = ws.prep + L.uw[1];
+    hp2.w3mf = ws.prep + L.w3mf; hp2.b3 = ws.prep + L.ub[2]; hp2.w3raw = ws.prep + L.uw[2];
+    hp2.w4eff_c = ws.prep + L.w4eff_c; hp2.b4 = ws.prep + L.b4; hp2.w4raw = ws.prep + L.w4raw;
+    hp2.u2fr = ws.u2fr; hp2.u3fr = ws.u3fr; hp2.c4 = ws.c4;
+    hp2.mask = ship_mask; hp2.best = ws.best; hp2.heat = heatmap; hp2.probe = probe; hp2.ptr_probe = probe ? ptr_probe : nullptr;
+    const int pb = h->prof_base;
+    if (pb >= 0 && (rc = ofx_event_record(h, pb))) return rc;
+    if ((rc = ofx_launch_head(h, hp2))) return rc;
+    if (pb >= 0) {
+      if ((rc = ofx_event_record(h, pb + 1))) return rc;
+      h->prof_base = pb + 2;
+    }
+  } else if (!policy_unfused()) {
     HeadTailParams ht;
     ht.up1 = ws.up1;
     ht.w2mf = ws.prep + L.w2mf; ht.w2raw = ws.prep + L.uw[1]; ht.b2 = ws.prep + L.ub[1];
