@@ -234,9 +234,9 @@ constexpr int HS_PL3 = HS_NR3 * HS_P3 + 4;   // channel plane stride (floats)
 // three rows of a window are always contiguous and the A gather of stage B is one base address + immediates
 constexpr int HS_NR2 = 16, HS_P2 = 56;
 constexpr int HS_PL2 = (HS_NR2 + 2) * HS_P2 + 16;  // +16: the channel planes of the MFMA A-gather land on different banks
-// uprelu2 row pairs finished by the end of sub-step s - 1 (index s; index 0 = prologue): tools/head_schedule.py
-__device__ const unsigned char kStageADone[HS_NS + 1] = {2, 3, 5, 6, 7, 8, 10, 11, 12, 13, 15, 16, 17, 18, 20, 21, 22, 23, 25, 26, 27, 28, 30,
-                                                        31, 32, 33, 35, 36, 37, 38, 40, 41, 42, 43, 45, 46, 47, 48, 50, 50, 50, 50, 50};
+// uprelu2 row pairs finished by the end of sub-step s - 1 (0 = by the prologue): the table of tools/head_schedule.py,
+// 2, 3, 5, 6, 7, 8, 10, ...
+__device__ __forceinline__ int hs_pairs_done(int s) { return min(50, s + 2 + ((s + 2) >> 2)); }
 
 __device__ __forceinline__ int hs_tiles_done(int s) {  // tiles finished by the end of sub-step s
   return s < 0 ? 0 : min(HS_NTILES, 8 * (s + 1) + ((s + 1) >> 3));
@@ -257,6 +257,9 @@ __device__ __forceinline__ void hs_u2_store(float *u2r, int ch, int row, int col
 __global__ __launch_bounds__(512, 4) void k_head_stream(HeadParams2 p) {
   __shared__ __align__(16) float u3r[8 * HS_PL3];
   __shared__ __align__(16) float u2r[4 * HS_PL2];
+  // group (flat over quad rows) -> float offset of its first quad in the uprelu2 ring (row slot of quad row - 1) and
+  // in the uprelu3 ring (row slot of uprelu3 row 2 * quad row): two table reads replace the index arithmetic of a tile
+  __shared__ unsigned short tabA[4 * HS_NTILES], tabD[4 * HS_NTILES];
   // blocks b and b + 8 (same XCD under round-robin placement) are the two halves of one ship
   const int blk = blockIdx.x;
   const int s = (blk >> 4) * 8 + (blk & 7), side = (blk >> 3) & 1;
@@ -264,6 +267,11 @@ __global__ __launch_bounds__(512, 4) void k_head_stream(HeadParams2 p) {
   if (p.mask && !p.mask[s]) return;  // block-uniform
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int g = tid; g < 4 * HS_NTILES; g += 512) {
+    const int q = g / HS_GPR, gg = g - HS_GPR * q;
+    tabA[g] = (unsigned short)((q & (HS_NR2 - 1)) * HS_P2 + 4 * gg);
+    tabD[g] = (unsigned short)(((2 * q) & (HS_NR3 - 1)) * HS_P3 + 8 * gg);
+  }
 
   // Both roles run the same number of barriers (1 + HS_NS); each has its own loop so that the register allocator
   // sees only one role's long-lived state at a time.
@@ -271,12 +279,14 @@ __global__ __launch_bounds__(512, 4) void k_head_stream(HeadParams2 p) {
     // ================================================================ producer waves (stage A + stage B)
     const int n16 = lane & 15, kq = lane >> 4;
     const int ph = n16 >> 2, cl = n16 & 3, pa = ph >> 1, pb = ph & 1;
-    float bw[2][9], bw2[5], bias3[2];  // B operands, constant over the strip
+    float bw[2][9], bw2[5];  // B operands, constant over the strip
+    f32x4 binit3[2];         // the folded bias as the C operand of a tile's first MFMA
 #pragma unroll
     for (int hf = 0; hf < 2; hf++) {
 #pragma unroll
       for (int j = 0; j < 9; j++) bw[hf][j] = p.w3mf[(hf * 36 + 4 * j + kq) * 16 + n16];
-      bias3[hf] = p.b3[4 * hf + cl];
+      const float b = p.b3[4 * hf + cl];
+      binit3[hf] = (f32x4){b, b, b, b};
     }
 #pragma unroll
     for (int j = 0; j < 5; j++) bw2[j] = p.w2mf[(4 * j + kq) * 16 + n16];
@@ -334,23 +344,25 @@ __global__ __launch_bounds__(512, 4) void k_head_stream(HeadParams2 p) {
     struct TileB {
       const float *a;   // A: cell (row qi - 1, column of the lane's quad - 1) of channel kq; rows + P2, columns + 1
       float *w;         // D: first of the 4 cells of the lane group's quads (channel cl of half 0, phase row / column)
-      int qi_d, g_d;    // quad row and group of the lane group (D side)
+      int gd;           // flat group of the lane group (D side)
       float fv;         // exact frame-column cell of this lane (requested in front of the MFMAs)
       bool hasf;        // wave-uniform: the tile touches the frame of the plane
     };
+    const float *const a_lane = &u2r[kq * HS_PL2 + (n16 & 3) + side];
+    float *const w_lane = &u3r[cl * HS_PL3 + pa * HS_P3 + pb + 1];
+    const unsigned short *const ta_lane = &tabA[n16 >> 2], *const td_lane = &tabD[kq];
     auto tile_setup = [&](int T, TileB &t) {
-      const int ga = 4 * T + (n16 >> 2), qa = (ga * 5042) >> 16, ql = 4 * (ga - HS_GPR * qa) + (n16 & 3);
-      t.a = &u2r[kq * HS_PL2 + (qa & (HS_NR2 - 1)) * HS_P2 + ql + side];
-      const int gd = 4 * T + kq;
-      t.qi_d = (gd * 5042) >> 16;
-      t.g_d = gd - HS_GPR * t.qi_d;
-      t.w = &u3r[cl * HS_PL3 + ((2 * t.qi_d + pa) & (HS_NR3 - 1)) * HS_P3 + 8 * t.g_d + pb + 1];
+      t.a = a_lane + ta_lane[4 * T];
+      t.w = w_lane + td_lane[4 * T];
+      t.gd = 4 * T + kq;
       // the strip's outer group (0 | 12) among groups g0 .. g0 + 3 (mod 13), or the first / last quad row
       const int g0 = (4 * T) % HS_GPR;
       t.hasf = 4 * T < HS_GPR || 4 * T + 3 >= 99 * HS_GPR || (side ? g0 >= 9 : (g0 == 0 || g0 >= 10));
       t.fv = 0.f;
-      if (t.hasf && (side ? t.g_d == 12 : t.g_d == 0))
-        t.fv = fr3[((side ? 3 : 2) * 200 + 2 * t.qi_d + (n16 >> 3)) * 8 + (n16 & 7)];
+      if (t.hasf) {
+        const int qi = (t.gd * 5042) >> 16, g = t.gd - HS_GPR * qi;
+        if (side ? g == 12 : g == 0) t.fv = fr3[((side ? 3 : 2) * 200 + 2 * qi + (n16 >> 3)) * 8 + (n16 & 7)];
+      }
     };
     auto tile_epilogue = [&](const TileB &t, const f32x4 d0, const f32x4 d1) {
 #pragma unroll
@@ -360,8 +372,9 @@ __global__ __launch_bounds__(512, 4) void k_head_stream(HeadParams2 p) {
     };
     // exact frame cells of uprelu3 (and the clamp copies around the plane) for a tile that touches the frame
     auto tile_frames = [&](const TileB &t) {
-      if (side ? t.g_d == 12 : t.g_d == 0) {  // lane group: 2 rows x 8 channels of the frame column + the clamp column
-        const int yp = n16 >> 3, ch = n16 & 7, y = 2 * t.qi_d + yp;
+      const int qi_d = (t.gd * 5042) >> 16, g_d = t.gd - HS_GPR * qi_d;
+      if (side ? g_d == 12 : g_d == 0) {  // lane group: 2 rows x 8 channels of the frame column + the clamp column
+        const int yp = n16 >> 3, ch = n16 & 7, y = 2 * qi_d + yp;
         const float v = t.fv;
         const int cf = side ? 104 : 1, cc = side ? 105 : 0;
         float *q = &u3r[ch * HS_PL3 + (y & (HS_NR3 - 1)) * HS_P3];
@@ -369,11 +382,11 @@ __global__ __launch_bounds__(512, 4) void k_head_stream(HeadParams2 p) {
         if (y == 0) { float *q2 = &u3r[ch * HS_PL3 + (HS_NR3 - 1) * HS_P3]; q2[cf] = v; q2[cc] = v; }             // row -1
         if (y == 199) { float *q2 = &u3r[ch * HS_PL3 + (200 & (HS_NR3 - 1)) * HS_P3]; q2[cf] = v; q2[cc] = v; }  // row 200
       }
-      if (t.qi_d == 0 || t.qi_d == 99) {  // frame row over the group's 8 columns: lane = (column, channel half)
+      if (qi_d == 0 || qi_d == 99) {  // frame row over the group's 8 columns: lane = (column, channel half)
         const int c = n16 >> 1, chh = n16 & 1;
-        const int ci3 = 8 * t.g_d + 1 + c, x = ci3 - 1 - 4 * side + 100 * side;
-        const int y = t.qi_d ? 199 : 0, yc = t.qi_d ? 200 : -1;
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(fr3 + ((t.qi_d ? 1 : 0) * 200 + x) * 8 + 4 * chh);
+        const int ci3 = 8 * g_d + 1 + c, x = ci3 - 1 - 4 * side + 100 * side;
+        const int y = qi_d ? 199 : 0, yc = qi_d ? 200 : -1;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(fr3 + ((qi_d ? 1 : 0) * 200 + x) * 8 + 4 * chh);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           u3r[(4 * chh + k) * HS_PL3 + (y & (HS_NR3 - 1)) * HS_P3 + ci3] = v[k];
@@ -385,15 +398,14 @@ __global__ __launch_bounds__(512, 4) void k_head_stream(HeadParams2 p) {
       TileB t0, t1;
       tile_setup(T0, t0);
       tile_setup(T1, t1);
-      f32x4 d00 = {bias3[0], bias3[0], bias3[0], bias3[0]}, d01 = {bias3[1], bias3[1], bias3[1], bias3[1]};
-      f32x4 d10 = d00, d11 = d01;
+      f32x4 d00, d01, d10, d11;
 #pragma unroll
       for (int j = 0; j < 9; j++) {
         const float a0 = t0.a[(j / 3) * HS_P2 + j % 3], a1 = t1.a[(j / 3) * HS_P2 + j % 3];
-        d00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bw[0][j], d00, 0, 0, 0);
-        d01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bw[1][j], d01, 0, 0, 0);
-        d10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bw[0][j], d10, 0, 0, 0);
-        d11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bw[1][j], d11, 0, 0, 0);
+        d00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bw[0][j], j ? d00 : binit3[0], 0, 0, 0);
+        d01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bw[1][j], j ? d01 : binit3[1], 0, 0, 0);
+        d10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bw[0][j], j ? d10 : binit3[0], 0, 0, 0);
+        d11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bw[1][j], j ? d11 : binit3[1], 0, 0, 0);
       }
       tile_epilogue(t0, d00, d01);
       tile_epilogue(t1, d10, d11);
@@ -403,12 +415,12 @@ __global__ __launch_bounds__(512, 4) void k_head_stream(HeadParams2 p) {
     auto run_single = [&](int T0) {
       TileB t0;
       tile_setup(T0, t0);
-      f32x4 d00 = {bias3[0], bias3[0], bias3[0], bias3[0]}, d01 = {bias3[1], bias3[1], bias3[1], bias3[1]};
+      f32x4 d00, d01;
 #pragma unroll
       for (int j = 0; j < 9; j++) {
         const float a0 = t0.a[(j / 3) * HS_P2 + j % 3];
-        d00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bw[0][j], d00, 0, 0, 0);
-        d01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bw[1][j], d01, 0, 0, 0);
+        d00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bw[0][j], j ? d00 : binit3[0], 0, 0, 0);
+        d01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bw[1][j], j ? d01 : binit3[1], 0, 0, 0);
       }
       tile_epilogue(t0, d00, d01);
       if (t0.hasf) tile_frames(t0);
@@ -424,11 +436,9 @@ __global__ __launch_bounds__(512, 4) void k_head_stream(HeadParams2 p) {
     for (int st = 0; st < HS_NS; st++) {
       // stage-A tile of this wave for the NEXT sub-step (tile (pair, half) belongs to wave (2 pair + half) & 3): its
       // global loads fly while the M-tiles of stage B run
-      const int p0 = kStageADone[st], p1 = kStageADone[st + 1];
-      int apr = -1, ahh = 0;
-      for (int pr = p0; pr < p1; pr++)
-        for (int hh = 0; hh < 2; hh++)
-          if (((2 * pr + hh) & 3) == wv) { apr = pr; ahh = hh; }
+      const int lo = 2 * hs_pairs_done(st), hi = 2 * hs_pairs_done(st + 1);  // tile ids 2 pair + half
+      const int at = lo + ((wv - lo) & 3);
+      const int apr = at < hi ? at >> 1 : -1, ahh = at & 1;
       float av[5];
       if (apr >= 0) stageA_load(apr, ahh, av);
       const int t0 = hs_tiles_done(st - 1), n = hs_tiles_done(st) - t0;
@@ -453,6 +463,7 @@ __global__ __launch_bounds__(512, 4) void k_head_stream(HeadParams2 p) {
     const int tk = task_ok ? task : 249;
     const int r_in = tk / 50, jx = tk - 50 * r_in;   // row of the block, pixel pair of the row
     const float bias4 = p.b4[0];
+    const f32x4 binit4 = {bias4, bias4, bias4, bias4};
     const bool fcol = side ? jx == 49 : jx == 0;     // the lane owns pixels of the strip's frame column
     const float *c4s = p.c4 + (size_t)s * 1600;
     const int x0 = 100 * side + 2 * jx;              // uprelu3 column of the lane's first pixel
@@ -479,7 +490,7 @@ __global__ __launch_bounds__(512, 4) void k_head_stream(HeadParams2 p) {
         f32x4 acc[2][2];
 #pragma unroll
         for (int px = 0; px < 2; px++) {
-          acc[px][0] = (f32x4){bias4, bias4, bias4, bias4};
+          acc[px][0] = binit4;
           acc[px][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
         // software pipeline over 12 steps (step = channel pair (c, c + 4), row dy): the 4 reads of step t + 2 are
@@ -540,21 +551,27 @@ __global__ __launch_bounds__(512, 4) void k_head_stream(HeadParams2 p) {
           if (qx >= 0 && qx < 4 && qy >= 0 && qy < 2) p.ptr_probe[s] = o[qx >> 1][2 * qy + (qx & 1)];
         }
         // the lane visits its values in increasing flat index (rows grow with the sub-step): strict > keeps the first
-        float tvn = tv;
-        int tsn = ts;
+        // (rarely taken once the running maximum has settled: first the maximum of the 8 values, the slot search
+        // only in the waves where a lane improves)
+        const float m8 = fmaxf(fmaxf(fmaxf(o[0][0], o[0][1]), fmaxf(o[0][2], o[0][3])),
+                               fmaxf(fmaxf(o[1][0], o[1][1]), fmaxf(o[1][2], o[1][3])));
+        if (__builtin_amdgcn_ballot_w64(ok && m8 > tv) != 0) {
+          float tvn = tv;
+          int tsn = ts;
 #pragma unroll
-        for (int a = 0; a < 2; a++)
+          for (int a = 0; a < 2; a++)
 #pragma unroll
-          for (int px = 0; px < 2; px++)
+            for (int px = 0; px < 2; px++)
 #pragma unroll
-            for (int b = 0; b < 2; b++) {
-              const float val = o[px][2 * a + b];
-              const bool gt = val > tvn;
-              tvn = gt ? val : tvn;
-              tsn = gt ? st * 8 + (a * 4 + px * 2 + b) : tsn;
-            }
-        tv = ok ? tvn : tv;
-        ts = ok ? tsn : ts;
+              for (int b = 0; b < 2; b++) {
+                const float val = o[px][2 * a + b];
+                const bool gt = val > tvn;
+                tvn = gt ? val : tvn;
+                tsn = gt ? st * 8 + (a * 4 + px * 2 + b) : tsn;
+              }
+          tv = ok ? tvn : tv;
+          ts = ok ? tsn : ts;
+        }
       }
       __syncthreads();
     }

@@ -74,6 +74,8 @@ def check():
         assert ad[s + 1] - ad[s] <= 2
     assert 5 * (NS - 1) + C_ROW0 <= 199 <= 5 * (NS - 1) + C_ROW0 + 4
     assert span3 <= NR3 and span2 <= NR2, (span3, span2)
+    # the kernel's closed form of the stage-A table
+    assert ad == [min(50, s + 2 + ((s + 2) >> 2)) for s in range(NS + 1)], ad
     # group index / 13 by multiply-shift, as the kernel does it
     for g in range(4 * NTILES + 4):
         assert (g * 5042) >> 16 == g // GPR, g
