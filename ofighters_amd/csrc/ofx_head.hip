@@ -20,6 +20,11 @@
 // uprelu2 / uprelu3, correction lines of the heat map) in a small pre-pass; k_head_stream overwrites the frame cells
 // of its rings with the exact values and starts the heat-map accumulators of frame pixels at bias - correction.
 #include "ofx_head.h"
+#include <stdlib.h>
+
+#ifndef OFX_HEAD_HOOKS
+#define OFX_HEAD_HOOKS 0  // 1: the OFX_HEAD_ABLATE timing switches are compiled into k_head_stream (results are wrong)
+#endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -233,7 +238,8 @@ constexpr int HS_PL3 = HS_NR3 * HS_P3 + 4;   // channel plane stride (floats)
 // uprelu2 ring (column c at index c - (side ? 46 : -1)): 16 row slots + 2 mirror slots (16, 17 repeat 0, 1), so the
 // three rows of a window are always contiguous and the A gather of stage B is one base address + immediates
 constexpr int HS_NR2 = 16, HS_P2 = 56;
-constexpr int HS_PL2 = (HS_NR2 + 2) * HS_P2 + 16;  // +16: the channel planes of the MFMA A-gather land on different banks
+constexpr int HS_PL2 = (HS_NR2 + 2) * HS_P2;  // 1008 = 16 mod 32: the channel planes of the MFMA A-gather land on different banks
+static_assert(HS_PL2 % 32 == 16, "uprelu2 plane stride");
 // uprelu2 row pairs finished by the end of sub-step s - 1 (0 = by the prologue): the table of tools/head_schedule.py,
 // 2, 3, 5, 6, 7, 8, 10, ...
 __device__ __forceinline__ int hs_pairs_done(int s) { return min(50, s + 2 + ((s + 2) >> 2)); }
@@ -254,7 +260,10 @@ __device__ __forceinline__ void hs_u2_store(float *u2r, int ch, int row, int col
   if (slot < 2) q[HS_NR2 * HS_P2] = v;
 }
 
-__global__ __launch_bounds__(512, 4) void k_head_stream(HeadParams2 p) {
+constexpr int HS_NB = 4;                 // producer waves (two M-tiles per sub-step each); 4 consumer waves behind them
+constexpr int HS_THREADS = 64 * (HS_NB + 4);
+
+__global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
   __shared__ __align__(16) float u3r[8 * HS_PL3];
   __shared__ __align__(16) float u2r[4 * HS_PL2];
   // group (flat over quad rows) -> float offset of its first quad in the uprelu2 ring (row slot of quad row - 1) and
@@ -267,15 +276,25 @@ __global__ __launch_bounds__(512, 4) void k_head_stream(HeadParams2 p) {
   if (p.mask && !p.mask[s]) return;  // block-uniform
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int g = tid; g < 4 * HS_NTILES; g += 512) {
+  for (int g = tid; g < 4 * HS_NTILES; g += HS_THREADS) {
     const int q = g / HS_GPR, gg = g - HS_GPR * q;
     tabA[g] = (unsigned short)((q & (HS_NR2 - 1)) * HS_P2 + 4 * gg);
-    tabD[g] = (unsigned short)(((2 * q) & (HS_NR3 - 1)) * HS_P3 + 8 * gg);
+    // bit 15: the group holds the strip's frame column; bit 14: the group lies in the first / last quad row
+    tabD[g] = (unsigned short)((((2 * q) & (HS_NR3 - 1)) * HS_P3 + 8 * gg) | ((gg == (side ? 12 : 0)) ? 0x8000 : 0) |
+                               ((q == 0 || q == 99) ? 0x4000 : 0));
   }
 
+#if OFX_HEAD_HOOKS
+  unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0}, stamp_last = __builtin_amdgcn_s_memtime();
+#define HS_STAMP(i) do { if (p.dbg) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp_acc[i] += t_ - stamp_last; stamp_last = t_; } } while (0)
+#define HS_STAMP_OUT() do { if (p.dbg && lane == 0) for (int i_ = 0; i_ < 6; i_++) p.dbg[((size_t)blk * (HS_NB + 4) + wv) * 6 + i_] = stamp_acc[i_]; } while (0)
+#else
+#define HS_STAMP(i) do { } while (0)
+#define HS_STAMP_OUT() do { } while (0)
+#endif
   // Both roles run the same number of barriers (1 + HS_NS); each has its own loop so that the register allocator
   // sees only one role's long-lived state at a time.
-  if (wv < 4) {
+  if (wv < HS_NB) {
     // ================================================================ producer waves (stage A + stage B)
     const int n16 = lane & 15, kq = lane >> 4;
     const int ph = n16 >> 2, cl = n16 & 3, pa = ph >> 1, pb = ph & 1;
@@ -313,8 +332,16 @@ __global__ __launch_bounds__(512, 4) void k_head_stream(HeadParams2 p) {
       for (int j = 0; j < 5; j++) d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bw2[j], d, 0, 0, 0);
       // D: rows = pixels px0 + 4 kq + i, column n16 = (phase, channel)
       const int col = 2 * (px0 + 4 * kq) + pb - (side ? 46 : -1);
+      float *w = &u2r[cl * HS_PL2 + ((2 * pr + pa + 1) & (HS_NR2 - 1)) * HS_P2 + col];
+      const bool mir = ((2 * pr + pa + 1) & (HS_NR2 - 1)) < 2;  // rows 2 pr, 2 pr + 1 sit in slots 0 / 1 when pr % 8 is 7 / 0
 #pragma unroll
-      for (int i = 0; i < 4; i++) hs_u2_store(u2r, cl, 2 * pr + pa, col + 2 * i, hd_max_raw(d[i], 0.f));
+      for (int i = 0; i < 4; i++) w[2 * i] = hd_max_raw(d[i], 0.f);
+      if ((pr & 7) == 0 || (pr & 7) == 7) {  // wave-uniform
+        if (mir) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) w[HS_NR2 * HS_P2 + 2 * i] = hd_max_raw(d[i], 0.f);
+        }
+      }
       // exact frame cells + the clamp copies outside the plane (same wave: LDS operations of a wave stay in order)
       if ((side == 0 && hh == 0) || (side == 1 && hh == 1)) {  // the strip's frame column: 2 rows x 4 channels
         if (lane < 8) {
@@ -345,24 +372,23 @@ __global__ __launch_bounds__(512, 4) void k_head_stream(HeadParams2 p) {
       const float *a;   // A: cell (row qi - 1, column of the lane's quad - 1) of channel kq; rows + P2, columns + 1
       float *w;         // D: first of the 4 cells of the lane group's quads (channel cl of half 0, phase row / column)
       int gd;           // flat group of the lane group (D side)
-      float fv;         // exact frame-column cell of this lane (requested in front of the MFMAs)
+      float fv;         // exact frame-column cell of this lane (requested a sub-step ahead)
+      bool fcol;        // the lane group's group holds the strip's frame column
       bool hasf;        // wave-uniform: the tile touches the frame of the plane
     };
     const float *const a_lane = &u2r[kq * HS_PL2 + (n16 & 3) + side];
     float *const w_lane = &u3r[cl * HS_PL3 + pa * HS_P3 + pb + 1];
     const unsigned short *const ta_lane = &tabA[n16 >> 2], *const td_lane = &tabD[kq];
-    auto tile_setup = [&](int T, TileB &t) {
+    auto tile_setup = [&](int T, TileB &t) {  // T < HS_NTILES
       t.a = a_lane + ta_lane[4 * T];
-      t.w = w_lane + td_lane[4 * T];
+      const unsigned td = td_lane[4 * T];
+      t.w = w_lane + (td & 0x3FFFu);
       t.gd = 4 * T + kq;
-      // the strip's outer group (0 | 12) among groups g0 .. g0 + 3 (mod 13), or the first / last quad row
-      const int g0 = (4 * T) % HS_GPR;
-      t.hasf = 4 * T < HS_GPR || 4 * T + 3 >= 99 * HS_GPR || (side ? g0 >= 9 : (g0 == 0 || g0 >= 10));
-      t.fv = 0.f;
-      if (t.hasf) {
-        const int qi = (t.gd * 5042) >> 16, g = t.gd - HS_GPR * qi;
-        if (side ? g == 12 : g == 0) t.fv = fr3[((side ? 3 : 2) * 200 + 2 * qi + (n16 >> 3)) * 8 + (n16 & 7)];
-      }
+      t.fcol = (td & 0x8000u) != 0;
+      t.hasf = __builtin_amdgcn_ballot_w64((td & 0xC000u) != 0) != 0;  // the tile touches the frame of the plane
+      // exact frame-column cell of this lane: loaded by every lane (a valid address either way), used where fcol
+      const int qi = (t.gd * 5042) >> 16;
+      t.fv = fr3[((side ? 3 : 2) * 200 + 2 * qi + (n16 >> 3)) * 8 + (n16 & 7)];
     };
     auto tile_epilogue = [&](const TileB &t, const f32x4 d0, const f32x4 d1) {
 #pragma unroll
@@ -373,7 +399,7 @@ __global__ __launch_bounds__(512, 4) void k_head_stream(HeadParams2 p) {
     // exact frame cells of uprelu3 (and the clamp copies around the plane) for a tile that touches the frame
     auto tile_frames = [&](const TileB &t) {
       const int qi_d = (t.gd * 5042) >> 16, g_d = t.gd - HS_GPR * qi_d;
-      if (side ? g_d == 12 : g_d == 0) {  // lane group: 2 rows x 8 channels of the frame column + the clamp column
+      if (t.fcol) {  // lane group: 2 rows x 8 channels of the frame column + the clamp column
         const int yp = n16 >> 3, ch = n16 & 7, y = 2 * qi_d + yp;
         const float v = t.fv;
         const int cf = side ? 104 : 1, cc = side ? 105 : 0;
@@ -394,10 +420,7 @@ __global__ __launch_bounds__(512, 4) void k_head_stream(HeadParams2 p) {
         }
       }
     };
-    auto run_pair = [&](int T0, int T1) {
-      TileB t0, t1;
-      tile_setup(T0, t0);
-      tile_setup(T1, t1);
+    auto run_pair = [&](const TileB &t0, const TileB &t1) {
       f32x4 d00, d01, d10, d11;
 #pragma unroll
       for (int j = 0; j < 9; j++) {
@@ -412,9 +435,7 @@ __global__ __launch_bounds__(512, 4) void k_head_stream(HeadParams2 p) {
       if (t0.hasf) tile_frames(t0);
       if (t1.hasf) tile_frames(t1);
     };
-    auto run_single = [&](int T0) {
-      TileB t0;
-      tile_setup(T0, t0);
+    auto run_single = [&](const TileB &t0) {
       f32x4 d00, d01;
 #pragma unroll
       for (int j = 0; j < 9; j++) {
@@ -426,29 +447,59 @@ __global__ __launch_bounds__(512, 4) void k_head_stream(HeadParams2 p) {
       if (t0.hasf) tile_frames(t0);
     };
 
-    {  // prologue: uprelu2 row pairs 0 and 1, one tile per producer wave
-      float av[5];
-      stageA_load(wv >> 1, wv & 1, av);
-      stageA_compute(wv >> 1, wv & 1, av);
+    if (wv < 4) {  // prologue: uprelu2 row pairs 0 and 1, one tile per wave
+      float av0[5];
+      stageA_load(wv >> 1, wv & 1, av0);
+      stageA_compute(wv >> 1, wv & 1, av0);
     }
+    // every global load so far (the weights) has landed: without this the compiler's wait-count bookkeeping carries
+    // the weight loads into the loop as "maybe pending" and its in-order vmcnt waits then block on the loads of the
+    // loop itself (vmcnt(0); expcnt / lgkmcnt fields left at their maxima)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    // Software pipeline over the sub-steps: the tile set-up (table reads), the frame-column load of the NEXT
+    // sub-step's M-tile and the uprelu1 loads of its stage-A tile are all requested at the end of a sub-step, in front
+    // of the barrier; nothing is loaded in front of their use, so every vmcnt wait names loads a whole sub-step old.
+    // (vmcnt counts in order: one late load in front of a wait exposes the full HBM latency, ~1 us, per sub-step.)
+    TileB ta, tb;
+    float av[5];
+    int apr, ahh;
+    auto prepare = [&](int st) {  // for sub-step st
+      const int t0 = hs_tiles_done(st - 1), n = hs_tiles_done(st) - t0;
+      tile_setup(n > 0 ? t0 + wv : HS_NTILES - 1, ta);
+      tile_setup(n > 0 ? t0 + wv + 4 : HS_NTILES - 1, tb);
+      // stage-A tile of this wave in sub-step st (for the tiles of st + 1): tile id 2 pair + half belongs to wave id & 3
+      const int lo = 2 * hs_pairs_done(st), hi = 2 * hs_pairs_done(st + 1);
+      const int at = lo + ((wv - lo) & (HS_NB - 1));
+      apr = at < hi ? at >> 1 : -1;
+      ahh = at & 1;
+      stageA_load(max(apr, 0), ahh, av);
+    };
+    prepare(0);
     __syncthreads();
 #pragma unroll 1
     for (int st = 0; st < HS_NS; st++) {
-      // stage-A tile of this wave for the NEXT sub-step (tile (pair, half) belongs to wave (2 pair + half) & 3): its
-      // global loads fly while the M-tiles of stage B run
-      const int lo = 2 * hs_pairs_done(st), hi = 2 * hs_pairs_done(st + 1);  // tile ids 2 pair + half
-      const int at = lo + ((wv - lo) & 3);
-      const int apr = at < hi ? at >> 1 : -1, ahh = at & 1;
-      float av[5];
-      if (apr >= 0) stageA_load(apr, ahh, av);
+#if OFX_HEAD_HOOKS
+      if (p.ablate & 2) { __syncthreads(); continue; }
+#endif
       const int t0 = hs_tiles_done(st - 1), n = hs_tiles_done(st) - t0;
+      HS_STAMP(0);
       if (n > 0) {
-        run_pair(t0 + wv, t0 + wv + 4);
-        if (n == 9 && wv == 0) run_single(t0 + 8);
+        run_pair(ta, tb);
+        HS_STAMP(1);
+        if (n == 9 && wv == 0) {  // every eighth sub-step: a ninth tile, set up on the spot
+          tile_setup(t0 + 8, ta);
+          run_single(ta);
+        }
       }
+      HS_STAMP(2);
       if (apr >= 0) stageA_compute(apr, ahh, av);
+      HS_STAMP(3);
+      prepare(min(st + 1, HS_NS - 1));
+      HS_STAMP(4);
       __syncthreads();
+      HS_STAMP(5);
     }
+    HS_STAMP_OUT();
   } else {
     // ================================================================ consumer waves (stage C + arg-max)
     // stage-C weights: register r, lane L holds W[k = 16 r + (L >> 2)][phase L & 3]; an MFMA picks its k with ABID
@@ -458,7 +509,7 @@ __global__ __launch_bounds__(512, 4) void k_head_stream(HeadParams2 p) {
       const int k = 16 * r + (lane >> 2);
       wreg[r] = k < 72 ? p.w4eff_c[((k / 9) * 4 + (lane & 3)) * 9 + (k % 9)] : 0.f;
     }
-    const int task = 64 * (wv - 4) + lane;           // 250 two-pixel tasks per sub-step: 5 rows x 50
+    const int task = 64 * (wv - HS_NB) + lane;           // 250 two-pixel tasks per sub-step: 5 rows x 50
     const bool task_ok = task < 250;
     const int tk = task_ok ? task : 249;
     const int r_in = tk / 50, jx = tk - 50 * r_in;   // row of the block, pixel pair of the row
@@ -475,6 +526,10 @@ __global__ __launch_bounds__(512, 4) void k_head_stream(HeadParams2 p) {
     for (int st = 0; st < HS_NS; st++) {
       const int R = 5 * st - 8 + r_in;               // uprelu3 row of the lane's two pixels
       const bool ok = task_ok && R >= 0 && R < 200;
+#if OFX_HEAD_HOOKS
+      if (p.ablate & 1) { __syncthreads(); continue; }
+#endif
+      HS_STAMP(0);
       if (__builtin_amdgcn_ballot_w64(ok) != 0) {    // wave-uniform
         const int Rc = min(max(R, 0), 199);
         // zero-padding corrections of frame pixels (global memory: requested up front, zero for the other lanes)
@@ -531,6 +586,7 @@ __global__ __launch_bounds__(512, 4) void k_head_stream(HeadParams2 p) {
             }
           __builtin_amdgcn_sched_barrier(0);
         }
+        HS_STAMP(1);
         f32x4 o[2];
 #pragma unroll
         for (int px = 0; px < 2; px++) o[px] = acc[px][0] + acc[px][1];
@@ -573,8 +629,11 @@ __global__ __launch_bounds__(512, 4) void k_head_stream(HeadParams2 p) {
           ts = ok ? tsn : ts;
         }
       }
+      HS_STAMP(4);
       __syncthreads();
+      HS_STAMP(5);
     }
+    HS_STAMP_OUT();
 
     // ---- arg-max of the strip (first maximum in C order) ----
     const int sst = ts >> 3, slot = ts & 7;
@@ -598,11 +657,40 @@ size_t ofx_head_frame_bytes(size_t S, size_t *u2fr, size_t *u3fr, size_t *c4) {
   return *u2fr + *u3fr + *c4;
 }
 
-int ofx_launch_head(ofx_handle *h, const HeadParams2 &p) {
+int ofx_launch_head(ofx_handle *h, const HeadParams2 &p0) {
+  HeadParams2 p = p0;
+#if OFX_HEAD_HOOKS
+  { const char *e = getenv("OFX_HEAD_ABLATE"); p.ablate = e ? atoi(e) : 0; }  // diagnostics: 1 no stage C, 2 no stage A / B
+  static unsigned long long *dbg = nullptr;
+  static int dbg_calls = 0;
+  const unsigned dbg_blocks = (unsigned)(((p.S + 7) / 8) * 16);
+  p.dbg = nullptr;
+  if (getenv("OFX_HEAD_STAMPS")) {  // s_memtime stamps per wave, printed for the 20th forward
+    if (!dbg) (void)hipMalloc(&dbg, (size_t)dbg_blocks * 6 * (HS_NB + 4) * 8);
+    if (++dbg_calls == 20) p.dbg = dbg;
+  }
+#endif
   hipLaunchKernelGGL(k_head_frames, dim3((unsigned)p.S), dim3(HF_THREADS), 0, h->stream, p);
   OFX_HIP(hipGetLastError());
   const unsigned blocks = (unsigned)(((p.S + 7) / 8) * 16);
-  hipLaunchKernelGGL(k_head_stream, dim3(blocks), dim3(512), 0, h->stream, p);
+  hipLaunchKernelGGL(k_head_stream, dim3(blocks), dim3(HS_THREADS), 0, h->stream, p);
   OFX_HIP(hipGetLastError());
+#if OFX_HEAD_HOOKS
+  if (p.dbg) {
+    (void)hipStreamSynchronize(h->stream);
+    unsigned long long *hst = (unsigned long long *)malloc((size_t)blocks * 6 * (HS_NB + 4) * 8);
+    (void)hipMemcpy(hst, p.dbg, (size_t)blocks * 6 * (HS_NB + 4) * 8, hipMemcpyDeviceToHost);
+    double sum[2][6] = {{0}};
+    for (unsigned b = 0; b < blocks; b++)
+      for (int w = 0; w < HS_NB + 4; w++)
+        for (int i = 0; i < 6; i++) sum[w >= HS_NB][i] += (double)hst[((size_t)b * (HS_NB + 4) + w) * 6 + i] / (w >= HS_NB ? 4.0 : (double)HS_NB);
+    for (int r = 0; r < 2; r++) {
+      fprintf(stderr, "head stamps %s (cycles per wave and sub-step):", r ? "C" : "B");
+      for (int i = 0; i < 6; i++) fprintf(stderr, " %.0f", sum[r][i] / ((double)blocks * HS_NS));
+      fprintf(stderr, "\n");
+    }
+    free(hst);
+  }
+#endif
   return OFX_OK;
 }

@@ -2348,7 +2348,7 @@ static int policy_forward_impl(ofx_handle *h, const float *weights, int N, int M
     hp2.w3mf = ws.prep + L.w3mf; hp2.b3 = ws.prep + L.ub[2]; hp2.w3raw = ws.prep + L.uw[2];
     hp2.w4eff_c = ws.prep + L.w4eff_c; hp2.b4 = ws.prep + L.b4; hp2.w4raw = ws.prep + L.w4raw;
     hp2.u2fr = ws.u2fr; hp2.u3fr = ws.u3fr; hp2.c4 = ws.c4;
-    hp2.mask = ship_mask; hp2.best = ws.best; hp2.heat = heatmap; hp2.probe = probe; hp2.ptr_probe = probe ? ptr_probe : nullptr;
+    hp2.ablate = 0; hp2.dbg = nullptr; hp2.mask = ship_mask; hp2.best = ws.best; hp2.heat = heatmap; hp2.probe = probe; hp2.ptr_probe = probe ? ptr_probe : nullptr;
     const int pb = h->prof_base;
     if (pb >= 0 && (rc = ofx_event_record(h, pb))) return rc;
     if ((rc = ofx_launch_head(h, hp2))) return rc;
