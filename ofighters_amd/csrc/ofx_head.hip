@@ -295,10 +295,10 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
   // Both roles run the same number of barriers (1 + HS_NS); each has its own loop so that the register allocator
   // sees only one role's long-lived state at a time.
   if (wv < HS_NB) {
-    // ================================================================ producer waves (stage A + stage B)
+    // ================================================================ producer waves (stage B)
     const int n16 = lane & 15, kq = lane >> 4;
     const int ph = n16 >> 2, cl = n16 & 3, pa = ph >> 1, pb = ph & 1;
-    float bw[2][9], bw2[5];  // B operands, constant over the strip
+    float bw[2][9];          // B operands, constant over the strip
     f32x4 binit3[2];         // the folded bias as the C operand of a tile's first MFMA
 #pragma unroll
     for (int hf = 0; hf < 2; hf++) {
@@ -307,65 +307,7 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
       const float b = p.b3[4 * hf + cl];
       binit3[hf] = (f32x4){b, b, b, b};
     }
-#pragma unroll
-    for (int j = 0; j < 5; j++) bw2[j] = p.w2mf[(4 * j + kq) * 16 + n16];
-    const float bias2 = p.b2[cl];
-    const float *up1s = p.up1 + (size_t)s * 5000;
-    const float *fr2 = p.u2fr + (size_t)s * 1600, *fr3 = p.u3fr + (size_t)s * 6400;
-
-    // ---- stage A: one M-tile = 16 uprelu1 pixels of row pair `pr` -> 2 x 32 cells x 4 channels of uprelu2 ----
-    // A[pixel][k = 4 j + kq]: tap = 2 j + (kq >> 1), ci = kq & 1 (K = 18, padded to 20)
-    auto stageA_load = [&](int pr, int hh, float *av) {
-      const int px0 = side ? (hh ? 34 : 23) : (hh ? 11 : 0);
-      const int j1 = px0 + n16;
-#pragma unroll
-      for (int j = 0; j < 5; j++) {
-        const int tap = min(2 * j + (kq >> 1), 8);
-        const int yy = min(max(pr + tap / 3 - 1, 0), 49), xx = min(max(j1 + tap % 3 - 1, 0), 49);
-        av[j] = up1s[((kq & 1) * 50 + yy) * 50 + xx];
-      }
-    };
-    auto stageA_compute = [&](int pr, int hh, const float *av) {
-      const int px0 = side ? (hh ? 34 : 23) : (hh ? 11 : 0);
-      f32x4 d = {bias2, bias2, bias2, bias2};
-#pragma unroll
-      for (int j = 0; j < 5; j++) d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bw2[j], d, 0, 0, 0);
-      // D: rows = pixels px0 + 4 kq + i, column n16 = (phase, channel)
-      const int col = 2 * (px0 + 4 * kq) + pb - (side ? 46 : -1);
-      float *w = &u2r[cl * HS_PL2 + ((2 * pr + pa + 1) & (HS_NR2 - 1)) * HS_P2 + col];
-      const bool mir = ((2 * pr + pa + 1) & (HS_NR2 - 1)) < 2;  // rows 2 pr, 2 pr + 1 sit in slots 0 / 1 when pr % 8 is 7 / 0
-#pragma unroll
-      for (int i = 0; i < 4; i++) w[2 * i] = hd_max_raw(d[i], 0.f);
-      if ((pr & 7) == 0 || (pr & 7) == 7) {  // wave-uniform
-        if (mir) {
-#pragma unroll
-          for (int i = 0; i < 4; i++) w[HS_NR2 * HS_P2 + 2 * i] = hd_max_raw(d[i], 0.f);
-        }
-      }
-      // exact frame cells + the clamp copies outside the plane (same wave: LDS operations of a wave stay in order)
-      if ((side == 0 && hh == 0) || (side == 1 && hh == 1)) {  // the strip's frame column: 2 rows x 4 channels
-        if (lane < 8) {
-          const int yp = lane >> 2, ch = lane & 3, y = 2 * pr + yp;
-          const float v = fr2[((side ? 3 : 2) * 100 + y) * 4 + ch];
-          const int cf = side ? 53 : 1, cc = side ? 54 : 0;
-          hs_u2_store(u2r, ch, y, cf, v);
-          hs_u2_store(u2r, ch, y, cc, v);
-          if (y == 0) { hs_u2_store(u2r, ch, -1, cf, v); hs_u2_store(u2r, ch, -1, cc, v); }
-          if (y == 99) { hs_u2_store(u2r, ch, 100, cf, v); hs_u2_store(u2r, ch, 100, cc, v); }
-        }
-      }
-      if (pr == 0 || pr == 49) {  // frame row of the plane (and its clamp copy) over the tile's 32 columns
-        const int c = lane >> 1, chh = lane & 1, x = 2 * px0 + c;
-        const int y = pr ? 99 : 0, yc = pr ? 100 : -1;
-        const f32x2 v = *reinterpret_cast<const f32x2 *>(fr2 + ((pr ? 1 : 0) * 100 + x) * 4 + 2 * chh);
-        const int ci2 = x - (side ? 46 : -1);
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-          hs_u2_store(u2r, 2 * chh + k, y, ci2, v[k]);
-          hs_u2_store(u2r, 2 * chh + k, yc, ci2, v[k]);
-        }
-      }
-    };
+    const float *fr3 = p.u3fr + (size_t)s * 6400;
 
     // ---- stage B: M-tile T = groups 4 T .. 4 T + 3 (flat over quad rows), both channel halves from one A gather ----
     struct TileB {
@@ -447,35 +389,22 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
       if (t0.hasf) tile_frames(t0);
     };
 
-    if (wv < 4) {  // prologue: uprelu2 row pairs 0 and 1, one tile per wave
-      float av0[5];
-      stageA_load(wv >> 1, wv & 1, av0);
-      stageA_compute(wv >> 1, wv & 1, av0);
-    }
     // every global load so far (the weights) has landed: without this the compiler's wait-count bookkeeping carries
     // the weight loads into the loop as "maybe pending" and its in-order vmcnt waits then block on the loads of the
     // loop itself (vmcnt(0); expcnt / lgkmcnt fields left at their maxima)
     __builtin_amdgcn_s_waitcnt(0x0F70);
-    // Software pipeline over the sub-steps: the tile set-up (table reads), the frame-column load of the NEXT
-    // sub-step's M-tile and the uprelu1 loads of its stage-A tile are all requested at the end of a sub-step, in front
-    // of the barrier; nothing is loaded in front of their use, so every vmcnt wait names loads a whole sub-step old.
-    // (vmcnt counts in order: one late load in front of a wait exposes the full HBM latency, ~1 us, per sub-step.)
+    // Software pipeline over the sub-steps: the tile set-ups (table reads) and the frame-column loads of the NEXT
+    // sub-step's M-tiles are requested at the end of a sub-step, in front of the barrier; nothing is loaded in front of
+    // its use, so every vmcnt wait names loads a whole sub-step old.  (vmcnt counts in order: one late load in front of
+    // a wait exposes the full HBM latency, ~1 us, per sub-step.)
     TileB ta, tb;
-    float av[5];
-    int apr, ahh;
     auto prepare = [&](int st) {  // for sub-step st
       const int t0 = hs_tiles_done(st - 1), n = hs_tiles_done(st) - t0;
       tile_setup(n > 0 ? t0 + wv : HS_NTILES - 1, ta);
       tile_setup(n > 0 ? t0 + wv + 4 : HS_NTILES - 1, tb);
-      // stage-A tile of this wave in sub-step st (for the tiles of st + 1): tile id 2 pair + half belongs to wave id & 3
-      const int lo = 2 * hs_pairs_done(st), hi = 2 * hs_pairs_done(st + 1);
-      const int at = lo + ((wv - lo) & (HS_NB - 1));
-      apr = at < hi ? at >> 1 : -1;
-      ahh = at & 1;
-      stageA_load(max(apr, 0), ahh, av);
     };
     prepare(0);
-    __syncthreads();
+    __syncthreads();  // the consumers' prologue (uprelu2 row pairs 0, 1)
 #pragma unroll 1
     for (int st = 0; st < HS_NS; st++) {
 #if OFX_HEAD_HOOKS
@@ -492,8 +421,6 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
         }
       }
       HS_STAMP(2);
-      if (apr >= 0) stageA_compute(apr, ahh, av);
-      HS_STAMP(3);
       prepare(min(st + 1, HS_NS - 1));
       HS_STAMP(4);
       __syncthreads();
@@ -501,7 +428,12 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
     }
     HS_STAMP_OUT();
   } else {
-    // ================================================================ consumer waves (stage C + arg-max)
+    // ================================================================ consumer waves (stage C + arg-max + stage A)
+    // the consumers are the MFMA-dense half of the workgroup and finish last: their instructions go first when a
+    // producer wave of the same SIMD competes for the issue slot (A/B on the chip: 17.2 against 17.9 ms)
+    __builtin_amdgcn_s_setprio(1);
+    // Every VALU instruction here is paid in matrix throughput (the f32 MFMAs and the VALU share the SIMD's issue
+    // slots), so the per-pass bookkeeping is kept to running counters and the arg-max to a snapshot of the best pass.
     // stage-C weights: register r, lane L holds W[k = 16 r + (L >> 2)][phase L & 3]; an MFMA picks its k with ABID
     float wreg[5];
 #pragma unroll
@@ -509,38 +441,126 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
       const int k = 16 * r + (lane >> 2);
       wreg[r] = k < 72 ? p.w4eff_c[((k / 9) * 4 + (lane & 3)) * 9 + (k % 9)] : 0.f;
     }
-    const int task = 64 * (wv - HS_NB) + lane;           // 250 two-pixel tasks per sub-step: 5 rows x 50
+    const int n16 = lane & 15, kq = lane >> 4;
+    const int ph = n16 >> 2, cl = n16 & 3, pa = ph >> 1, pb = ph & 1;
+    const int cw = wv - HS_NB;
+    float bw2[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) bw2[j] = p.w2mf[(4 * j + kq) * 16 + n16];
+    const float bias2 = p.b2[cl];
+    const float *up1s = p.up1 + (size_t)s * 5000;
+    const float *fr2 = p.u2fr + (size_t)s * 1600;
+    // ---- stage A (run by the consumer waves behind their stage-C pass: they wait at the barrier otherwise): one M-tile = 16 uprelu1 pixels of row pair `pr` -> 2 x 32 cells x 4 channels of uprelu2 ----
+    // A[pixel][k = 4 j + kq]: tap = 2 j + (kq >> 1), ci = kq & 1 (K = 18, padded to 20)
+    auto stageA_load = [&](int pr, int hh, float *av) {
+      const int px0 = side ? (hh ? 34 : 23) : (hh ? 11 : 0);
+      const int j1 = px0 + n16;
+#pragma unroll
+      for (int j = 0; j < 5; j++) {
+        const int tap = min(2 * j + (kq >> 1), 8);
+        const int yy = min(max(pr + tap / 3 - 1, 0), 49), xx = min(max(j1 + tap % 3 - 1, 0), 49);
+        av[j] = up1s[((kq & 1) * 50 + yy) * 50 + xx];
+      }
+    };
+    auto stageA_compute = [&](int pr, int hh, const float *av) {
+      const int px0 = side ? (hh ? 34 : 23) : (hh ? 11 : 0);
+      f32x4 d = {bias2, bias2, bias2, bias2};
+#pragma unroll
+      for (int j = 0; j < 5; j++) d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bw2[j], d, 0, 0, 0);
+      // D: rows = pixels px0 + 4 kq + i, column n16 = (phase, channel)
+      const int col = 2 * (px0 + 4 * kq) + pb - (side ? 46 : -1);
+      float *w = &u2r[cl * HS_PL2 + ((2 * pr + pa + 1) & (HS_NR2 - 1)) * HS_P2 + col];
+      const bool mir = ((2 * pr + pa + 1) & (HS_NR2 - 1)) < 2;  // rows 2 pr, 2 pr + 1 sit in slots 0 / 1 when pr % 8 is 7 / 0
+#pragma unroll
+      for (int i = 0; i < 4; i++) w[2 * i] = hd_max_raw(d[i], 0.f);
+      if ((pr & 7) == 0 || (pr & 7) == 7) {  // wave-uniform
+        if (mir) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) w[HS_NR2 * HS_P2 + 2 * i] = hd_max_raw(d[i], 0.f);
+        }
+      }
+      // exact frame cells + the clamp copies outside the plane (same wave: LDS operations of a wave stay in order)
+      if ((side == 0 && hh == 0) || (side == 1 && hh == 1)) {  // the strip's frame column: 2 rows x 4 channels
+        if (lane < 8) {
+          const int yp = lane >> 2, ch = lane & 3, y = 2 * pr + yp;
+          const float v = fr2[((side ? 3 : 2) * 100 + y) * 4 + ch];
+          const int cf = side ? 53 : 1, cc = side ? 54 : 0;
+          hs_u2_store(u2r, ch, y, cf, v);
+          hs_u2_store(u2r, ch, y, cc, v);
+          if (y == 0) { hs_u2_store(u2r, ch, -1, cf, v); hs_u2_store(u2r, ch, -1, cc, v); }
+          if (y == 99) { hs_u2_store(u2r, ch, 100, cf, v); hs_u2_store(u2r, ch, 100, cc, v); }
+        }
+      }
+      if (pr == 0 || pr == 49) {  // frame row of the plane (and its clamp copy) over the tile's 32 columns
+        const int c = lane >> 1, chh = lane & 1, x = 2 * px0 + c;
+        const int y = pr ? 99 : 0, yc = pr ? 100 : -1;
+        const f32x2 v = *reinterpret_cast<const f32x2 *>(fr2 + ((pr ? 1 : 0) * 100 + x) * 4 + 2 * chh);
+        const int ci2 = x - (side ? 46 : -1);
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+          hs_u2_store(u2r, 2 * chh + k, y, ci2, v[k]);
+          hs_u2_store(u2r, 2 * chh + k, yc, ci2, v[k]);
+        }
+      }
+    };
+
+    const int task = 64 * (wv - HS_NB) + lane;       // 250 two-pixel tasks per sub-step: 5 rows x 50
     const bool task_ok = task < 250;
     const int tk = task_ok ? task : 249;
     const int r_in = tk / 50, jx = tk - 50 * r_in;   // row of the block, pixel pair of the row
     const float bias4 = p.b4[0];
     const f32x4 binit4 = {bias4, bias4, bias4, bias4};
-    const bool fcol = side ? jx == 49 : jx == 0;     // the lane owns pixels of the strip's frame column
+    const bool fcol = task_ok && (side ? jx == 49 : jx == 0);  // the lane owns pixels of the strip's frame column
     const float *c4s = p.c4 + (size_t)s * 1600;
     const int x0 = 100 * side + 2 * jx;              // uprelu3 column of the lane's first pixel
+    // running per-lane state: R = uprelu3 row of the lane's pixels in this sub-step (+5 per sub-step); q[dy] = byte
+    // offset of ring row R + dy - 1 at the lane's column (+5 rows per sub-step, wrapped at 16 rows)
+    constexpr unsigned PB = HS_P3 * 4, RING = HS_NR3 * PB;
+    const unsigned lcol = (unsigned)(2 * jx + 4 * side) * 4;
+    int R = r_in - 8;
+    unsigned q[3];
+#pragma unroll
+    for (int dy = 0; dy < 3; dy++) q[dy] = (unsigned)((R + dy - 1) & (HS_NR3 - 1)) * PB + lcol;
+    const unsigned qlim = RING + lcol;
+    int coff = (side ? 3 : 2) * 400 + 2 * R;         // frame-column correction of the lane's two heat-map rows
     float tv = -INFINITY;
-    int ts = 0;
+    int tst = 0;
+    f32x4 snap[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};  // the 8 values of the pass that holds the lane's maximum
+    const char *const u3b = reinterpret_cast<const char *>(u3r);
 
-    __syncthreads();  // the producers' prologue
+    {  // prologue: uprelu2 row pairs 0 and 1, one tile per consumer wave
+      float av0[5];
+      stageA_load(cw >> 1, cw & 1, av0);
+      stageA_compute(cw >> 1, cw & 1, av0);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // see the producers
+    // stage-A tile of this wave in sub-step st (uprelu2 rows for the M-tiles of st + 1): tile id 2 pair + half belongs to
+    // wave id & 3; its uprelu1 loads are requested one sub-step ahead
+    float av[5];
+    int apr, ahh;
+    auto stageA_pick = [&](int st) {
+      const int lo = 2 * hs_pairs_done(st), hi = 2 * hs_pairs_done(st + 1);
+      const int at = lo + ((cw - lo) & 3);
+      apr = at < hi ? at >> 1 : -1;
+      ahh = at & 1;
+      stageA_load(max(apr, 0), ahh, av);
+    };
+    stageA_pick(0);
+    __syncthreads();
 #pragma unroll 1
     for (int st = 0; st < HS_NS; st++) {
-      const int R = 5 * st - 8 + r_in;               // uprelu3 row of the lane's two pixels
-      const bool ok = task_ok && R >= 0 && R < 200;
+      const bool ok = task_ok && (unsigned)R < 200u;
 #if OFX_HEAD_HOOKS
       if (p.ablate & 1) { __syncthreads(); continue; }
 #endif
       HS_STAMP(0);
       if (__builtin_amdgcn_ballot_w64(ok) != 0) {    // wave-uniform
-        const int Rc = min(max(R, 0), 199);
         // zero-padding corrections of frame pixels (global memory: requested up front, zero for the other lanes)
         f32x2 ccol = {0.f, 0.f};
         f32x4 crow = {0.f, 0.f, 0.f, 0.f};
-        if (fcol) ccol = *reinterpret_cast<const f32x2 *>(c4s + (side ? 3 : 2) * 400 + 2 * Rc);
+        if (fcol && ok) ccol = *reinterpret_cast<const f32x2 *>(c4s + coff);
         const bool edge = st < 3 || st > 38;         // wave-uniform: the block may hold row 0 or row 199
-        if (edge && (Rc == 0 || Rc == 199)) crow = *reinterpret_cast<const f32x4 *>(c4s + (Rc ? 1 : 0) * 400 + 2 * x0);
-        const float *rowp[3];
-#pragma unroll
-        for (int dy = 0; dy < 3; dy++) rowp[dy] = &u3r[((Rc + dy - 1) & (HS_NR3 - 1)) * HS_P3 + 2 * jx + 4 * side];
+        if (edge && ok && (R == 0 || R == 199)) crow = *reinterpret_cast<const f32x4 *>(c4s + (R ? 1 : 0) * 400 + 2 * x0);
         // accumulators [pixel][channel half]: 4 independent MFMA chains, combined at the end
         f32x4 acc[2][2];
 #pragma unroll
@@ -555,9 +575,9 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
           const int c = t / 3, dy = t % 3;
 #pragma unroll
           for (int hf = 0; hf < 2; hf++) {
-            const float *q = rowp[dy] + (c + 4 * hf) * HS_PL3;
-            V[t % 3][hf][0] = *(hs_lds_v2 *)(q);
-            V[t % 3][hf][1] = *(hs_lds_v2 *)(q + 2);
+            const char *qq = u3b + q[dy] + (c + 4 * hf) * (HS_PL3 * 4);
+            V[t % 3][hf][0] = *(hs_lds_v2 *)(qq);
+            V[t % 3][hf][1] = *(hs_lds_v2 *)(qq + 8);
           }
         };
         ldv(0);
@@ -606,28 +626,29 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
           const int qx = p.probe[2 * s] - 2 * x0, qy = p.probe[2 * s + 1] - 2 * R;
           if (qx >= 0 && qx < 4 && qy >= 0 && qy < 2) p.ptr_probe[s] = o[qx >> 1][2 * qy + (qx & 1)];
         }
-        // the lane visits its values in increasing flat index (rows grow with the sub-step): strict > keeps the first
-        // (rarely taken once the running maximum has settled: first the maximum of the 8 values, the slot search
-        // only in the waves where a lane improves)
-        const float m8 = fmaxf(fmaxf(fmaxf(o[0][0], o[0][1]), fmaxf(o[0][2], o[0][3])),
-                               fmaxf(fmaxf(o[1][0], o[1][1]), fmaxf(o[1][2], o[1][3])));
-        if (__builtin_amdgcn_ballot_w64(ok && m8 > tv) != 0) {
-          float tvn = tv;
-          int tsn = ts;
-#pragma unroll
-          for (int a = 0; a < 2; a++)
-#pragma unroll
-            for (int px = 0; px < 2; px++)
-#pragma unroll
-              for (int b = 0; b < 2; b++) {
-                const float val = o[px][2 * a + b];
-                const bool gt = val > tvn;
-                tvn = gt ? val : tvn;
-                tsn = gt ? st * 8 + (a * 4 + px * 2 + b) : tsn;
-              }
-          tv = ok ? tvn : tv;
-          ts = ok ? tsn : ts;
+        // arg-max: the maximum of the pass (med3 with +inf = max without the canonicalising pre-op), and where it beats
+        // the lane's running maximum (strictly: the rows grow with the sub-step, so the first maximum in C order
+        // stays) the 8 values are kept; the position inside the pass is looked up once, behind the loop
+        const float m01 = hd_max_raw(hd_max_raw(o[0][0], o[0][1]), hd_max_raw(o[0][2], o[0][3]));
+        const float m23 = hd_max_raw(hd_max_raw(o[1][0], o[1][1]), hd_max_raw(o[1][2], o[1][3]));
+        const float m8 = hd_max_raw(m01, m23);
+        if (ok && m8 > tv) {
+          tv = m8;
+          tst = st;
+          snap[0] = o[0];
+          snap[1] = o[1];
         }
+      }
+      HS_STAMP(2);
+      if (apr >= 0) stageA_compute(apr, ahh, av);
+      stageA_pick(min(st + 1, HS_NS - 1));
+      HS_STAMP(3);
+      R += 5;
+      coff += 10;
+#pragma unroll
+      for (int dy = 0; dy < 3; dy++) {  // + 5 rows, wrapped at the ring size
+        const unsigned n = q[dy] + 5 * PB;
+        q[dy] = n >= qlim ? n - RING : n;
       }
       HS_STAMP(4);
       __syncthreads();
@@ -636,8 +657,13 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
     HS_STAMP_OUT();
 
     // ---- arg-max of the strip (first maximum in C order) ----
-    const int sst = ts >> 3, slot = ts & 7;
-    const int Rb = 5 * sst - 8 + r_in;
+    int slot = 0;  // first of the 8 values, in flat order (row a, pixel, column b), that equals the maximum
+#pragma unroll
+    for (int i = 7; i >= 0; i--) {
+      const int a = i >> 2, px = (i >> 1) & 1, b = i & 1;
+      if (snap[px][2 * a + b] == tv) slot = i;
+    }
+    const int Rb = 5 * tst - 8 + r_in;
     const int y = 2 * Rb + (slot >> 2), x = 2 * x0 + (slot & 3);
     unsigned long long key = 0ull;
     if (tv > -INFINITY) key = ((unsigned long long)hd_ordered_f32(tv) << 32) | (unsigned long long)(~(unsigned)(y * HD_PS + x));
