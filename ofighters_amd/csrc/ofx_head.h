@@ -12,6 +12,8 @@ struct HeadParams2 {
   const float *w3raw;           // BN-folded upconv3 kernel [9][4][8]
   const float *w4eff_c, *b4;    // upconv4 phase weights [ci 8][phase 4][tap 9], bias [1]
   const float *w4raw;           // upconv4 kernel [9][8]
+  const float *w2fr, *w3fr;     // frame-line variants of the phase weights (PrepLayout::w2fr, w3fr)
+  const float *efr;             // frame phase weights of upconv4 [line h|v][side][parity 2][3][8] (PrepLayout::efr)
   float *u2fr;                  // [S][4][100][4] exact frame lines of uprelu2: row 0, row 99, col 0, col 99
   float *u3fr;                  // [S][4][200][8] exact frame lines of uprelu3
   float *c4;                    // [S][4][400]   zero-padding corrections of the heat-map frame pixels

@@ -78,7 +78,9 @@ constexpr int HF_B2C = HF_B2R + 1600;          // u2cb[4][100][4]: uprelu2 colum
 constexpr int HF_U3L = HF_B2C + 1600;          // u3l[4][200][8]: exact frame lines of uprelu3 (top, bottom, left, right)
 constexpr int HF_TOTAL = HF_U3L + 6400;        // 17048 floats = 68 KB
 
-__global__ __launch_bounds__(HF_THREADS) void k_head_frames(HeadParams2 p) {
+// Reference version: everything from the definition (up-sample, then convolve with zero padding) on the VALU.  Kept
+// for the agreement test of the phase-form version below (OFX_HEAD_FRAMES_REF=1).
+__global__ __launch_bounds__(HF_THREADS) void k_head_frames_ref(HeadParams2 p) {
   __shared__ __align__(16) float sm[HF_TOTAL];
   const int s = blockIdx.x, tid = threadIdx.x;
   if (p.mask && !p.mask[s]) return;  // block-uniform
@@ -221,6 +223,211 @@ __global__ __launch_bounds__(HF_THREADS) void k_head_frames(HeadParams2 p) {
           if (yy < 0 || yy > 399) continue;  // cannot happen (dy == d0 covers it)
           for (int ci = 0; ci < 8; ci++) acc += p.w4raw[(dy * 3 + dx) * 8 + ci] * hf_up(u3l + cl * 1600 + ci, 8, 200, yy);
         }
+      }
+    }
+    p.c4[(size_t)s * 1600 + e] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_head_frames: the same lines in PHASE FORM on the matrix cores.  A frame line of a layer's output is one phase
+// row (column) of the low-resolution grid's first / last row (column), with the taps that fall into the zero padding
+// left out of the pre-combined phase weights (PrepLayout::w2fr / w3fr): no up-sampled value is ever formed.
+//   uprelu2: four 2-wide bands (rows {0,1}, {98,99}, columns {0,1}, {98,99}) = all four phases of the first / last
+//            low-res row / column: 4 bands x 4 M-tiles of 16 pixels, K = 20, N = 16
+//   uprelu3: the four frame lines = one phase row / column of the first / last quad row / column, from the uprelu2
+//            bands: 4 lines x 7 M-tiles of 16 quads, K = 36, N = 2 parities x 8 channels
+//   heat-map corrections: PrepLayout::efr along the uprelu3 lines (VALU, 24 MACs per pixel)
+// The four corner cells of each plane lose taps in both directions: they are evaluated from the definition.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int HG_THREADS = 256;
+constexpr int HG_L1 = 0;                     // l1p[2][52][52]: uprelu1, clamp-extended by one cell; dead once the bands stand
+constexpr int HG_U3 = 0;                     // u3l[4][200][8]: over l1p
+constexpr int HG_RB = 6400;                  // u2rb[4][102][4]: uprelu2 rows {0,1,98,99}, columns -1 .. 100 (clamp copies)
+constexpr int HG_CB = HG_RB + 4 * 102 * 4;   // u2cb[4][102][4]: uprelu2 columns {0,1,98,99}, rows -1 .. 100
+constexpr int HG_TOTAL = HG_CB + 4 * 102 * 4;  // 9664 floats = 38 KB: four workgroups per CU
+static_assert(2 * 52 * 52 <= 6400, "l1p fits under u3l");
+
+// zero-padded conv output at a plane corner from the definition: cell (yc, xc) in {0, n2 - 1}^2 of the up-sampled
+// (n2 = 2 n) plane of `get(y, x, ci)` (low-res, n x n)
+template <int CIN, int COUT, class G>
+__device__ __forceinline__ float hg_corner(G get, int n, int yc, int xc, const float *w, float bias, int co) {
+  float acc = bias;
+  for (int dy = 0; dy < 3; dy++) {
+    const int uy = yc + dy - 1;
+    if (uy < 0 || uy >= 2 * n) continue;
+    int ya, yb; float wy;
+    hf_taps(uy, n, ya, yb, wy);
+    for (int dx = 0; dx < 3; dx++) {
+      const int ux = xc + dx - 1;
+      if (ux < 0 || ux >= 2 * n) continue;
+      int xa, xb; float wx;
+      hf_taps(ux, n, xa, xb, wx);
+      for (int ci = 0; ci < CIN; ci++) {
+        const float a = get(ya, xa, ci), b = get(ya, xb, ci), d = get(yb, xa, ci), g = get(yb, xb, ci);
+        const float top = a + (b - a) * wx, bot = d + (g - d) * wx;
+        acc += w[((dy * 3 + dx) * CIN + ci) * COUT + co] * (top + (bot - top) * wy);
+      }
+    }
+  }
+  return fmaxf(acc, 0.f);
+}
+
+__global__ __launch_bounds__(HG_THREADS) void k_head_frames(HeadParams2 p) {
+  __shared__ __align__(16) float sm[HG_TOTAL];
+  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  if (p.mask && !p.mask[s]) return;  // block-uniform
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n16 = lane & 15, kq = lane >> 4;
+  float *l1p = sm + HG_L1, *u2rb = sm + HG_RB, *u2cb = sm + HG_CB, *u3l = sm + HG_U3;
+
+  for (int e = tid; e < 2 * 52 * 52; e += HG_THREADS) {
+    const int c = e % 52, r = (e / 52) % 52, ci = e / 2704;
+    l1p[e] = p.up1[(size_t)s * 5000 + (ci * 50 + min(max(r - 1, 0), 49)) * 50 + min(max(c - 1, 0), 49)];
+  }
+  __syncthreads();
+
+  // ---- uprelu2 bands: band v, M-tile m: pixels 16 m + n16 along the band (50), all four phases ----
+  // wave = band: its B operands are loaded once
+  float bw2[5];
+#pragma unroll
+  for (int jj = 0; jj < 5; jj++) bw2[jj] = p.w2fr[(wv * 20 + 4 * jj + kq) * 16 + n16];
+  float bw3[9];
+#pragma unroll
+  for (int jj = 0; jj < 9; jj++) bw3[jj] = p.w3fr[(wv * 36 + 4 * jj + kq) * 16 + n16];
+#pragma unroll 1
+  for (int m = 0; m < 4; m++) {
+    const int v = wv;
+    const int pp = min(16 * m + n16, 49);
+    const int i = v == 0 ? 0 : v == 1 ? 49 : pp, j = v == 2 ? 0 : v == 3 ? 49 : pp;  // low-res pixel of the A row
+    const float bias = p.b2[n16 & 3];
+    f32x4 d = {bias, bias, bias, bias};
+#pragma unroll
+    for (int jj = 0; jj < 5; jj++) {  // k = 4 jj + kq: tap = 2 jj + (kq >> 1), ci = kq & 1 (k >= 18: zero weights)
+      const int tap = min(2 * jj + (kq >> 1), 8);
+      const float a = l1p[((kq & 1) * 52 + i + tap / 3) * 52 + j + tap % 3];
+      d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw2[jj], d, 0, 0, 0);
+    }
+    // D: rows = pixels 16 m + 4 kq + r, column n16 = (phase a, b; channel)
+    const int co = n16 & 3, pa = n16 >> 3, pb = (n16 >> 2) & 1;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int q = 16 * m + 4 * kq + r;
+      if (q >= 50) continue;
+      const float val = fmaxf(d[r], 0.f);
+      if (v < 2) {  // rows 2 i + pa, column 2 q + pb
+        u2rb[((2 * v + pa) * 102 + 2 * q + pb + 1) * 4 + co] = val;
+      } else {      // column 2 j + pb, row 2 q + pa
+        u2cb[((2 * (v - 2) + pb) * 102 + 2 * q + pa + 1) * 4 + co] = val;
+      }
+    }
+  }
+  __syncthreads();
+  // the 2 x 2 corner blocks exist in both band sets and a band is wrong where the OTHER direction loses taps too:
+  // (frame row, inner column) comes from the row band, (inner row, frame column) from the column band, the plane's
+  // corner cell from the definition
+  if (tid < 64) {
+    const int co = tid & 3, cx = (tid >> 2) & 1, cy = (tid >> 3) & 1, bx = (tid >> 4) & 1, by = tid >> 5;
+    const int y = by ? 98 + cy : cy, x = bx ? 98 + cx : cx;              // the cell
+    const int rb = by ? 2 + cy : cy, cb = bx ? 2 + cx : cx;              // its band index in u2rb / u2cb
+    const bool fy = y == 0 || y == 99, fx = x == 0 || x == 99;
+    float val;
+    if (fy && fx) {
+      auto get = [&](int yy, int xx, int ci) { return l1p[(ci * 52 + yy + 1) * 52 + xx + 1]; };
+      val = hg_corner<2, 4>(get, 50, y, x, p.w2raw, p.b2[co], co);
+    } else if (fx) {
+      val = u2cb[(cb * 102 + y + 1) * 4 + co];
+    } else {
+      val = u2rb[(rb * 102 + x + 1) * 4 + co];
+    }
+    // (the two reads above and the writes below touch different cells of the arrays for every thread pair: a cell is
+    // read from the array it is right in and written to the other one; the corner is written to both)
+    if (fy && fx) { u2rb[(rb * 102 + x + 1) * 4 + co] = val; u2cb[(cb * 102 + y + 1) * 4 + co] = val; }
+    else if (fx) u2rb[(rb * 102 + x + 1) * 4 + co] = val;
+    else u2cb[(cb * 102 + y + 1) * 4 + co] = val;
+  }
+  __syncthreads();
+  if (tid < 128) {  // clamp copies at -1 / 100 of every band line
+    const int co = tid & 3, b = (tid >> 2) & 3, hi = (tid >> 4) & 1, isc = tid >> 5;
+    if (isc < 2) {
+      float *ln = (isc ? u2cb : u2rb) + b * 102 * 4;
+      ln[(hi ? 101 : 0) * 4 + co] = ln[(hi ? 100 : 1) * 4 + co];
+    }
+  }
+  for (int e = tid; e < 4 * 100 * 4; e += HG_THREADS) {  // lines: row 0, row 99, col 0, col 99
+    const int ln = e / 400, r = e - ln * 400;
+    const float *src = ln < 2 ? u2rb + (ln ? 3 : 0) * 408 : u2cb + (ln == 3 ? 3 : 0) * 408;
+    p.u2fr[(size_t)s * 1600 + e] = src[4 + r];
+  }
+  __syncthreads();
+
+  // ---- uprelu3 frame lines: line v, M-tile m: quads 16 m + n16 along the line (100) ----
+#pragma unroll 1
+  for (int m = 0; m < 7; m++) {  // wave = line
+    const int v = wv;
+    const int qq = min(16 * m + n16, 99);
+    const float *band = (v < 2 ? u2rb : u2cb);
+    const int b0 = (v & 1) ? 2 : 0;              // the band pair {0,1} or {98,99}
+    const float bias = p.b3[n16 & 7];
+    f32x4 d = {bias, bias, bias, bias};
+#pragma unroll
+    for (int jj = 0; jj < 9; jj++) {            // k = 4 jj + kq: tap jj, ci = kq
+      const int ty = jj / 3, tx = jj % 3;
+      // across the line: the low-res rows (columns) -1 | 0 | 1 of the first, 98 | 99 | 100 of the last, clamped
+      const int tf = v < 2 ? ty : tx, ta = v < 2 ? tx : ty;
+      const int bsel = (v & 1) ? b0 + min(tf, 1) : b0 + max(tf - 1, 0);
+      const float a = band[(bsel * 102 + qq + ta) * 4 + kq];
+      d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw3[jj], d, 0, 0, 0);
+    }
+    const int co = n16 & 7, par = n16 >> 3;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int q = 16 * m + 4 * kq + r;
+      if (q < 100) u3l[(v * 200 + 2 * q + par) * 8 + co] = fmaxf(d[r], 0.f);
+    }
+  }
+  __syncthreads();
+  if (tid < 32) {  // the four corner cells, from the definition, into both lines they belong to
+    const int co = tid & 7, c = tid >> 3;
+    const int y = (c & 1) ? 199 : 0, x = (c & 2) ? 199 : 0;
+    auto get = [&](int yy, int xx, int ci) {  // uprelu2 near the corner: rows {0,1} / {98,99} of the row bands
+      return u2rb[((yy < 50 ? yy : yy - 96) * 102 + xx + 1) * 4 + ci];
+    };
+    const float val = hg_corner<4, 8>(get, 100, y, x, p.w3raw, p.b3[co], co);
+    u3l[(((c & 1) ? 1 : 0) * 200 + x) * 8 + co] = val;
+    u3l[(((c & 2) ? 3 : 2) * 200 + y) * 8 + co] = val;
+  }
+  __syncthreads();
+  for (int e = tid; e < 6400; e += HG_THREADS) p.u3fr[(size_t)s * 6400 + e] = u3l[e];
+
+  // ---- corrections of the heat-map frame pixels (PrepLayout::efr: the conv taps of the row / column outside the
+  // image in phase form along the line): pixel 2 j + b of a line gets sum_o E[b][o] L[j + o - 1] ----
+  for (int e = tid; e < 4 * 400; e += HG_THREADS) {
+    const int ln = e / 400, t = e - ln * 400, isc = ln >> 1, side = ln & 1, jq = t >> 1, b = t & 1;
+    float acc = 0.f;
+    if (!isc || (t > 0 && t < 399)) {  // the corner pixels are counted with the row lines
+      const float *E = p.efr + ((isc * 2 + side) * 2 + b) * 24;
+      const float *L = u3l + ln * 1600;
+#pragma unroll
+      for (int o = 0; o < 3; o++) {
+        const float *Lp = L + min(max(jq + o - 1, 0), 199) * 8;
+#pragma unroll
+        for (int ci = 0; ci < 8; ci++) acc += E[o * 8 + ci] * Lp[ci];
+      }
+      if (!isc && (t == 0 || t == 399)) {
+        // corner pixel: + the column line's sum at this row, minus the tap (outside row, outside column) it shares
+        // with the row line
+        const int cs = t ? 1 : 0;                       // left | right column line
+        const int yq = side ? 199 : 0, a = side ? 1 : 0;  // low-res row and row phase of heat-map row 0 | 399
+        const float *E2 = p.efr + ((2 + cs) * 2 + a) * 24;
+        const float *L2 = u3l + (2 + cs) * 1600;
+        for (int o = 0; o < 3; o++) {
+          const float *Lp = L2 + min(max(yq + o - 1, 0), 199) * 8;
+          for (int ci = 0; ci < 8; ci++) acc += E2[o * 8 + ci] * Lp[ci];
+        }
+        const int tap = (side ? 2 : 0) * 3 + (cs ? 2 : 0);
+        const float *Lc = L + (t ? 199 : 0) * 8;        // the corner cell of uprelu3
+        for (int ci = 0; ci < 8; ci++) acc -= p.w4raw[tap * 8 + ci] * Lc[ci];
       }
     }
     p.c4[(size_t)s * 1600 + e] = acc;
@@ -696,7 +903,9 @@ int ofx_launch_head(ofx_handle *h, const HeadParams2 &p0) {
     if (++dbg_calls == 20) p.dbg = dbg;
   }
 #endif
-  hipLaunchKernelGGL(k_head_frames, dim3((unsigned)p.S), dim3(HF_THREADS), 0, h->stream, p);
+  static const bool frames_ref = getenv("OFX_HEAD_FRAMES_REF") != nullptr;  // the VALU reference (agreement test)
+  if (frames_ref) hipLaunchKernelGGL(k_head_frames_ref, dim3((unsigned)p.S), dim3(HF_THREADS), 0, h->stream, p);
+  else hipLaunchKernelGGL(k_head_frames, dim3((unsigned)p.S), dim3(HG_THREADS), 0, h->stream, p);
   OFX_HIP(hipGetLastError());
   const unsigned blocks = (unsigned)(((p.S + 7) / 8) * 16);
   hipLaunchKernelGGL(k_head_stream, dim3(blocks), dim3(HS_THREADS), 0, h->stream, p);

@@ -134,6 +134,10 @@ struct PrepLayout {
                       // where the whole receptive window shows empty space
   int w3mf;           // [half 2][k = tap*4 + ci (36)][n = phase*4 + co_local (16)]  MFMA B operand
   int w2mf;           // upconv2 in phase form: [k = tap*2 + ci (18, padded to 20)][n = phase*4 + co (16)]
+  int w2fr;           // [variant top|bottom|left|right][20][16]: w2mf with the taps that fall into the zero padding of the
+                      // variant's frame line dropped (k_head_frames: exact frame bands of uprelu2)
+  int w3fr;           // [variant][k = tap*4 + ci (36)][n = parity*8 + co (16)]: upconv3 phase weights of one frame line
+                      // (top / bottom: row phase fixed, n's parity = column phase; left / right the other way round)
   int w4eff;          // [4 phases][9 low-res taps][8 ci] (v1 kernel)
   int w4eff_c;        // [8 ci][4 phases][9 taps] (fused kernel: one contiguous slice per input channel)
   int w4raw;          // [9][8]
@@ -154,6 +158,8 @@ static PrepLayout prep_layout() {
   for (int i = 0; i < 4; i++) { L.bg[i] = off; off += 8; }
   L.w3mf = off; off += 36 * 32;
   L.w2mf = off; off += 20 * 16;
+  L.w2fr = off; off += 4 * 20 * 16;
+  L.w3fr = off; off += 4 * 36 * 16;
   L.w4eff = off; off += 4 * 9 * 8;
   L.w4eff_c = off; off += 8 * 4 * 9;
   L.w4raw = off; off += 72;
@@ -172,7 +178,7 @@ struct PrepParams {
   float *prep;
   int src_k[7], src_b[7], src_g[7], cin[7], cout[7], dst_w[7], dst_b[7];
   int src_k4, src_b4, dst_w4eff, dst_w4raw, dst_b4, dst_efr;
-  int dst_w4eff_c, dst_w3mf, dst_w2mf, dst_lut1, dst_wbm[3];
+  int dst_w4eff_c, dst_w3mf, dst_w2mf, dst_w2fr, dst_w3fr, dst_lut1, dst_wbm[3];
   int phase;
   int dst_bg[4];
 };
@@ -278,6 +284,39 @@ __global__ void k_policy_prepare(PrepParams p) {
             acc += (p.w[p.src_k[5] + ((dy * 3 + dx) * cin + ci) * cout + co] * inv) * (up_coef(a, dy, ty) * up_coef(b, dx, tx));
       }
       p.prep[p.dst_w2mf + e] = acc;
+    }
+  }
+  // frame-line variants of the phase weights (k_head_frames): the conv taps that fall into the zero padding of the
+  // variant's frame line are left out.  v = 0 top (row phase 0 loses dy = 0), 1 bottom (row phase 1 loses dy = 2),
+  // 2 left (column phase 0 loses dx = 0), 3 right (column phase 1 loses dx = 2)
+  {
+    const float *g2 = p.w + p.src_g[5], *g3 = p.w + p.src_g[6];
+    for (int e = tid; e < 4 * 20 * 16; e += nthr) {
+      const int n = e % 16, k = (e / 16) % 20, v = e / 320, co = n & 3, ph = n >> 2, ci = k & 1, tap = k >> 1;
+      float acc = 0.f;
+      if (k < 18) {
+        const int a = ph >> 1, b = ph & 1, ty = tap / 3, tx = tap % 3;
+        const float inv = g2[co] / sqrtf(g2[3 * 4 + co] + 1e-3f);
+        for (int dy = 0; dy < 3; dy++)
+          for (int dx = 0; dx < 3; dx++) {
+            const bool drop = (v == 0 && a == 0 && dy == 0) || (v == 1 && a == 1 && dy == 2) || (v == 2 && b == 0 && dx == 0) ||
+                              (v == 3 && b == 1 && dx == 2);
+            if (!drop) acc += (p.w[p.src_k[5] + ((dy * 3 + dx) * 2 + ci) * 4 + co] * inv) * (up_coef(a, dy, ty) * up_coef(b, dx, tx));
+          }
+      }
+      p.prep[p.dst_w2fr + e] = acc;
+    }
+    for (int e = tid; e < 4 * 36 * 16; e += nthr) {
+      const int n = e % 16, k = (e / 16) % 36, v = e / 576, co = n & 7, q = n >> 3, ci = k & 3, tap = k >> 2;
+      const int a = v == 0 ? 0 : v == 1 ? 1 : q, b = v == 2 ? 0 : v == 3 ? 1 : q, ty = tap / 3, tx = tap % 3;
+      const float inv = g3[co] / sqrtf(g3[3 * 8 + co] + 1e-3f);
+      float acc = 0.f;
+      for (int dy = 0; dy < 3; dy++)
+        for (int dx = 0; dx < 3; dx++) {
+          const bool drop = (v == 0 && dy == 0) || (v == 1 && dy == 2) || (v == 2 && dx == 0) || (v == 3 && dx == 2);
+          if (!drop) acc += (p.w[p.src_k[6] + ((dy * 3 + dx) * 4 + ci) * 8 + co] * inv) * (up_coef(a, dy, ty) * up_coef(b, dx, tx));
+        }
+      p.prep[p.dst_w3fr + e] = acc;
     }
   }
   if (tid == 0) p.prep[p.dst_b4] = p.w[p.src_b4];
@@ -2253,7 +2292,7 @@ static int policy_forward_impl(ofx_handle *h, const float *weights, int N, int M
   }
   pp.src_k4 = off[t_u4]; pp.src_b4 = off[t_u4 + 1];
   pp.dst_w4eff = L.w4eff; pp.dst_w4raw = L.w4raw; pp.dst_b4 = L.b4; pp.dst_efr = L.efr;
-  pp.dst_w4eff_c = L.w4eff_c; pp.dst_w3mf = L.w3mf; pp.dst_w2mf = L.w2mf; pp.dst_lut1 = L.lut1;
+  pp.dst_w4eff_c = L.w4eff_c; pp.dst_w3mf = L.w3mf; pp.dst_w2mf = L.w2mf; pp.dst_w2fr = L.w2fr; pp.dst_w3fr = L.w3fr; pp.dst_lut1 = L.lut1;
   for (int i = 0; i < 3; i++) pp.dst_wbm[i] = L.wbm[i];
   for (int i = 0; i < 4; i++) pp.dst_bg[i] = L.bg[i];
   pp.phase = 0;
@@ -2347,6 +2386,7 @@ static int policy_forward_impl(ofx_handle *h, const float *weights, int N, int M
     hp2.w2mf = ws.prep + L.w2mf; hp2.b2 = ws.prep + L.ub[1]; hp2.w2raw = ws.prep + L.uw[1];
     hp2.w3mf = ws.prep + L.w3mf; hp2.b3 = ws.prep + L.ub[2]; hp2.w3raw = ws.prep + L.uw[2];
     hp2.w4eff_c = ws.prep + L.w4eff_c; hp2.b4 = ws.prep + L.b4; hp2.w4raw = ws.prep + L.w4raw;
+    hp2.w2fr = ws.prep + L.w2fr; hp2.w3fr = ws.prep + L.w3fr; hp2.efr = ws.prep + L.efr;
     hp2.u2fr = ws.u2fr; hp2.u3fr = ws.u3fr; hp2.c4 = ws.c4;
     hp2.ablate = 0; hp2.dbg = nullptr; hp2.mask = ship_mask; hp2.best = ws.best; hp2.heat = heatmap; hp2.probe = probe; hp2.ptr_probe = probe ? ptr_probe : nullptr;
     const int pb = h->prof_base;
