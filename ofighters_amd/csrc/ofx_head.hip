@@ -275,16 +275,29 @@ __device__ __forceinline__ float hg_corner(G get, int n, int yc, int xc, const f
 
 __global__ __launch_bounds__(HG_THREADS) void k_head_frames(HeadParams2 p) {
   __shared__ __align__(16) float sm[HG_TOTAL];
+  __shared__ float efr_s[192];
   const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   if (p.mask && !p.mask[s]) return;  // block-uniform
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n16 = lane & 15, kq = lane >> 4;
   float *l1p = sm + HG_L1, *u2rb = sm + HG_RB, *u2cb = sm + HG_CB, *u3l = sm + HG_U3;
 
-  for (int e = tid; e < 2 * 52 * 52; e += HG_THREADS) {
-    const int c = e % 52, r = (e / 52) % 52, ci = e / 2704;
-    l1p[e] = p.up1[(size_t)s * 5000 + (ci * 50 + min(max(r - 1, 0), 49)) * 50 + min(max(c - 1, 0), 49)];
+  {  // uprelu1 -> LDS, clamp-extended by one cell: all loads of a thread in flight before the first store
+    constexpr int NE = 2 * 52 * 52, PER = (NE + HG_THREADS - 1) / HG_THREADS;  // 22
+    float v[PER];
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+      const int e = min(u * HG_THREADS + tid, NE - 1);
+      const int c = e % 52, r = (e / 52) % 52, ci = e / 2704;
+      v[u] = p.up1[(size_t)s * 5000 + (ci * 50 + min(max(r - 1, 0), 49)) * 50 + min(max(c - 1, 0), 49)];
+    }
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+      const int e = u * HG_THREADS + tid;
+      if (e < NE) l1p[e] = v[u];
+    }
   }
+  if (tid < 192) efr_s[tid] = p.efr[tid];
   __syncthreads();
 
   // ---- uprelu2 bands: band v, M-tile m: pixels 16 m + n16 along the band (50), all four phases ----
@@ -398,7 +411,8 @@ __global__ __launch_bounds__(HG_THREADS) void k_head_frames(HeadParams2 p) {
     u3l[(((c & 2) ? 3 : 2) * 200 + y) * 8 + co] = val;
   }
   __syncthreads();
-  for (int e = tid; e < 6400; e += HG_THREADS) p.u3fr[(size_t)s * 6400 + e] = u3l[e];
+  for (int e = tid; e < 1600; e += HG_THREADS)
+    reinterpret_cast<f32x4 *>(p.u3fr + (size_t)s * 6400)[e] = reinterpret_cast<const f32x4 *>(u3l)[e];
 
   // ---- corrections of the heat-map frame pixels (PrepLayout::efr: the conv taps of the row / column outside the
   // image in phase form along the line): pixel 2 j + b of a line gets sum_o E[b][o] L[j + o - 1] ----
@@ -406,7 +420,7 @@ __global__ __launch_bounds__(HG_THREADS) void k_head_frames(HeadParams2 p) {
     const int ln = e / 400, t = e - ln * 400, isc = ln >> 1, side = ln & 1, jq = t >> 1, b = t & 1;
     float acc = 0.f;
     if (!isc || (t > 0 && t < 399)) {  // the corner pixels are counted with the row lines
-      const float *E = p.efr + ((isc * 2 + side) * 2 + b) * 24;
+      const float *E = efr_s + ((isc * 2 + side) * 2 + b) * 24;
       const float *L = u3l + ln * 1600;
 #pragma unroll
       for (int o = 0; o < 3; o++) {
@@ -419,7 +433,7 @@ __global__ __launch_bounds__(HG_THREADS) void k_head_frames(HeadParams2 p) {
         // with the row line
         const int cs = t ? 1 : 0;                       // left | right column line
         const int yq = side ? 199 : 0, a = side ? 1 : 0;  // low-res row and row phase of heat-map row 0 | 399
-        const float *E2 = p.efr + ((2 + cs) * 2 + a) * 24;
+        const float *E2 = efr_s + ((2 + cs) * 2 + a) * 24;
         const float *L2 = u3l + (2 + cs) * 1600;
         for (int o = 0; o < 3; o++) {
           const float *Lp = L2 + min(max(yq + o - 1, 0), 199) * 8;
