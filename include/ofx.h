@@ -250,6 +250,16 @@ int ofx_policy_layout(const ofx_handle *h, ofx_policy_desc *desc_host);
 int ofx_policy_forward(ofx_handle *h, const float *weights, const uint8_t *ship_mask,
                        float *act_values, int32_t *iaction, int32_t *ipointer,
                        float *heatmap);
+/* Keras keeps a compiled model between predict() calls (the module-level TRAINER, agents/qlearnIA_V2.py:308); the
+ * counterpart here: a forward first folds BatchNorm into the convolutions and builds its phase weights / tables from
+ * the blob (two small launches).  Pinning a blob does that once: every following forward that names the same
+ * pointer reuses the prepared weights, until another blob (or NULL) is pinned.  ofx_dqn_fit on a pinned blob
+ * re-prepares behind its update; after changing a pinned blob any other way, pin it again.                     */
+int ofx_policy_pin_weights(ofx_handle *h, const float *weights);
+/* Diagnostic switches of the policy forward (value 0 / 1): results agree up to fp32 summation order.              */
+#define OFX_OPT_TRUNK_PLAIN 1 /* the four trunk layers through the plain VALU convolution (test reference)        */
+#define OFX_OPT_FRAMES_REF  2 /* frame lines of the head from the definition instead of the phase form (reference) */
+int ofx_set_option(ofx_handle *h, int32_t option, int32_t value);
 /* Exploration of the bi-head action space (Trainer.get_best_action epsilon branch, agents/qlearnIA_V2.py:199-204,
  * and the collecting phase :393-395): for every selected ship, with probability `epsilon` - or always when
  * `collecting` != 0 - replace (iaction, ipointer) by random_play() (:317-321): iaction = randint(0, 1),
@@ -322,6 +332,14 @@ int ofx_replay_sample(ofx_handle *h, uint64_t seed, uint32_t draw, int32_t batch
  * [W*H/32] uint32 in the layout ofx_policy_forward's trunk reads.             */
 int ofx_replay_gather(ofx_handle *h, const int32_t *slot, int32_t batch, ofx_transition *rows, void *bits_prev,
                       void *bits_next);
+/* The same minibatch WITHOUT padding, the form Trainer.replay works on (its batch is min(batch_size, len(memory)) real
+ * transitions, qlearnIA_V2.py:241-243): the sampled entries of all arenas in (arena, j) order, packed; entries `first`
+ * .. `first + max_rows - 1` of that sequence land in rows[max_rows] / bits_*[max_rows][2][W*H/32] (device, maps may be
+ * NULL) and *n_rows_host receives how many were written.  slot / n_sampled as written by ofx_replay_sample.
+ * Synchronises.  This is what ofx_dqn_targets / ofx_dqn_fit take: the fit refuses padding rows.                      */
+int ofx_replay_gather_valid(ofx_handle *h, const int32_t *slot, const int32_t *n_sampled, int32_t batch, int32_t first,
+                            int32_t max_rows, ofx_transition *rows, void *bits_prev, void *bits_next,
+                            int32_t *n_rows_host);
 
 /* ---- forward on stored observations, TD targets -------------------------
  * The predictions Trainer.replay makes on a minibatch (agents/qlearnIA_V2.py:251-268): n_obs observations given as
@@ -351,7 +369,9 @@ int ofx_dqn_targets(ofx_handle *h, const float *weights, int32_t n, const ofx_tr
  * 1-based).  weights / adam_m / adam_v: device float32 [n_floats] in the ofx_policy_layout order, updated in place;
  * grad_out (device, may be NULL) receives the gradient; loss_host[2] = the two mse terms.  Inputs are the
  * transitions' `state` observations and the pointer addresses heat[y][x] (the reference fits on next_state's inputs
- * and indexes [x][y], :280-283: stated, not reproduced).  Reference-quality kernels, not the hot path; synchronises. */
+ * and indexes [x][y], :280-283: stated, not reproduced).  Every row must be a real transition (ship >= 0; use
+ * ofx_replay_gather_valid): a padding row would enter the BatchNorm batch statistics and the loss scale, so the call
+ * fails with OFX_ERR_INVALID before anything is updated.  Reference-quality kernels, not the hot path; synchronises. */
 int ofx_dqn_fit(ofx_handle *h, float *weights, float *adam_m, float *adam_v, int32_t step, float lr, int32_t n,
                 const ofx_transition *rows, const void *bits_prev, const float *y_act, const float *y_ptr,
                 float *grad_out, float *loss_host);
@@ -364,7 +384,8 @@ int ofx_timer_stop(ofx_handle *h, float *ms_host); /* synchronises */
  * time between two of them later (synchronises on the second).              */
 int ofx_event_record(ofx_handle *h, int32_t idx);
 /* When event_base >= 0 every following ofx_policy_forward records events event_base / event_base+1 around its
- * dominant kernel (the fused head tail) and then advances event_base by 2; -1 switches it off.               */
+ * dominant kernels (the head: k_head_frames + k_head_stream) and then advances event_base by 2; it switches itself
+ * off when the event ring is full; -1 switches it off.                                                        */
 int ofx_policy_profile(ofx_handle *h, int32_t event_base);
 int ofx_event_elapsed(ofx_handle *h, int32_t idx_from, int32_t idx_to, float *ms_host);
 

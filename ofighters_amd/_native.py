@@ -29,6 +29,7 @@ BEHAVIOURS = {None: BOT_IDLE, "idle": BOT_IDLE, "random": BOT_RANDOM, "turret": 
  F_OBS_REWARD) = range(19)
 
 MAP_U8, MAP_F32, MAP_F64, MAP_BITS = range(4)
+OPT_TRUNK_PLAIN, OPT_FRAMES_REF = 1, 2   # ofx_set_option
 
 
 class OfxError(Exception):
@@ -110,10 +111,13 @@ SIGNATURES = {
     "ofx_replay_frame_host": (_i, [_vp, C.c_int32, C.c_int32, _vp, _vp]),
     "ofx_replay_sample": (_i, [_vp, _u64, _u32, C.c_int32, _vp, _vp]),
     "ofx_replay_gather": (_i, [_vp, _vp, C.c_int32, _vp, _vp, _vp]),
+    "ofx_replay_gather_valid": (_i, [_vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp]),
     "ofx_timer_start": (_i, [_vp]),
     "ofx_timer_stop": (_i, [_vp, C.POINTER(C.c_float)]),
     "ofx_event_record": (_i, [_vp, C.c_int32]),
     "ofx_policy_profile": (_i, [_vp, C.c_int32]),
+    "ofx_policy_pin_weights": (_i, [_vp, _vp]),
+    "ofx_set_option": (_i, [_vp, C.c_int32, C.c_int32]),
     "ofx_event_elapsed": (_i, [_vp, C.c_int32, C.c_int32, C.POINTER(C.c_float)]),
 }
 

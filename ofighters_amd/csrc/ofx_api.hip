@@ -163,7 +163,7 @@ extern "C" int ofx_destroy(ofx_handle *h) {
   ofx_state &s = h->st;
   void *ptrs[] = {s.ship_x, s.ship_y, s.ship_px, s.ship_py, s.hull, s.reward, s.score, s.obs_reward, s.last_score,
                   s.alive, s.killer, s.time, s.n_lasers, s.laser_x, s.laser_y, s.laser_dx, s.laser_dy,
-                  s.laser_owner, s.laser_dead, s.overflow, s.episode_sums, h->bot_behaviours, h->scratch, h->aux};
+                  s.laser_owner, s.laser_dead, s.overflow, s.episode_sums, h->bot_behaviours, h->scratch, h->aux, h->prep};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   for (int t = 0; t < 5; t++) for (int w = 0; w < 2; w++) if (h->maps[t][w]) (void)hipFree(h->maps[t][w]);
   if (h->events) { (void)hipEventDestroy(h->ev0); (void)hipEventDestroy(h->ev1); }
@@ -545,7 +545,6 @@ extern "C" int ofx_timer_stop(ofx_handle *h, float *ms_host) {
   return OFX_OK;
 }
 
-#define OFX_RING_MAX 65536
 extern "C" int ofx_event_record(ofx_handle *h, int32_t idx) {
   if (!h || idx < 0 || idx >= OFX_RING_MAX) { ofx_set_error("ofx_event_record: bad index %d", idx); return OFX_ERR_INVALID; }
   OFX_HIP(hipSetDevice(h->cfg.device));

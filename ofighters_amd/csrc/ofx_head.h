@@ -22,6 +22,7 @@ struct HeadParams2 {
   float *heat;                  // [S][400][400] or null
   const int32_t *probe;         // [S][2] (x, y) or null
   float *ptr_probe;             // [S] heat-map value at the probe
+  int frames_ref;               // frame lines through the from-the-definition kernel (OFX_OPT_FRAMES_REF)
   int ablate;                   // diagnostics (OFX_HEAD_HOOKS builds only)
   unsigned long long *dbg;      // diagnostics: [blocks][8 waves][6] s_memtime sums
 };

@@ -79,7 +79,7 @@ constexpr int HF_U3L = HF_B2C + 1600;          // u3l[4][200][8]: exact frame li
 constexpr int HF_TOTAL = HF_U3L + 6400;        // 17048 floats = 68 KB
 
 // Reference version: everything from the definition (up-sample, then convolve with zero padding) on the VALU.  Kept
-// for the agreement test of the phase-form version below (OFX_HEAD_FRAMES_REF=1).
+// for the agreement test of the phase-form version below (OFX_OPT_FRAMES_REF).
 __global__ __launch_bounds__(HF_THREADS) void k_head_frames_ref(HeadParams2 p) {
   __shared__ __align__(16) float sm[HF_TOTAL];
   const int s = blockIdx.x, tid = threadIdx.x;
@@ -504,6 +504,7 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
     tabD[g] = (unsigned short)((((2 * q) & (HS_NR3 - 1)) * HS_P3 + 8 * gg) | ((gg == (side ? 12 : 0)) ? 0x8000 : 0) |
                                ((q == 0 || q == 99) ? 0x4000 : 0));
   }
+  __syncthreads();  // the producers read the tables in front of their first barrier
 
 #if OFX_HEAD_HOOKS
   unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0}, stamp_last = __builtin_amdgcn_s_memtime();
@@ -917,8 +918,7 @@ int ofx_launch_head(ofx_handle *h, const HeadParams2 &p0) {
     if (++dbg_calls == 20) p.dbg = dbg;
   }
 #endif
-  static const bool frames_ref = getenv("OFX_HEAD_FRAMES_REF") != nullptr;  // the VALU reference (agreement test)
-  if (frames_ref) hipLaunchKernelGGL(k_head_frames_ref, dim3((unsigned)p.S), dim3(HF_THREADS), 0, h->stream, p);
+  if (p.frames_ref) hipLaunchKernelGGL(k_head_frames_ref, dim3((unsigned)p.S), dim3(HF_THREADS), 0, h->stream, p);
   else hipLaunchKernelGGL(k_head_frames, dim3((unsigned)p.S), dim3(HG_THREADS), 0, h->stream, p);
   OFX_HIP(hipGetLastError());
   const unsigned blocks = (unsigned)(((p.S + 7) / 8) * 16);

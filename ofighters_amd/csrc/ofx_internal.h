@@ -60,7 +60,11 @@ struct ofx_handle {
   ofx_replay *replay;              // transition memory (ofx_replay_create), null = none
   void *aux;                       // temporaries of ofx_dqn_targets (grown on demand)
   size_t aux_bytes;
+  float *prep;                     // prepared policy weights (BN folded, phase weights, tables): ofx_policy.hip
+  const float *prep_pinned;        // the blob `prep` was built from while it is pinned (ofx_policy_pin_weights)
+  bool opt_trunk_plain, opt_frames_ref;  // ofx_set_option
 };
+#define OFX_RING_MAX 65536         /* numbered events of ofx_event_record */
 
 // kernels / launchers implemented in the other translation units
 int ofx_launch_step(ofx_handle *h, const ofx_action *actions);
@@ -68,6 +72,7 @@ int ofx_launch_raster(ofx_handle *h, int map_type, void *ship_map, void *laser_m
 int ofx_ensure_scratch(ofx_handle *h, size_t bytes);
 void ofx_replay_free(ofx_handle *h);
 int ofx_replay_episode_reset(ofx_handle *h, const uint8_t *arena_mask);
+int ofx_policy_weights_updated(ofx_handle *h, const float *weights);  // the blob was changed in place (ofx_dqn_fit)
 
 #define OFX_MAP_BITS_LSB 4 /* internal: 1 bit / cell, pixel p -> bit (p & 31) of word p >> 5 */
 

@@ -349,8 +349,14 @@ __global__ __launch_bounds__(256) void k_replay_gather(GatherParams p) {
   const int a = blockIdx.x / p.batch, j = blockIdx.x - a * p.batch;
   const int s = p.slot[(size_t)a * p.batch + j];
   ofx_transition *dst = p.rows + (size_t)a * p.batch + j;
-  if (s < 0) {  // padding: an all-zero row with ship = -1
+  if (s < 0) {  // padding: an all-zero row with ship = -1 and empty maps (never uninitialised memory)
     if (threadIdx.x < sizeof(ofx_transition) / 4) ((int32_t *)dst)[threadIdx.x] = threadIdx.x == 4 ? -1 : 0;
+    uint32_t *pads[2] = {p.bits_prev, p.bits_next};
+    for (int w = 0; w < 2; w++) {
+      if (!pads[w]) continue;
+      uint4 *out = reinterpret_cast<uint4 *>(pads[w] + ((size_t)a * p.batch + j) * 2 * p.words);
+      for (int k = threadIdx.x; k < 2 * p.words / 4; k += 256) out[k] = make_uint4(0u, 0u, 0u, 0u);
+    }
     return;
   }
   const int count = p.r.count[a], head = p.r.head[a];
@@ -377,5 +383,78 @@ extern "C" int ofx_replay_gather(ofx_handle *h, const int32_t *slot, int32_t bat
   p.r = *r; p.slot = slot; p.rows = rows; p.bits_prev = (uint32_t *)bits_prev; p.bits_next = (uint32_t *)bits_next;
   hipLaunchKernelGGL(k_replay_gather, dim3((unsigned)(p.N * batch)), dim3(256), 0, h->stream, p);
   OFX_HIP(hipGetLastError());
+  return OFX_OK;
+}
+
+// ---- the same minibatch without padding: only the rows that exist, packed (Trainer.replay never pads: its batch is
+// min(batch_size, len(memory)) real transitions, qlearnIA_V2.py:241-243) ------------------------------------------------
+// exclusive scan of n_sampled[N] by one workgroup -> off[N], total in off[N]
+__global__ __launch_bounds__(1024) void k_replay_scan(int N, const int32_t *n_sampled, int32_t *off) {
+  __shared__ int part[1024];
+  const int tid = threadIdx.x, per = (N + 1023) / 1024, lo = min(tid * per, N), hi = min(lo + per, N);
+  int sum = 0;
+  for (int i = lo; i < hi; i++) sum += n_sampled[i];
+  part[tid] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan of the partial sums
+    const int v = tid >= d ? part[tid - d] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int run = tid ? part[tid - 1] : 0;
+  for (int i = lo; i < hi; i++) { off[i] = run; run += n_sampled[i]; }
+  if (tid == 1023) off[N] = part[1023];
+}
+
+// one workgroup per (arena, j): sampled entry j of arena a is packed row off[a] + j - first, when it falls into
+// [0, max_rows)
+__global__ __launch_bounds__(256) void k_replay_gather_valid(GatherParams p, const int32_t *n_sampled, const int32_t *off, int first,
+                                                             int max_rows) {
+  const int a = blockIdx.x / p.batch, j = blockIdx.x - a * p.batch;
+  if (j >= n_sampled[a]) return;
+  const int d = off[a] + j - first;
+  if (d < 0 || d >= max_rows) return;
+  const int s = p.slot[(size_t)a * p.batch + j];
+  const int count = p.r.count[a], head = p.r.head[a];
+  const int first_row = ((head - count) % p.C + p.C) % p.C;
+  const ofx_transition *src = p.r.rows + (size_t)a * p.C + (first_row + s) % p.C;
+  ofx_transition *dst = p.rows + d;
+  if (threadIdx.x < sizeof(ofx_transition) / 4) ((int32_t *)dst)[threadIdx.x] = ((const int32_t *)src)[threadIdx.x];
+  const int slots[2] = {src->frame_prev, src->frame_next};
+  uint32_t *outs[2] = {p.bits_prev, p.bits_next};
+  for (int w = 0; w < 2; w++) {
+    if (!outs[w]) continue;
+    const uint4 *in = reinterpret_cast<const uint4 *>(p.r.frame_bits + ((size_t)a * p.F + slots[w]) * 2 * p.words);
+    uint4 *out = reinterpret_cast<uint4 *>(outs[w] + (size_t)d * 2 * p.words);
+    for (int k = threadIdx.x; k < 2 * p.words / 4; k += 256) out[k] = in[k];
+  }
+}
+
+extern "C" int ofx_replay_gather_valid(ofx_handle *h, const int32_t *slot, const int32_t *n_sampled, int32_t batch,
+                                       int32_t first, int32_t max_rows, ofx_transition *rows, void *bits_prev,
+                                       void *bits_next, int32_t *n_rows_host) {
+  if (!h || !h->replay || !slot || !n_sampled || !rows || !n_rows_host || batch <= 0 || first < 0 || max_rows <= 0) {
+    ofx_set_error("ofx_replay_gather_valid: bad argument");
+    return OFX_ERR_INVALID;
+  }
+  ofx_replay *r = h->replay;
+  OFX_HIP(hipSetDevice(h->cfg.device));
+  const int N = h->cfg.n_arenas;
+  int32_t *off = nullptr;
+  OFX_HIP(hipMalloc((void **)&off, sizeof(int32_t) * (N + 1)));
+  hipLaunchKernelGGL(k_replay_scan, dim3(1), dim3(1024), 0, h->stream, N, n_sampled, off);
+  GatherParams p;
+  p.N = N; p.C = r->capacity; p.F = r->frames; p.batch = batch; p.words = r->words;
+  p.r = *r; p.slot = slot; p.rows = rows; p.bits_prev = (uint32_t *)bits_prev; p.bits_next = (uint32_t *)bits_next;
+  hipLaunchKernelGGL(k_replay_gather_valid, dim3((unsigned)(N * batch)), dim3(256), 0, h->stream, p, n_sampled, (const int32_t *)off,
+                     first, max_rows);
+  hipError_t e = hipGetLastError();
+  int32_t total = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&total, off + N, sizeof(total), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(off);
+  if (e != hipSuccess) { ofx_set_error("ofx_replay_gather_valid: %s", hipGetErrorString(e)); return OFX_ERR_HIP; }
+  *n_rows_host = total - first < 0 ? 0 : (total - first > max_rows ? max_rows : total - first);
   return OFX_OK;
 }

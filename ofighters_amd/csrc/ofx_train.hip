@@ -373,6 +373,11 @@ static void conv_bwd_weight(hipStream_t st, int n, int ci, int co, int H, int W,
   hipLaunchKernelGGL(t_conv_bwd_finish, dim3((nw + co + 255) / 256), dim3(256), 0, st, nw, co, slices, part, dw, db);
 }
 
+__global__ void t_count_pads(int n, const ofx_transition *rows, int32_t *out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && rows[i].ship < 0) atomicAdd(out, 1);
+}
+
 extern "C" int ofx_dqn_fit(ofx_handle *h, float *weights, float *adam_m, float *adam_v, int32_t step, float lr, int32_t n,
                            const ofx_transition *rows, const void *bits_prev, const float *y_act, const float *y_ptr,
                            float *grad_out, float *loss_host) {
@@ -385,6 +390,20 @@ extern "C" int ofx_dqn_fit(ofx_handle *h, float *weights, float *adam_m, float *
   ofx_policy_desc L;
   int rc = ofx_policy_layout(h, &L);
   if (rc) return rc;
+  {  // padding rows (ship < 0) would enter the BatchNorm batch statistics and the loss scale: refuse them up front
+    int32_t *npad = nullptr, pads = 0;
+    OFX_HIP(hipMalloc((void **)&npad, sizeof(int32_t)));
+    OFX_HIP(hipMemsetAsync(npad, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(t_count_pads, dim3((n + 255) / 256), dim3(256), 0, st, n, rows, npad);
+    hipError_t e = hipMemcpyAsync(&pads, npad, sizeof(pads), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(npad);
+    if (e != hipSuccess) { ofx_set_error("ofx_dqn_fit: %s", hipGetErrorString(e)); return OFX_ERR_HIP; }
+    if (pads) {
+      ofx_set_error("ofx_dqn_fit: %d of %d rows are padding (ship < 0); gather with ofx_replay_gather_valid", pads, n);
+      return OFX_ERR_INVALID;
+    }
+  }
   const size_t N = (size_t)n;
   // activations: trunk sizes 400,200,100,50 (z, a per layer + pooled), head-2 sizes 50,100,200 (+ upsampled inputs)
   size_t need = 0;
@@ -545,5 +564,6 @@ extern "C" int ofx_dqn_fit(ofx_handle *h, float *weights, float *adam_m, float *
   OFX_HIP(hipStreamSynchronize(st));
   if (loss_host) { loss_host[0] = lh[0]; loss_host[1] = lh[1]; }
   (void)W_;
+  if ((rc = ofx_policy_weights_updated(h, weights))) return rc;  // a pinned blob is prepared again
   return OFX_OK;  // `release` frees the block (the stream is idle: synchronised above)
 }

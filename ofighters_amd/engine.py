@@ -45,11 +45,12 @@ class DeviceBuffer:
         nat.check(nat.lib().ofx_memcpy_h2d(self.ptr, arr.ctypes.data_as(C.c_void_p), arr.nbytes))
         return self
 
-    def download(self, dtype, shape):
+    def download(self, dtype, shape, offset=0):
+        """Copy `shape` elements of `dtype` starting `offset` bytes into the buffer back to the host."""
         out = np.empty(shape, dtype=dtype)
-        if out.nbytes > self.nbytes:
-            raise Exception("DeviceBuffer.download: %d bytes from a %d byte buffer" % (out.nbytes, self.nbytes))
-        nat.check(nat.lib().ofx_memcpy_d2h(out.ctypes.data_as(C.c_void_p), self.ptr, out.nbytes))
+        if offset < 0 or offset + out.nbytes > self.nbytes:
+            raise Exception("DeviceBuffer.download: %d bytes at offset %d from a %d byte buffer" % (out.nbytes, offset, self.nbytes))
+        nat.check(nat.lib().ofx_memcpy_d2h(out.ctypes.data_as(C.c_void_p), self.ptr + int(offset), out.nbytes))
         return out
 
     def free(self):
@@ -266,6 +267,15 @@ class ArenaBatch:
         nat.check(nat.lib().ofx_policy_forward(self._h, weights_ptr, ship_mask_ptr, act_ptr, iaction_ptr,
                                                ipointer_ptr, heat_ptr))
 
+    def policy_pin_weights(self, weights_ptr):
+        """Prepare (fold BatchNorm, build the phase weights) once: every following forward on this blob reuses it.
+        None unpins.  (The reference keeps one compiled Keras model between predicts, qlearnIA_V2.py:308.)"""
+        nat.check(nat.lib().ofx_policy_pin_weights(self._h, weights_ptr))
+
+    def set_option(self, option, value):
+        """Diagnostic switches of the forward: nat.OPT_TRUNK_PLAIN, nat.OPT_FRAMES_REF (reference variants)."""
+        nat.check(nat.lib().ofx_set_option(self._h, int(option), int(value)))
+
     def policy_actions(self, out_ptr=None, iaction_ptr=None, ipointer_ptr=None, ship_mask_ptr=None):
         """QlearnIA.play packing of the last forward into [N][M] ofx_action."""
         out_ptr = out_ptr or self._actions.ptr
@@ -376,6 +386,17 @@ class ArenaBatch:
         bp, bn = DeviceBuffer(4 * self.N * batch * 2 * words), DeviceBuffer(4 * self.N * batch * 2 * words)
         nat.check(nat.lib().ofx_replay_gather(self._h, slot.ptr, int(batch), rows.ptr, bp.ptr, bn.ptr))
         return rows, bp, bn
+
+    def replay_gather_valid(self, slot, n_sampled, batch, first, max_rows):
+        """The sampled minibatch without padding rows, packed in (arena, j) order and kept in HBM: entries first ..
+        first + max_rows - 1 -> (rows, bits_prev, bits_next, n_rows).  Trainer.replay never pads (qlearnIA_V2.py:241-243)."""
+        rows = DeviceBuffer(max_rows * self.TRANSITION_DTYPE.itemsize)
+        words = self.W * self.H // 32
+        bp, bn = DeviceBuffer(4 * max_rows * 2 * words), DeviceBuffer(4 * max_rows * 2 * words)
+        n = C.c_int32()
+        nat.check(nat.lib().ofx_replay_gather_valid(self._h, slot.ptr, n_sampled.ptr, int(batch), int(first), int(max_rows),
+                                                     rows.ptr, bp.ptr, bn.ptr, C.byref(n)))
+        return rows, bp, bn, n.value
 
     def policy_forward_obs(self, weights_ptr, n_obs, bits_ptr, vec8_ptr, want_probe_ptr=None):
         """Forward on stored observations (Trainer.replay's predictions): host dict of act / iaction / ipointer /

@@ -46,16 +46,18 @@ class DeviceTrainer:
         cnt, _ = b.replay_count()
         if int(cnt.max()) == 0:
             return None
-        slot, _ = b.replay_sample(self.seed, self.draws, bs)
+        slot, n_s = b.replay_sample(self.seed, self.draws, bs)
         self.draws += 1
-        rows, bits_prev, bits_next = b.replay_gather_device(slot, bs)
-        # every arena contributed bs rows ([N][bs], -1 padded); one optimisation step takes a window of them that
-        # moves with the draw counter
-        total = b.N * bs
-        n = min(total, int(self.fit_batch))
-        start = ((self.draws - 1) * n) % (total - n + 1)
-        row_b, map_b = b.TRANSITION_DTYPE.itemsize, 2 * (b.W * b.H // 32) * 4
-        rows_p, prev_p, next_p = rows.ptr + start * row_b, bits_prev.ptr + start * map_b, bits_next.ptr + start * map_b
+        # the sampled transitions of all arenas, WITHOUT the -1 pads of arenas that hold fewer than bs (a pad would enter
+        # the BatchNorm batch statistics and the loss scale of the fit; the reference's batch is min(bs, len(memory)) real
+        # rows); one optimisation step takes a window of them that moves with the draw counter
+        n_valid = int(np.minimum(cnt, bs).sum())
+        n = min(n_valid, int(self.fit_batch))
+        start = ((self.draws - 1) * n) % (n_valid - n + 1)
+        rows, bits_prev, bits_next, got = b.replay_gather_valid(slot, n_s, bs, start, n)
+        if got != n:
+            raise Exception("DeviceTrainer.replay: gathered %d of %d rows" % (got, n))
+        rows_p, prev_p, next_p = rows.ptr, bits_prev.ptr, bits_next.ptr
         outs = [DeviceBuffer(4 * n) for _ in range(4)]     # q_sa, p_sp, y_act, y_ptr
         from . import _native as nat
         nat.check(nat.lib().ofx_dqn_targets(b.handle, self.weights.ptr, n, rows_p, prev_p, next_p, float(self.gamma),

@@ -253,8 +253,8 @@ def test_dqn_targets_vs_oracle():
         act0, heat0, _, _ = pyoracle.policy_forward(m0[0], m0[1], r["head_prev"], w)
         act1, heat1, _, _ = pyoracle.policy_forward(m1[0], m1[1], r["head_next"], w)
         live = 0.0 if r["done"] else 1.0
-        tol_a = 2e-4 * max(1.0, float(np.abs(act0).max()), float(np.abs(act1).max()))
-        tol_h = 2e-4 * max(float(np.abs(heat0).max()), float(np.abs(heat1).max()))
+        tol_a = 2e-5 * max(1.0, float(np.abs(act0).max()), float(np.abs(act1).max()))
+        tol_h = 2e-5 * max(float(np.abs(heat0).max()), float(np.abs(heat1).max()))
         assert abs(q_sa[i] - act0[r["iaction"]]) <= tol_a
         assert abs(p_sp[i] - heat0[r["py"], r["px"]]) <= tol_h
         assert abs(y_act[i] - (r["reward"] + gamma * act1.max() * live)) <= tol_a

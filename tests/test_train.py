@@ -159,3 +159,68 @@ def test_device_trainer_replay_reduces_the_td_error():
               for k in range(12)]
     assert losses[-1][0] < 0.7 * losses[0][0], losses
     b.close()
+
+
+def test_short_memories_are_not_padded_into_the_fit():
+    """An arena that holds fewer transitions than the batch size gives -1 pads in ofx_replay_gather (their maps are
+    zeroed, not left uninitialised); ofx_replay_gather_valid packs only the real rows - the form Trainer.replay works
+    on, batch = min(batch_size, len(memory)) (qlearnIA_V2.py:241-243) - and ofx_dqn_fit refuses a padded batch.  Two
+    fits of the packed batch from identical state give the same gradients (to the last bits: the fit's reductions use
+    double-precision atomics, whose order is not fixed)."""
+    from ofighters_amd import ArenaBatch, DeviceBuffer
+    N, M, seed, bs = 3, 4, 11, 6
+    b = ArenaBatch(N, M)
+    b.replay_create(16, 0)
+    b.spawn_random(seed)
+    w, _ = pyoracle.policy_init(2, trained_like=True)
+    # arena 0 captures with two ships, arena 1 with one, arena 2 with none: memories of different lengths
+    mask = np.zeros((N, M), np.uint8)
+    mask[0, [0, 2]] = 1
+    mask[1, 1] = 1
+    mask_d = DeviceBuffer(mask.nbytes).upload(mask)
+    ia_d, ip_d = DeviceBuffer(4 * N * M), DeviceBuffer(8 * N * M)
+    for t in range(4):
+        b.bot_actions(["random"] * M, seed, tick=t)
+        b.policy_explore(1.0, seed, tick=t, collecting=True, ship_mask_ptr=mask_d.ptr, iaction_ptr=ia_d.ptr, ipointer_ptr=ip_d.ptr)
+        b.policy_actions(out_ptr=b._actions.ptr, ship_mask_ptr=mask_d.ptr, iaction_ptr=ia_d.ptr, ipointer_ptr=ip_d.ptr)
+        b.replay_capture(t, mask_d.ptr, ia_d.ptr, ip_d.ptr)
+        b.step(actions_ptr=b._actions.ptr)
+    cnt, _ = b.replay_count()
+    assert cnt[2] == 0 and 0 < cnt[1] < bs and cnt[0] > cnt[1]
+    slot, n_s = b.replay_sample(5, 0, bs)
+    ns = n_s.download(np.int32, (N,))
+    assert list(ns) == [min(int(c), bs) for c in cnt]
+    # padded form: pads are ship = -1 rows with EMPTY maps
+    rows_h, bp_h, bn_h = b.replay_gather(slot, bs)
+    pads = rows_h["ship"] < 0
+    assert pads.sum() == N * bs - ns.sum() and pads[2].all()
+    assert not bp_h[pads].any() and not bn_h[pads].any()
+    # packed form
+    total = int(ns.sum())
+    rows, bp, bn, got = b.replay_gather_valid(slot, n_s, bs, 0, total)
+    assert got == total
+    packed = rows.download(b.TRANSITION_DTYPE, (total,))
+    assert (packed["ship"] >= 0).all()
+    assert np.array_equal(packed, rows_h[~pads])                      # (arena, j) order
+    assert np.array_equal(bp.download(np.uint32, (total, 2, 5000)), bp_h[~pads])
+    r2, _, _, got2 = b.replay_gather_valid(slot, n_s, bs, 1, 2)       # a window of the packed sequence
+    assert got2 == 2 and np.array_equal(r2.download(b.TRANSITION_DTYPE, (2,)), packed[1:3])
+    # the fit refuses padding rows ...
+    rows_d, bp_d, bn_d = b.replay_gather_device(slot, bs)
+    n_all = N * bs
+    y = DeviceBuffer(4 * n_all).upload(np.zeros(n_all, np.float32))
+    zeros = np.zeros_like(w)
+    w_d, m_d, v_d = DeviceBuffer(w.nbytes).upload(w), DeviceBuffer(w.nbytes).upload(zeros), DeviceBuffer(w.nbytes).upload(zeros)
+    with pytest.raises(Exception, match="padding"):
+        b.dqn_fit(w_d, m_d, v_d, 1, 1e-4, n_all, rows_d.ptr, bp_d.ptr, y.ptr, y.ptr)
+    assert np.array_equal(w_d.download(np.float32, w.shape), w)       # nothing was updated
+    # ... and is deterministic on the packed batch
+    grads = []
+    for _ in range(2):
+        w_d.upload(w); m_d.upload(zeros); v_d.upload(zeros)
+        g_d = DeviceBuffer(w.nbytes)
+        b.dqn_fit(w_d, m_d, v_d, 1, 1e-4, total, rows.ptr, bp.ptr, y.ptr, y.ptr, g_d)
+        grads.append(g_d.download(np.float32, w.shape))
+    assert np.isfinite(grads[0]).all()
+    assert np.abs(grads[0] - grads[1]).max() <= 1e-6 * np.abs(grads[0]).max()
+    b.close()
