@@ -2,15 +2,23 @@
 """bench.py - arena-steps/sec of the hot path on N MI355X (one process per GPU).
 
 A "step" is one lock-step of the per-GPU arena batch: on-device random-bot
-actions (agents/agent.py:123-133 law, counter RNG) -> ofx_step (physics +
-collision + reward) -> ofx_rasterise (u8 ship/laser maps) [-> policy forward,
-once built], with Battleground.restart + the episodic score all-reduce (RCCL)
-every 200 ticks.  Arenas shard by global id (weak scaling: 4096 per GPU); the
-only collective is the [M+1] int64 score all-reduce at episode ends.
+actions (agents/agent.py:123-133 law, counter RNG) -> bi-head policy forward
+for the policy ships -> ofx_step (physics + collision + reward) ->
+ofx_rasterise (u8 ship/laser maps), with Battleground.restart + the episodic
+score all-reduce (RCCL) every 200 ticks.  The loop is
+ofighters_amd.rollout.ShardedRollout at EVERY world size - the class the
+world_size-2 gloo test drives (tests/test_sharded_gloo.py).  Arenas shard by
+global id: weak scaling (4096 per GPU, the default) or --scaling strong (32768
+in total); the only collective is the [M+1] int64 score all-reduce at episode
+ends.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including
-  roofline     - dominant kernel's algorithmic bytes / measured HIP-event time
-  cpu_baseline - the CPU oracle timed on a bounded sample (rank 0, N=1 only)
+  roofline      - dominant kernel's algorithmic work / measured HIP-event time
+  cpu_baseline  - the CPU oracle timed on a bounded sample (rank 0, N=1 only)
+  extra_configs - at N=1: BASELINE configs[1] (step) and configs[2] (step+obs)
+                  and the two reference-faithful policy workloads (one policy
+                  ship per arena; destroyed ships skipped), each with its own
+                  roofline - labelled secondary lines, never `value`
 """
 import argparse
 import json
@@ -22,15 +30,47 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 SEED = 0x0F160001
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+FP32_PEAK_TF = 157.3    # fp32 vector = f32-input MFMA peak
+PMC_FILE = os.path.join("profiles", "r02_full_pmc_hbm.txt")
+METRIC = "arena-steps/sec (env.step+obs+policy fwd) at 4096 arenas, 1/2/4/8 MI355X"
 
 
-def cpu_policy_sample(pyoracle, cfg, w, n_arenas, ticks, n_pol, seed):
-    """CPU-oracle leg of the full workload: per tick and arena, n_pol policy forwards (the oracle has no
-    trunk sharing: one full forward per ship, like the reference), step, rasterise."""
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of a kernel from this round's committed PMC summary (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate passes of this same command, tools/final_profile.sh; counters cannot be collected from
+    inside a timed run).  FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950.  None when the file
+    or the kernel is missing - e.g. after the kernel was renamed: never a stale number."""
+    try:
+        kb = {}
+        for line in open(os.path.join(ROOT, PMC_FILE)):
+            f = line.rstrip("\n").split("\t")
+            if len(f) == 2 and f[0].startswith(kernel_prefix) and "=" in f[1]:
+                name, val = f[1].split("=")
+                kb[name] = float(val)
+        if "FETCH_SIZE" in kb and "WRITE_SIZE" in kb:
+            return (2.0 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024.0
+    except OSError:
+        pass
+    return None
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_policy_sample(pyoracle, cfg, w, arenas, ticks, n_pol, seed):
+    """CPU-oracle leg of the full workload for the given global arenas: per tick and arena, n_pol policy forwards (the
+    oracle has no trunk sharing: one full forward per ship, like the reference), step, rasterise."""
     import numpy as np
     M = cfg.n_ships
-    for g in range(n_arenas):
+    for g in arenas:
         a = pyoracle.Arena(cfg=cfg)
         a.spawn(pyoracle.reset_draws(cfg, seed, g, 0))
         for t in range(ticks):
@@ -43,24 +83,162 @@ def cpu_policy_sample(pyoracle, cfg, w, n_arenas, ticks, n_pol, seed):
             a.step(act)
 
 
-def pmc_traffic(kernel_prefix):
-    """HBM bytes per launch of a kernel from the committed PMC summary (profiles/r01_full_pmc_hbm.txt: rocprofv3
-    --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this same command, tools/final_profile.sh; counters cannot be
-    collected from inside a timed run).  FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950.
-    None when the file or the kernel is missing."""
-    path = os.path.join(ROOT, "profiles", "r01_full_pmc_hbm.txt")
+def cpu_baseline(workload, M, n_pol, w_host, ep_ticks):
+    """The C oracle (a port) on the box's host cores: one thread, then all cores (threads over arenas: the C calls
+    release the GIL).  Bounded samples of the same workload."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import pyoracle
+    cfg = pyoracle.default_cfg(M)
+    cores = os.cpu_count() or 1
     try:
-        kb = {}
-        for line in open(path):
-            f = line.rstrip("\n").split("\t")
-            if len(f) == 2 and f[0].startswith(kernel_prefix) and "=" in f[1]:
-                name, val = f[1].split("=")
-                kb[name] = float(val)
-        if "FETCH_SIZE" in kb and "WRITE_SIZE" in kb:
-            return (2.0 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024.0
-    except OSError:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
         pass
-    return None
+
+    if workload == "step+obs+policy":
+        t_s = 2
+
+        def run(arenas):
+            cpu_policy_sample(pyoracle, cfg, w_host, arenas, t_s, n_pol, SEED)
+        n_one, n_all = 8, max(64, 4 * cores) // t_s      # 16 arena-steps on one thread, >= 64 over all cores
+    else:
+        t_s = 200
+        do_obs = workload == "step+obs"
+
+        def run(arenas):
+            pyoracle.run_random(cfg, len(arenas), t_s, SEED, int(do_obs), ep_ticks)
+        n_one, n_all = (1024, 1024 * cores) if do_obs else (4096, 4096 * cores)
+
+    c0 = time.perf_counter()
+    run(list(range(n_one)))
+    one = n_one * t_s / (time.perf_counter() - c0)
+    chunks = [list(range(i, n_all, cores)) for i in range(cores)]
+    c0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(run, chunks))
+    allc = n_all * t_s / (time.perf_counter() - c0)
+    return {
+        "value": one, "unit": "arena-steps/s", "cores": 1, "kind": "port",
+        "sample": "%d arenas x %d ticks of the same workload (C oracle, single thread)" % (n_one, t_s),
+        "all_cores": {"value": allc, "cores": cores,
+                      "sample": "%d arenas x %d ticks, threads over arenas" % (n_all, t_s)},
+        "cpu_model": cpu_model(),
+    }
+
+
+class Workload:
+    """One timed configuration on an ArenaBatch: ShardedRollout + the policy hook + HIP-event bracketing of the
+    dominant kernel."""
+
+    def __init__(self, b, workload, n_pol, alive_only, w_dev, dist, torch, nat, ep_ticks, start_tick=0):
+        import numpy as np
+        from ofighters_amd.rollout import ShardedRollout
+        self.b, self.workload, self.n_pol, self.alive_only = b, workload, n_pol, alive_only
+        self.do_obs = workload != "step"
+        self.do_policy = workload == "step+obs+policy"
+        self.nat, self.np = nat, np
+        self.ev = 0
+        self.timed = False
+        N, M = b.N, b.M
+        self.mask_ptr = None
+        self._keep = None
+        if self.do_policy:
+            if alive_only:
+                self.mask_ptr = b.device_ptr(nat.F_SHIP_ALIVE)   # the engine's alive flags [N][M] uint8 are the mask
+            elif n_pol < M:
+                mk = np.zeros((N, M), np.uint8)
+                mk[:, :n_pol] = 1
+                self._keep = torch.from_numpy(mk).cuda()
+                self.mask_ptr = self._keep.data_ptr()
+            b.policy_pin_weights(w_dev.data_ptr())               # prepared once: Keras keeps its compiled model too
+        self.w_ptr = w_dev.data_ptr() if w_dev is not None else None
+        self.stage = "policy" if self.do_policy else ("obs" if self.do_obs else "step")
+        self.roll = ShardedRollout(b, ["random"] * M, SEED, episode_ticks=ep_ticks, dist=dist, observe=self.do_obs,
+                                   policy=self._policy if self.do_policy else None,
+                                   to_tensor=lambda a: torch.from_numpy(a.copy()).cuda(), start_tick=start_tick,
+                                   probe=self._probe)
+
+    def _policy(self, e):
+        # request_actions: the policy ships' actions overwrite the scripted ones
+        if self.timed and self.ev == 0:
+            e.policy_profile(0)          # the library brackets its dominant kernel with event pairs from here on
+        e.policy_forward(self.w_ptr, self.mask_ptr)
+        if self.timed:
+            self.ev += 2
+        e.policy_actions(ship_mask_ptr=self.mask_ptr)
+
+    def _probe(self, stage, begin):
+        if self.timed and stage == self.stage and self.ev < 60000:
+            self.b.event_record(self.ev if begin else self.ev + 1)
+            if not begin:
+                self.ev += 2
+
+    def run(self, warmup, steps, fence, torch, dist):
+        self.roll.run(warmup)
+        fence()
+        self.episodes_before = len(self.roll.score_log)
+        self.timed = True
+        t0 = time.perf_counter()
+        self.roll.run(steps)
+        fence()
+        dt = time.perf_counter() - t0
+        self.timed = False
+        self.b.policy_profile(-1)
+        if dist is not None:
+            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        n_ev = min(self.ev // 2, 30000)
+        k_ms = [self.b.event_elapsed(2 * i, 2 * i + 1) for i in range(n_ev)]
+        return dt, (float(self.np.mean(k_ms)) if k_ms else float("nan"))
+
+    def roofline(self, k_avg_ms, dt, steps, full_config):
+        b, np, nat = self.b, self.np, self.nat
+        N, M = b.N, b.M
+        if self.do_policy:
+            # dominant kernel: k_head_stream = the last three up-convolutions of head-2 + arg-max, fused:
+            # [x2 bilinear + conv 2->4 @100^2] + [x2 + conv 4->8 @200^2] + [x2 + conv 8->1 @400^2]
+            # per policy ship: 0.72 + 11.52 + 11.52 = 23.76 MMAC (SURVEY 8a P1), dense, no sparsity credit
+            n_eff = self.n_pol
+            if self.alive_only:  # forwards actually run ~ mean number of playable ships (sampled at the end)
+                n_eff = float(b.get(nat.F_SHIP_ALIVE).mean()) * M
+            alg = N * n_eff * 2.0 * 23.76e6
+            whole = N * 2.0 * (53.28e6 + n_eff * 24.37e6)   # trunk once per arena + per-ship heads (SURVEY 8d)
+            ach = alg / (k_avg_ms * 1e-3) / 1e12
+            r = {"bound": "mfma", "kernel": "k_head_stream", "achieved": ach, "peak": FP32_PEAK_TF, "unit": "TFLOP/s",
+                 "frac": ach / FP32_PEAK_TF,
+                 "traffic": pmc_traffic("k_head_stream") if full_config else None,
+                 "avg_kernel_ms": k_avg_ms, "algorithmic_flops_per_launch": alg,
+                 "note": "fp32 (exact f32-input MFMA + fp32 VALU, both 157.3 TFLOP/s peak); whole tick = %.0f GFLOP dense "
+                         "algorithmic (trunk once per arena + per-ship heads) = %.1f TFLOP/s over ms_per_step = %.3f of peak"
+                         % (whole / 1e9, whole / (dt / steps) / 1e12, whole / (dt / steps) / 1e12 / FP32_PEAK_TF)}
+        else:
+            if self.do_obs:
+                kernel, alg = "k_raster<u8>", N * 2 * b.W * b.H * 1   # two u8 maps written per arena (SURVEY 8d cfg 3)
+            else:
+                kernel, alg = "k_step", N * 3200                       # SURVEY 8d cfg 2: ~3.2 KB per arena-step
+            ach = alg / (k_avg_ms * 1e-3) / 1e9
+            r = {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": ach / HBM_PEAK_GBS,
+                 "traffic": pmc_traffic("void k_raster<0>") if (full_config and self.do_obs) else None,
+                 "avg_kernel_ms": k_avg_ms, "algorithmic_bytes_per_launch": alg}
+        if r["traffic"] is not None:
+            r["traffic_source"] = ("HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE in separate "
+                                   "passes of this command: " + PMC_FILE)
+        return r
+
+    def describe(self):
+        N, M = self.b.N, self.b.M
+        s = "%d arenas x %d ships per GPU, random-bot actions + step" % (N, M)
+        if self.do_obs:
+            s += " + 2D obs rasterise (u8 maps)"
+        if self.do_policy:
+            s += (" + bi-head policy forward for %d ship(s)/arena, trunk shared per arena (BASELINE configs[3])" % self.n_pol)
+            if self.alive_only:
+                s += " (destroyed ships skipped)"
+        else:
+            s += "; no policy forward (BASELINE configs[%d])" % (2 if self.do_obs else 1)
+        return s
 
 
 def main():
@@ -68,14 +246,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--arenas", type=int, default=4096, help="arenas per GPU")
+    ap.add_argument("--arenas", type=int, default=4096, help="arenas per GPU (weak scaling)")
     ap.add_argument("--ships", type=int, default=8)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="strong: --total-arenas in all, split over the ranks (SURVEY 8d: fixed N = 32768)")
+    ap.add_argument("--total-arenas", type=int, default=32768)
     ap.add_argument("--workload", default="step+obs+policy", choices=["step", "step+obs", "step+obs+policy"])
     ap.add_argument("--policy-ships", type=int, default=-1, help="ships per arena driven by the bi-head policy (-1 = all)")
     ap.add_argument("--policy-alive-only", action="store_true",
                     help="skip the forward of destroyed ships (QlearnIA.play returns None once done, "
                          "agents/qlearnIA_V2.py:372-377); NOT the headline configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary configurations at N=1")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -101,194 +283,97 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     from ofighters_amd import ArenaBatch, _native as nat
+    from ofighters_amd.rollout import shard_range
 
-    N, M = args.arenas, args.ships
-    b = ArenaBatch(N, M, device=local_rank, arena_base=rank * N)
-    beh = ["random"] * M
-    ep_ticks = b.cfg.episode_ticks
-    do_obs = args.workload != "step"
-    do_policy = args.workload == "step+obs+policy"
+    M = args.ships
+    if args.scaling == "strong":
+        if args.total_arenas % world:
+            raise SystemExit("--total-arenas %d is not a multiple of the world size %d" % (args.total_arenas, world))
+        N = args.total_arenas // world
+    else:
+        N = args.arenas
+    base, _ = shard_range(rank, world, N)
     n_pol = M if args.policy_ships < 0 else min(M, args.policy_ships)
-    if do_policy:
+    w_host = w_dev = None
+    if args.workload == "step+obs+policy" or not args.no_extra:
         # synthetic he_uniform / glorot_uniform weights of the pointer_model architecture (no checkpoint
         # ships with the reference); seed 0x0F160002
         from ofighters_amd.agents.policy_weights import synthetic
         w_host = synthetic(0x0F160002)
         w_dev = torch.from_numpy(w_host).cuda()
-        mask_dev = None
-        if n_pol < M:
-            mk = np.zeros((N, M), np.uint8)
-            mk[:, :n_pol] = 1
-            mask_dev = torch.from_numpy(mk).cuda()
-        if args.policy_alive_only:
-            # the engine's own alive flags [N][M] uint8 serve as the ship mask: zero extra work
-            class _AliveMask:
-                def data_ptr(self_inner):
-                    return b.device_ptr(nat.F_SHIP_ALIVE)
-            mask_dev = _AliveMask()
-    scores = torch.zeros(M + 1, dtype=torch.int64, device="cuda")
     torch.cuda.synchronize()  # the handle's stream is non-blocking w.r.t. torch's
-    score_log = []
-
-    def episode_end():
-        # Agent.reset banks the episode score (agents/agent.py:61-63); the
-        # per-slot sums over all arenas of all GPUs are the one cross-GPU number.
-        b.restart_random(SEED)
-        b.episode_scores_into(scores.data_ptr())
-        b.sync()
-        if dist is not None:
-            dist.all_reduce(scores)
-        score_log.append(scores.clone())
-        torch.cuda.synchronize()
-
-    tick = [0]
-    EV = [0]
-
-    def lockstep(timed):
-        t = tick[0]
-        if t > 0 and t % ep_ticks == 0:
-            episode_end()
-        b.bot_actions(beh, SEED, tick=t)
-        if do_policy:
-            # request_actions: the policy ships' actions overwrite the scripted ones
-            if timed and EV[0] == 0:
-                b.policy_profile(0)     # the library brackets its dominant kernel with event pairs from here on
-            b.policy_forward(w_dev.data_ptr(), mask_dev.data_ptr() if mask_dev is not None else None)
-            if timed:
-                EV[0] += 2
-            b.policy_actions(ship_mask_ptr=mask_dev.data_ptr() if mask_dev is not None else None)
-        if timed and not do_obs:
-            b.event_record(EV[0])
-        b.step(actions_ptr=b._actions.ptr)
-        if timed and not do_obs:
-            b.event_record(EV[0] + 1)
-            EV[0] += 2
-        if do_obs:
-            if timed and not do_policy:
-                b.event_record(EV[0])
-            b.rasterise(nat.MAP_U8)
-            if timed and not do_policy:
-                b.event_record(EV[0] + 1)
-                EV[0] += 2
-        tick[0] = t + 1
 
     def fence():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    b.spawn_random(SEED)
-    for _ in range(args.warmup):
-        lockstep(False)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        lockstep(True)
-    fence()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    def measure(workload, n_pol_, alive_only, warmup, steps, full_config):
+        b = ArenaBatch(N, M, device=local_rank, arena_base=base)
+        ep = b.cfg.episode_ticks
+        # an episode end (restart + score all-reduce) falls into the middle of the timed region whatever --steps is
+        start = (ep - warmup - max(1, steps // 2)) % ep
+        wl = Workload(b, workload, n_pol_, alive_only, w_dev, dist, torch, nat, ep, start_tick=start)
+        dt, k_ms = wl.run(warmup, steps, fence, torch, dist)
+        rec = {"workload": wl.describe(), "value": world * N * steps / dt, "unit": "arena-steps/s", "steps": steps,
+               "warmup": warmup, "ms_per_step": dt / steps * 1e3, "roofline": wl.roofline(k_ms, dt, steps, full_config),
+               "laser_overflow": b.overflow_count(), "laser_cap": b.L, "episode_ticks": ep,
+               "episodes_in_timed_region": len(wl.roll.score_log) - wl.episodes_before}
+        if wl.roll.score_log:
+            rec["last_episode_score_sum"] = int(wl.roll.score_log[-1][:M].sum())
+            rec["last_episode_arenas"] = int(wl.roll.score_log[-1][M])
+        b.close()
+        return rec
 
-    # dominant kernel: average launch duration from the HIP events recorded on
-    # the handle's stream inside the timed region
-    n_ev = EV[0] // 2
-    k_ms = [b.event_elapsed(2 * i, 2 * i + 1) for i in range(min(n_ev, 32000))]
-    k_avg_ms = float(np.mean(k_ms)) if k_ms else float("nan")
-    overflow = b.overflow_count()
-    roof_unit, roof_peak, roof_bound, roof_note = "GB/s", HBM_PEAK_GBS, "hbm", None
-    if do_policy:
-        # dense algorithmic FLOPs, no sparsity credit: trunk 53.28 MMAC once per arena +
-        # 24.37 MMAC per policy ship
-        # dominant kernel: k_head_tail = the last three up-convolutions of head-2 + arg-max, fused:
-        # [x2 bilinear + conv 2->4 @100^2] + [x2 + conv 4->8 @200^2] + [x2 + conv 8->1 @400^2]
-        # per policy ship: 0.72 + 11.52 + 11.52 = 23.76 MMAC, dense, no sparsity credit
-        kernel = "k_head_tail"
-        n_eff = n_pol
-        if args.policy_alive_only:   # forwards actually run ~ mean number of playable ships (sampled at the end)
-            n_eff = float(b.get(nat.F_SHIP_ALIVE).mean()) * M
-        alg_flops = N * n_eff * 2.0 * 23.76e6
-        whole_forward_flops = N * 2.0 * (53.28e6 + n_eff * 24.37e6)
-        achieved = alg_flops / (k_avg_ms * 1e-3) / 1e12
-        roof_unit, roof_peak, roof_bound = "TFLOP/s", 157.3, "mfma"
-        roof_note = ("fp32 (exact f32-input MFMA + fp32 VALU, both 157.3 TFLOP/s peak); whole tick = %.0f GFLOP dense "
-                     "algorithmic (trunk once per arena + per-ship heads) = %.1f TFLOP/s over ms_per_step"
-                     % (whole_forward_flops / 1e9, whole_forward_flops / (dt / args.steps) / 1e12))
-        alg_bytes = None
-    elif do_obs:
-        kernel = "k_raster<u8>"
-        alg_bytes = N * 2 * b.W * b.H * 1          # two u8 maps written per arena (SURVEY 8d cfg 3)
-    else:
-        kernel = "k_step"
-        alg_bytes = N * 3200                        # SURVEY 8d cfg 2: ~3.2 KB per arena-step
-    if not do_policy:
-        achieved = alg_bytes / (k_avg_ms * 1e-3) / 1e9
-
+    headline_full = N == 4096 and M == 8 and n_pol == M and not args.policy_alive_only
+    head = measure(args.workload, n_pol, args.policy_alive_only, args.warmup, args.steps,
+                   headline_full or args.workload != "step+obs+policy")
+    do_policy = args.workload == "step+obs+policy"
     out = {
-        "metric": "arena-steps/sec (env.step+obs+policy fwd) at 4096 arenas, 1/2/4/8 MI355X",
-        "value": world * N * args.steps / dt,
+        "metric": METRIC,
+        "value": head["value"],
         "unit": "arena-steps/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3,
+        "ms_per_step": head["ms_per_step"],
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f32" if do_policy else "f64",
         "data": "synthetic",
         "config": {
-            "workload": ("%d arenas x %d ships per GPU, random-bot actions + step" % (N, M))
-                        + (" + 2D obs rasterise (u8 maps)" if do_obs else "")
-                        + ((" + bi-head policy forward for %d ship(s)/arena, trunk shared per arena (BASELINE configs[3])"
-                            % n_pol) + (" (destroyed ships skipped)" if do_policy and args.policy_alive_only else "")
-                           if do_policy else "; no policy forward (BASELINE configs[%d])" % (2 if do_obs else 1)),
-            "arenas_per_gpu": N, "ships": M, "laser_cap": b.L, "episode_ticks": ep_ticks,
+            "workload": head["workload"],
+            "arenas_per_gpu": N, "ships": M, "laser_cap": head["laser_cap"], "episode_ticks": head["episode_ticks"],
             "parallelism": "arena-sharded x%d, RCCL all-reduce of episodic scores only" % world,
-            "laser_overflow": overflow,
+            "laser_overflow": head["laser_overflow"],
+            "episodes_in_timed_region": head["episodes_in_timed_region"],
         },
-        "roofline": {
-            "bound": roof_bound, "kernel": kernel, "achieved": achieved, "peak": roof_peak, "unit": roof_unit,
-            "frac": achieved / roof_peak,
-            "traffic": pmc_traffic({"k_head_tail": "k_head_tail", "k_raster<u8>": "void k_raster<0>"}.get(kernel, "\0"))
-                       if (N == 4096 and M == 8 and (not do_policy or (n_pol == M and not args.policy_alive_only))) else None,
-            "avg_kernel_ms": k_avg_ms,
-            ("algorithmic_flops_per_launch" if do_policy else "algorithmic_bytes_per_launch"):
-                (alg_flops if do_policy else alg_bytes),
-        },
+        "roofline": head["roofline"],
     }
-    if roof_note:
-        out["roofline"]["note"] = roof_note
-    if out["roofline"]["traffic"] is not None:
-        out["roofline"]["traffic_source"] = ("HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE in separate "
-                                             "passes of this command: profiles/r01_full_pmc_hbm.txt")
-    if score_log:
-        out["config"]["last_episode_score_sum"] = int(score_log[-1][:M].sum().item())
-        out["config"]["last_episode_arenas"] = int(score_log[-1][M].item())
+    for k in ("last_episode_score_sum", "last_episode_arenas"):
+        if k in head:
+            out["config"][k] = head[k]
+
+    if world == 1 and not args.no_extra and do_policy and headline_full:
+        # secondary lines (never `value`): BASELINE configs[1] / [2], and the two reference-faithful policy workloads -
+        # the stock line-up has ONE QlearnIA ship (lib/ofighters.py:53: bound 1.01 M arena-steps/s), and
+        # QlearnIA.play returns None once the ship is destroyed (agents/qlearnIA_V2.py:372-377)
+        extra = []
+        for wl_name, np_, alive, wu, st in (("step", 0, False, 200, 1000), ("step+obs", 0, False, 200, 1000),
+                                            ("step+obs+policy", 1, False, 50, 300), ("step+obs+policy", M, True, 50, 200)):
+            r = measure(wl_name, np_, alive, wu, st, wl_name != "step+obs+policy")
+            if wl_name == "step+obs+policy":
+                flops = r["roofline"]["algorithmic_flops_per_launch"] / 23.76e6 * 24.37e6 + N * 2.0 * 53.28e6
+                r["fp32_bound_arena_steps_per_s"] = N * FP32_PEAK_TF * 1e12 / flops
+                r["frac_of_fp32_bound"] = r["value"] / r["fp32_bound_arena_steps_per_s"]
+            extra.append(r)
+        out["extra_configs"] = extra
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # CPU oracle (a port, 1 thread) on a bounded sample of the same workload
-        from oracle import pyoracle
-        cfg = pyoracle.default_cfg(M)
-        if do_policy:
-            # one policy forward costs ~0.3 s on one core: sample = a few arena-steps of the full workload
-            n_s, t_s = 2, 3
-            c0 = time.perf_counter()
-            cpu_policy_sample(pyoracle, cfg, w_host, n_s, t_s, n_pol, SEED)
-            cdt = time.perf_counter() - c0
-        else:
-            n_s, t_s = (1024, 200) if do_obs else (4096, 200)
-            c0 = time.perf_counter()
-            pyoracle.run_random(cfg, n_s, t_s, SEED, int(do_obs), ep_ticks)
-            cdt = time.perf_counter() - c0
-        out["cpu_baseline"] = {
-            "value": n_s * t_s / cdt, "unit": "arena-steps/s", "cores": 1, "kind": "port",
-            "sample": "%d arenas x %d ticks of the same workload (C oracle, single thread)" % (n_s, t_s),
-        }
+        out["cpu_baseline"] = cpu_baseline(args.workload, M, n_pol, w_host, head["episode_ticks"])
     if rank == 0:
         print(json.dumps(out))
-    b.close()
     if dist is not None:
         dist.destroy_process_group()
 

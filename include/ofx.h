@@ -384,8 +384,8 @@ int ofx_timer_stop(ofx_handle *h, float *ms_host); /* synchronises */
  * time between two of them later (synchronises on the second).              */
 int ofx_event_record(ofx_handle *h, int32_t idx);
 /* When event_base >= 0 every following ofx_policy_forward records events event_base / event_base+1 around its
- * dominant kernels (the head: k_head_frames + k_head_stream) and then advances event_base by 2; it switches itself
- * off when the event ring is full; -1 switches it off.                                                        */
+ * dominant kernel (k_head_stream: upconv2-4 + arg-max) and then advances event_base by 2; it switches itself off
+ * when the event ring is full; -1 switches it off.                                                               */
 int ofx_policy_profile(ofx_handle *h, int32_t event_base);
 int ofx_event_elapsed(ofx_handle *h, int32_t idx_from, int32_t idx_to, float *ms_host);
 

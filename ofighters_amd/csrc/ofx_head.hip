@@ -276,7 +276,11 @@ __device__ __forceinline__ float hg_corner(G get, int n, int yc, int xc, const f
 __global__ __launch_bounds__(HG_THREADS) void k_head_frames(HeadParams2 p) {
   __shared__ __align__(16) float sm[HG_TOTAL];
   __shared__ float efr_s[192];
-  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  // the ship of a block rotates inside its group of 8 (blocks go round-robin over the 8 XCDs: a regular ship mask
+  // must not leave all the live workgroups on one of them)
+  const int s = min((int)((blockIdx.x & ~7u) | ((blockIdx.x + (blockIdx.x >> 3)) & 7u)), p.S - 1);
+  const int tid = threadIdx.x, lane = tid & 63;
+  if ((int)((blockIdx.x & ~7u) | ((blockIdx.x + (blockIdx.x >> 3)) & 7u)) >= p.S) return;
   if (p.mask && !p.mask[s]) return;  // block-uniform
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n16 = lane & 15, kq = lane >> 4;
@@ -490,9 +494,11 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
   // group (flat over quad rows) -> float offset of its first quad in the uprelu2 ring (row slot of quad row - 1) and
   // in the uprelu3 ring (row slot of uprelu3 row 2 * quad row): two table reads replace the index arithmetic of a tile
   __shared__ unsigned short tabA[4 * HS_NTILES], tabD[4 * HS_NTILES];
-  // blocks b and b + 8 (same XCD under round-robin placement) are the two halves of one ship
+  // blocks b and b + 8 (same XCD under round-robin placement) are the two halves of one ship; the ship of a block
+  // rotates with the group of 16 blocks, so that a regular ship mask (say the first ship of every arena: the
+  // reference's own line-up has one policy ship) does not put all the live workgroups on one XCD
   const int blk = blockIdx.x;
-  const int s = (blk >> 4) * 8 + (blk & 7), side = (blk >> 3) & 1;
+  const int s = (blk >> 4) * 8 + ((blk + (blk >> 4)) & 7), side = (blk >> 3) & 1;
   if (s >= p.S) return;
   if (p.mask && !p.mask[s]) return;  // block-uniform
   const int tid = threadIdx.x, lane = tid & 63;
@@ -919,11 +925,14 @@ int ofx_launch_head(ofx_handle *h, const HeadParams2 &p0) {
   }
 #endif
   if (p.frames_ref) hipLaunchKernelGGL(k_head_frames_ref, dim3((unsigned)p.S), dim3(HF_THREADS), 0, h->stream, p);
-  else hipLaunchKernelGGL(k_head_frames, dim3((unsigned)p.S), dim3(HG_THREADS), 0, h->stream, p);
+  else hipLaunchKernelGGL(k_head_frames, dim3((unsigned)((p.S + 7) & ~7)), dim3(HG_THREADS), 0, h->stream, p);
   OFX_HIP(hipGetLastError());
   const unsigned blocks = (unsigned)(((p.S + 7) / 8) * 16);
+  int rc;
+  if (p.event_base >= 0 && (rc = ofx_event_record(h, p.event_base))) return rc;
   hipLaunchKernelGGL(k_head_stream, dim3(blocks), dim3(HS_THREADS), 0, h->stream, p);
   OFX_HIP(hipGetLastError());
+  if (p.event_base >= 0 && (rc = ofx_event_record(h, p.event_base + 1))) return rc;
 #if OFX_HEAD_HOOKS
   if (p.dbg) {
     (void)hipStreamSynchronize(h->stream);

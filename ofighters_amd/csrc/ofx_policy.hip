@@ -1074,13 +1074,10 @@ static int policy_forward_impl(ofx_handle *h, const float *weights, int N, int M
   hp2.u2fr = ws.u2fr; hp2.u3fr = ws.u3fr; hp2.c4 = ws.c4;
   hp2.frames_ref = h->opt_frames_ref;
   hp2.mask = ship_mask; hp2.best = ws.best; hp2.heat = heatmap; hp2.probe = probe; hp2.ptr_probe = probe ? ptr_probe : nullptr;
-  const int pb = h->prof_base;  // ofx_policy_profile: events around the dominant kernels, until the ring is full
-  if (pb >= 0 && (rc = ofx_event_record(h, pb))) return rc;
+  const int pb = h->prof_base;  // ofx_policy_profile: events around the dominant kernel, until the ring is full
+  hp2.event_base = pb;
   if ((rc = ofx_launch_head(h, hp2))) return rc;
-  if (pb >= 0) {
-    if ((rc = ofx_event_record(h, pb + 1))) return rc;
-    h->prof_base = pb + 3 < OFX_RING_MAX ? pb + 2 : -1;
-  }
+  if (pb >= 0) h->prof_base = pb + 3 < OFX_RING_MAX ? pb + 2 : -1;
   hipLaunchKernelGGL(k_policy_finish, dim3((S + 255) / 256), dim3(256), 0, h->stream, S, ship_mask, ws.best,
                      ipointer ? ipointer : ws.ipointer, ptr_max);
   OFX_HIP(hipGetLastError());

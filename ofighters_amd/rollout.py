@@ -29,12 +29,13 @@ class ShardedRollout:
 
     engine   object with spawn_random / restart_random / bot_actions / step /
              rasterise / episode_scores(as int64 numpy [M+1]) and attributes
-             N, M, episode
+             N, M, episode (ArenaBatch on the GPU - bench.py drives THIS class at every
+             world size - or the oracle-backed stand-in of the gloo test)
     dist     a torch.distributed-like module or None (single process)
     """
 
     def __init__(self, engine, behaviours, seed, episode_ticks=200, dist=None, observe=True, policy=None,
-                 to_tensor=None):
+                 to_tensor=None, start_tick=0, probe=None):
         self.e = engine
         self.behaviours = list(behaviours)
         self.seed = seed
@@ -43,7 +44,8 @@ class ShardedRollout:
         self.observe = observe
         self.policy = policy          # callable(engine) -> None: overwrite the policy ships' actions
         self.to_tensor = to_tensor    # numpy [M+1] int64 -> tensor usable by dist.all_reduce
-        self.tick = 0
+        self.probe = probe            # callable(stage, begin) around "step" / "obs" (bench.py: HIP events) or None
+        self.tick = start_tick        # a start inside an episode puts its end where the caller wants it (bench.py)
         self.score_log = []           # all-reduced [M+1] per finished episode
         self.e.spawn_random(seed)
 
@@ -65,9 +67,14 @@ class ShardedRollout:
         self.e.bot_actions(self.behaviours, self.seed, tick=self.tick)
         if self.policy is not None:
             self.policy(self.e)
+        p = self.probe
+        if p: p("step", True)
         self.e.step()
+        if p: p("step", False)
         if self.observe:
+            if p: p("obs", True)
             self.e.rasterise()
+            if p: p("obs", False)
         self.tick += 1
 
     def run(self, ticks):

@@ -1,0 +1,49 @@
+"""The launch line the driver uses for N > 1 (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`)
+rehearsed with two ranks on the ONE card of the test box (OFX_DIST_BACKEND=gloo: RCCL refuses two ranks per device):
+rendezvous on 127.0.0.1, arena sharding by rank, the ShardedRollout loop with an episode end (restart + score
+all-reduce) inside the timed region, barrier + max-over-ranks timing, one JSON line from rank 0."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(args, nproc=None, env=None):
+    e = dict(os.environ, **(env or {}))
+    if nproc:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+               "--master-addr", "127.0.0.1", "--master-port", "29533", "bench.py"] + args
+    else:
+        cmd = [sys.executable, "bench.py"] + args
+    p = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_two_rank_launch_line():
+    d = _bench(["--gpus", "2", "--arenas", "64", "--steps", "24", "--warmup", "4", "--no-cpu-baseline"], nproc=2,
+               env={"OFX_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["arenas_per_gpu"] == 64
+    assert d["config"]["episodes_in_timed_region"] >= 1          # restart + all-reduce were timed
+    assert d["config"]["last_episode_arenas"] == 2 * 64          # the count went through the all-reduce
+    assert d["roofline"]["kernel"] == "k_head_stream" and d["roofline"]["avg_kernel_ms"] > 0
+
+
+def test_single_rank_line_has_the_contract_fields():
+    d = _bench(["--arenas", "128", "--steps", "12", "--warmup", "3", "--no-extra"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 12 and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1
+    assert d["cpu_baseline"]["all_cores"]["cores"] >= 1 and d["cpu_baseline"]["cpu_model"]
+    assert d["config"]["episodes_in_timed_region"] >= 1
