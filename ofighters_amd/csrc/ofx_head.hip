@@ -591,16 +591,24 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
       }
     };
     auto run_pair = [&](const TileB &t0, const TileB &t1) {
+      // The two tiles run one after the other (two accumulator chains each: 64 cycles between dependent MFMAs, the
+      // 16x16x4 latency is 40) so that the ReLU + LDS writes of the first hide behind the MFMAs of the second; all 18
+      // A operands are requested up front.
+      float a0[9], a1[9];
+#pragma unroll
+      for (int j = 0; j < 9; j++) { a0[j] = t0.a[(j / 3) * HS_P2 + j % 3]; a1[j] = t1.a[(j / 3) * HS_P2 + j % 3]; }
       f32x4 d00, d01, d10, d11;
 #pragma unroll
       for (int j = 0; j < 9; j++) {
-        const float a0 = t0.a[(j / 3) * HS_P2 + j % 3], a1 = t1.a[(j / 3) * HS_P2 + j % 3];
-        d00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bw[0][j], j ? d00 : binit3[0], 0, 0, 0);
-        d01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bw[1][j], j ? d01 : binit3[1], 0, 0, 0);
-        d10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bw[0][j], j ? d10 : binit3[0], 0, 0, 0);
-        d11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bw[1][j], j ? d11 : binit3[1], 0, 0, 0);
+        d00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], bw[0][j], j ? d00 : binit3[0], 0, 0, 0);
+        d01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], bw[1][j], j ? d01 : binit3[1], 0, 0, 0);
       }
-      tile_epilogue(t0, d00, d01);
+#pragma unroll
+      for (int j = 0; j < 9; j++) {
+        d10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], bw[0][j], j ? d10 : binit3[0], 0, 0, 0);
+        d11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], bw[1][j], j ? d11 : binit3[1], 0, 0, 0);
+        if (j == 1) tile_epilogue(t0, d00, d01);
+      }
       tile_epilogue(t1, d10, d11);
       if (t0.hasf) tile_frames(t0);
       if (t1.hasf) tile_frames(t1);
@@ -689,6 +697,9 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
         const int yy = min(max(pr + tap / 3 - 1, 0), 49), xx = min(max(j1 + tap % 3 - 1, 0), 49);
         av[j] = up1s[((kq & 1) * 50 + yy) * 50 + xx];
       }
+      // the exact frame-column cell lanes 0-7 write behind the tile (2 rows x 4 channels), requested with the rest: a
+      // load in front of its use would expose the HBM latency in every second stage-A tile
+      av[5] = fr2[((side ? 3 : 2) * 100 + 2 * pr + ((lane >> 2) & 1)) * 4 + (lane & 3)];
     };
     auto stageA_compute = [&](int pr, int hh, const float *av) {
       const int px0 = side ? (hh ? 34 : 23) : (hh ? 11 : 0);
@@ -711,7 +722,7 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
       if ((side == 0 && hh == 0) || (side == 1 && hh == 1)) {  // the strip's frame column: 2 rows x 4 channels
         if (lane < 8) {
           const int yp = lane >> 2, ch = lane & 3, y = 2 * pr + yp;
-          const float v = fr2[((side ? 3 : 2) * 100 + y) * 4 + ch];
+          const float v = av[5];
           const int cf = side ? 53 : 1, cc = side ? 54 : 0;
           hs_u2_store(u2r, ch, y, cf, v);
           hs_u2_store(u2r, ch, y, cc, v);
@@ -757,14 +768,14 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
     const char *const u3b = reinterpret_cast<const char *>(u3r);
 
     {  // prologue: uprelu2 row pairs 0 and 1, one tile per consumer wave
-      float av0[5];
+      float av0[6];
       stageA_load(cw >> 1, cw & 1, av0);
       stageA_compute(cw >> 1, cw & 1, av0);
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // see the producers
     // stage-A tile of this wave in sub-step st (uprelu2 rows for the M-tiles of st + 1): tile id 2 pair + half belongs to
     // wave id & 3; its uprelu1 loads are requested one sub-step ahead
-    float av[5];
+    float av[6];
     int apr, ahh;
     auto stageA_pick = [&](int st) {
       const int lo = 2 * hs_pairs_done(st), hi = 2 * hs_pairs_done(st + 1);
