@@ -259,6 +259,11 @@ int ofx_policy_pin_weights(ofx_handle *h, const float *weights);
 /* Diagnostic switches of the policy forward (value 0 / 1): results agree up to fp32 summation order.              */
 #define OFX_OPT_TRUNK_PLAIN 1 /* the four trunk layers through the plain VALU convolution (test reference)        */
 #define OFX_OPT_FRAMES_REF  2 /* frame lines of the head from the definition instead of the phase form (reference) */
+/* NOT a diagnostic: which bilinear UpSampling2D((2,2), interpolation='bilinear') (qlearnIA_V2.py:166,172,178,184) means.
+ * The reference's unpinned keras / tensorflow range admits two: 0 (default) half-pixel centres (TF2 tf.image.resize),
+ * 1 the TF1 legacy resize_bilinear(align_corners=False), src = dst / 2.  Weights trained under one give a different
+ * heat map under the other.  Applies to the forward, the DQN targets and ofx_dqn_fit; a pinned blob is re-prepared. */
+#define OFX_OPT_BILINEAR_LEGACY 3
 int ofx_set_option(ofx_handle *h, int32_t option, int32_t value);
 /* Exploration of the bi-head action space (Trainer.get_best_action epsilon branch, agents/qlearnIA_V2.py:199-204,
  * and the collecting phase :393-395): for every selected ship, with probability `epsilon` - or always when
@@ -356,9 +361,9 @@ int ofx_policy_forward_obs(ofx_handle *h, const float *weights, int32_t n_obs, c
  *   q_sa  = act_values(state)[iaction]           y_act = reward + gamma * max(act_values(next_state)) * (not done)
  *   p_sp  = heat(state) at ipointer              y_ptr = reward + gamma * max(heat(next_state))       * (not done)
  * i.e. the current values and the values written into target[iaction] / ptr_target[ipointer]; their squared
- * differences are the two MSE terms the fit minimises.  The reference indexes ptr_target[x][y] on a [y][x] map
- * (:280) and fits on next_state's inputs (:282-283); here the pointer addresses the pixel it was chosen as - the
- * quirks are stated, not reproduced.  Padding rows (ship < 0) give zeros.  The fit itself is not built.           */
+ * differences are the two MSE terms ofx_dqn_fit minimises.  The reference indexes ptr_target[x][y] on a [y][x] map
+ * (:280) and fits on next_state's inputs (:282-283); here the pointer addresses the pixel it was chosen as
+ * (ofx_dqn_fit_reference reproduces the reference as written).  Padding rows (ship < 0) give zeros.               */
 int ofx_dqn_targets(ofx_handle *h, const float *weights, int32_t n, const ofx_transition *rows, const void *bits_prev,
                     const void *bits_next, float gamma, float *q_sa, float *p_sp, float *y_act, float *y_ptr);
 
@@ -369,12 +374,26 @@ int ofx_dqn_targets(ofx_handle *h, const float *weights, int32_t n, const ofx_tr
  * 1-based).  weights / adam_m / adam_v: device float32 [n_floats] in the ofx_policy_layout order, updated in place;
  * grad_out (device, may be NULL) receives the gradient; loss_host[2] = the two mse terms.  Inputs are the
  * transitions' `state` observations and the pointer addresses heat[y][x] (the reference fits on next_state's inputs
- * and indexes [x][y], :280-283: stated, not reproduced).  Every row must be a real transition (ship >= 0; use
+ * and indexes [x][y], :280-283: that form is ofx_dqn_fit_reference).  Every row must be a real transition (ship >= 0; use
  * ofx_replay_gather_valid): a padding row would enter the BatchNorm batch statistics and the loss scale, so the call
  * fails with OFX_ERR_INVALID before anything is updated.  Reference-quality kernels, not the hot path; synchronises. */
 int ofx_dqn_fit(ofx_handle *h, float *weights, float *adam_m, float *adam_v, int32_t step, float lr, int32_t n,
                 const ofx_transition *rows, const void *bits_prev, const float *y_act, const float *y_ptr,
                 float *grad_out, float *loss_host);
+/* The same step with Trainer.replay's quirks reproduced as written (agents/qlearnIA_V2.py:251-285), for a user who
+ * wants the reference's training dynamics rather than the textbook DQN step above:
+ *   - targets are whole predictions of `state` ([target, ptr_target] = predict(state), inference-mode BatchNorm) with
+ *     target[iaction] and ptr_target[ipointer] replaced (:279-280);
+ *   - ipointer = (x, y) indexes the (400, 400, 1) prediction as [x][y] - row x, column y, the transpose of the pixel
+ *     get_best_action named (:218-220 vs :280);
+ *   - the fit's inputs are NEXT_state's maps and head (img_input is re-bound at :273; :282-283), so every output
+ *     element carries an error (training-mode forward on next_state against targets built from state).
+ * Computes the targets itself (gamma = Trainer.gamma, 0.9 at :60): rows / bits_prev / bits_next from
+ * ofx_replay_gather_valid.  Everything else (loss scale, Adam, moving statistics, padding refusal, outputs) as
+ * ofx_dqn_fit.  Parity with Keras is unpinned for both forms.                                                     */
+int ofx_dqn_fit_reference(ofx_handle *h, float *weights, float *adam_m, float *adam_v, int32_t step, float lr, int32_t n,
+                          const ofx_transition *rows, const void *bits_prev, const void *bits_next, float gamma,
+                          float *grad_out, float *loss_host);
 
 /* ---- timing helpers (HIP events on the handle's stream) ---------------- */
 int ofx_timer_start(ofx_handle *h);

@@ -29,7 +29,7 @@ BEHAVIOURS = {None: BOT_IDLE, "idle": BOT_IDLE, "random": BOT_RANDOM, "turret": 
  F_OBS_REWARD) = range(19)
 
 MAP_U8, MAP_F32, MAP_F64, MAP_BITS = range(4)
-OPT_TRUNK_PLAIN, OPT_FRAMES_REF = 1, 2   # ofx_set_option
+OPT_TRUNK_PLAIN, OPT_FRAMES_REF, OPT_BILINEAR_LEGACY = 1, 2, 3   # ofx_set_option
 
 
 class OfxError(Exception):
@@ -103,6 +103,7 @@ SIGNATURES = {
     "ofx_policy_forward_obs": (_i, [_vp, _vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ofx_dqn_targets": (_i, [_vp, _vp, C.c_int32, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp]),
     "ofx_dqn_fit": (_i, [_vp, _vp, _vp, _vp, C.c_int32, C.c_float, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ofx_dqn_fit_reference": (_i, [_vp, _vp, _vp, _vp, C.c_int32, C.c_float, C.c_int32, _vp, _vp, _vp, C.c_float, _vp, _vp]),
     "ofx_replay_create": (_i, [_vp, C.c_int32, C.c_int32]),
     "ofx_replay_destroy": (_i, [_vp]),
     "ofx_replay_capture": (_i, [_vp, _u32, _vp, _vp, _vp]),

@@ -22,7 +22,7 @@ struct HeadParams2 {
   float *heat;                  // [S][400][400] or null
   const int32_t *probe;         // [S][2] (x, y) or null
   float *ptr_probe;             // [S] heat-map value at the probe
-  int frames_ref;               // frame lines through the from-the-definition kernel (OFX_OPT_FRAMES_REF)
+  int frames_ref; int legacy;               // frame lines through the from-the-definition kernel (OFX_OPT_FRAMES_REF)
   int event_base;               // >= 0: ofx_event_record(event_base / event_base + 1) around k_head_stream
   int ablate;                   // diagnostics (OFX_HEAD_HOOKS builds only)
   unsigned long long *dbg;      // diagnostics: [blocks][8 waves][6] s_memtime sums

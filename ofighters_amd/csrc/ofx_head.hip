@@ -48,17 +48,19 @@ __device__ __forceinline__ unsigned hd_ordered_f32(float v) {
 // k_head_frames: exact frame lines.  One workgroup per ship.
 // ---------------------------------------------------------------------------------------------------------------
 
-// x2 half-pixel bilinear with edge clamp along a line of n samples, at up-res index u in [-1, 2n]:
-// even u = 2k -> L[k-1] + (L[k] - L[k-1]) * .75 ; odd u = 2k+1 -> L[k] + (L[k+1] - L[k]) * .25  (oracle: upsample2)
-__device__ __forceinline__ void hf_taps(int u, int n, int &ka, int &kb, float &w) {
+// x2 bilinear with edge clamp along a line of n samples, at up-res index u in [-1, 2n] (oracle: upsample2).
+// Half-pixel centres: even u = 2k -> L[k-1] + (L[k] - L[k-1]) * .75 ; odd u = 2k+1 -> L[k] + (L[k+1] - L[k]) * .25.
+// Legacy (src = u / 2): even -> L[k] ; odd -> L[k] + (L[k+1] - L[k]) * .5.
+__device__ __forceinline__ void hf_taps(int u, int n, int &ka, int &kb, float &w, int legacy) {
   const int k = u >> 1;  // arithmetic: u = -1 -> k = -1
-  if (u & 1) { ka = k; kb = k + 1; w = 0.25f; } else { ka = k - 1; kb = k; w = 0.75f; }
+  if (legacy) { ka = k; kb = k + 1; w = (u & 1) ? 0.5f : 0.f; }
+  else if (u & 1) { ka = k; kb = k + 1; w = 0.25f; } else { ka = k - 1; kb = k; w = 0.75f; }
   ka = min(max(ka, 0), n - 1);
   kb = min(max(kb, 0), n - 1);
 }
-__device__ __forceinline__ float hf_up(const float *L, int stride, int n, int u) {
+__device__ __forceinline__ float hf_up(const float *L, int stride, int n, int u, int legacy) {
   int ka, kb; float w;
-  hf_taps(u, n, ka, kb, w);
+  hf_taps(u, n, ka, kb, w, legacy);
   const float a = L[ka * stride], b = L[kb * stride];
   return a + (b - a) * w;
 }
@@ -98,8 +100,8 @@ __global__ __launch_bounds__(HF_THREADS) void k_head_frames_ref(HeadParams2 p) {
     if (t >= 0 && t < 100) {
       const int Y = isc ? t : f, X = isc ? f : t;
       int ya, yb, xa, xb; float wy, wx;
-      hf_taps(Y, 50, ya, yb, wy);
-      hf_taps(X, 50, xa, xb, wx);
+      hf_taps(Y, 50, ya, yb, wy, p.legacy);
+      hf_taps(X, 50, xa, xb, wx, p.legacy);
       const float *pl = l1 + ci * 2500;
       const float a = pl[ya * 50 + xa], bq = pl[ya * 50 + xb], d = pl[yb * 50 + xa], g = pl[yb * 50 + xb];
       const float top = a + (bq - a) * wx, bot = d + (g - d) * wx;
@@ -151,8 +153,8 @@ __global__ __launch_bounds__(HF_THREADS) void k_head_frames_ref(HeadParams2 p) {
     float v = 0.f;
     if (t >= 0 && t < 200) {
       int fa, fb, ta, tb; float wf, wt;
-      hf_taps(f, 100, fa, fb, wf);  // band axis: source rows (columns) fa, fb are inside the 2-wide band
-      hf_taps(t, 100, ta, tb, wt);
+      hf_taps(f, 100, fa, fb, wf, p.legacy);  // band axis: source rows (columns) fa, fb are inside the 2-wide band
+      hf_taps(t, 100, ta, tb, wt, p.legacy);
       const int ba = fa < 2 ? fa : fa - 96, bb = fb < 2 ? fb : fb - 96;
       const float *src = isc ? u2cb : u2rb;
       const float a = src[(ba * 100 + ta) * 4 + ci], bq = src[(ba * 100 + tb) * 4 + ci];
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(HF_THREADS) void k_head_frames_ref(HeadParams2 p) {
 #pragma unroll
         for (int ci = 0; ci < 8; ci++) {
           const int tap = isc ? d1 * 3 + d0 : d0 * 3 + d1;
-          acc += p.w4raw[tap * 8 + ci] * hf_up(u3l + ln * 1600 + ci, 8, 200, t + d1 - 1);
+          acc += p.w4raw[tap * 8 + ci] * hf_up(u3l + ln * 1600 + ci, 8, 200, t + d1 - 1, p.legacy);
         }
       if (!isc && (t == 0 || t == 399)) {  // corner: the two taps of the column outside the image, rows inside
         const int cl = t ? 3 : 2, dx = t ? 2 : 0;
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(HF_THREADS) void k_head_frames_ref(HeadParams2 p) {
           if (dy == d0) continue;            // already counted with the row
           const int yy = (side ? 399 : 0) + dy - 1;
           if (yy < 0 || yy > 399) continue;  // cannot happen (dy == d0 covers it)
-          for (int ci = 0; ci < 8; ci++) acc += p.w4raw[(dy * 3 + dx) * 8 + ci] * hf_up(u3l + cl * 1600 + ci, 8, 200, yy);
+          for (int ci = 0; ci < 8; ci++) acc += p.w4raw[(dy * 3 + dx) * 8 + ci] * hf_up(u3l + cl * 1600 + ci, 8, 200, yy, p.legacy);
         }
       }
     }
@@ -251,18 +253,18 @@ static_assert(2 * 52 * 52 <= 6400, "l1p fits under u3l");
 // zero-padded conv output at a plane corner from the definition: cell (yc, xc) in {0, n2 - 1}^2 of the up-sampled
 // (n2 = 2 n) plane of `get(y, x, ci)` (low-res, n x n)
 template <int CIN, int COUT, class G>
-__device__ __forceinline__ float hg_corner(G get, int n, int yc, int xc, const float *w, float bias, int co) {
+__device__ __forceinline__ float hg_corner(G get, int n, int yc, int xc, const float *w, float bias, int co, int legacy) {
   float acc = bias;
   for (int dy = 0; dy < 3; dy++) {
     const int uy = yc + dy - 1;
     if (uy < 0 || uy >= 2 * n) continue;
     int ya, yb; float wy;
-    hf_taps(uy, n, ya, yb, wy);
+    hf_taps(uy, n, ya, yb, wy, legacy);
     for (int dx = 0; dx < 3; dx++) {
       const int ux = xc + dx - 1;
       if (ux < 0 || ux >= 2 * n) continue;
       int xa, xb; float wx;
-      hf_taps(ux, n, xa, xb, wx);
+      hf_taps(ux, n, xa, xb, wx, legacy);
       for (int ci = 0; ci < CIN; ci++) {
         const float a = get(ya, xa, ci), b = get(ya, xb, ci), d = get(yb, xa, ci), g = get(yb, xb, ci);
         const float top = a + (b - a) * wx, bot = d + (g - d) * wx;
@@ -351,7 +353,7 @@ __global__ __launch_bounds__(HG_THREADS) void k_head_frames(HeadParams2 p) {
     float val;
     if (fy && fx) {
       auto get = [&](int yy, int xx, int ci) { return l1p[(ci * 52 + yy + 1) * 52 + xx + 1]; };
-      val = hg_corner<2, 4>(get, 50, y, x, p.w2raw, p.b2[co], co);
+      val = hg_corner<2, 4>(get, 50, y, x, p.w2raw, p.b2[co], co, p.legacy);
     } else if (fx) {
       val = u2cb[(cb * 102 + y + 1) * 4 + co];
     } else {
@@ -410,7 +412,7 @@ __global__ __launch_bounds__(HG_THREADS) void k_head_frames(HeadParams2 p) {
     auto get = [&](int yy, int xx, int ci) {  // uprelu2 near the corner: rows {0,1} / {98,99} of the row bands
       return u2rb[((yy < 50 ? yy : yy - 96) * 102 + xx + 1) * 4 + ci];
     };
-    const float val = hg_corner<4, 8>(get, 100, y, x, p.w3raw, p.b3[co], co);
+    const float val = hg_corner<4, 8>(get, 100, y, x, p.w3raw, p.b3[co], co, p.legacy);
     u3l[(((c & 1) ? 1 : 0) * 200 + x) * 8 + co] = val;
     u3l[(((c & 2) ? 3 : 2) * 200 + y) * 8 + co] = val;
   }

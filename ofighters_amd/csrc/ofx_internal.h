@@ -62,7 +62,7 @@ struct ofx_handle {
   size_t aux_bytes;
   float *prep;                     // prepared policy weights (BN folded, phase weights, tables): ofx_policy.hip
   const float *prep_pinned;        // the blob `prep` was built from while it is pinned (ofx_policy_pin_weights)
-  bool opt_trunk_plain, opt_frames_ref;  // ofx_set_option
+  bool opt_trunk_plain, opt_frames_ref, opt_bilinear_legacy;  // ofx_set_option
 };
 #define OFX_RING_MAX 65536         /* numbered events of ofx_event_record */
 
@@ -73,6 +73,9 @@ int ofx_ensure_scratch(ofx_handle *h, size_t bytes);
 void ofx_replay_free(ofx_handle *h);
 int ofx_replay_episode_reset(ofx_handle *h, const uint8_t *arena_mask);
 int ofx_policy_weights_updated(ofx_handle *h, const float *weights);  // the blob was changed in place (ofx_dqn_fit)
+// model.predict on n stored observations: act_values [n][2], heatmap [n][H][W], ptr_max [n] (any may be null)
+int ofx_policy_predict_obs(ofx_handle *h, const float *weights, int32_t n_obs, const void *bits, const float *vec8,
+                           float *act_values, float *heatmap, float *ptr_max);
 
 #define OFX_MAP_BITS_LSB 4 /* internal: 1 bit / cell, pixel p -> bit (p & 31) of word p >> 5 */
 

@@ -111,15 +111,20 @@ struct PrepParams {
   int src_k4, src_b4, dst_w4raw, dst_b4, dst_efr;
   int dst_w4eff_c, dst_w3mf, dst_w2mf, dst_w2fr, dst_w3fr, dst_lut1, dst_wbm[3];
   int phase;
+  int legacy;                      // OFX_OPT_BILINEAR_LEGACY
 };
 
-// interpolation coefficients of the x2 half-pixel bilinear: output row 2i+a, conv
-// tap dy in {-1,0,1} touches low-res rows i-1, i, i+1 with these weights
-__device__ inline float up_coef(int a, int dy, int t) {
-  // a=0: dy-1 -> row 2i-1 = .75 L[i-1] + .25 L[i]; dy0 -> .25 L[i-1] + .75 L[i]; dy+1 -> .75 L[i] + .25 L[i+1]
-  // a=1: dy-1 -> row 2i   = .25 L[i-1] + .75 L[i]; dy0 -> .75 L[i] + .25 L[i+1]; dy+1 -> .25 L[i] + .75 L[i+1]
+// interpolation coefficients of the x2 bilinear up-sampling: output row 2i+a, conv tap dy in {-1,0,1} touches low-res
+// rows i-1, i, i+1 with these weights.  Half-pixel centres (default): up[2i] = .25 L[i-1] + .75 L[i],
+// up[2i+1] = .75 L[i] + .25 L[i+1].  Legacy (TF1 resize_bilinear, OFX_OPT_BILINEAR_LEGACY): up[2i] = L[i],
+// up[2i+1] = .5 L[i] + .5 L[i+1].  Both clamp at the edge, so the phase form and its frame handling are the same.
+__device__ inline float up_coef(int a, int dy, int t, int legacy) {
+  // a=0: dy-1 -> row 2i-1, dy0 -> row 2i, dy+1 -> row 2i+1 ; a=1: rows 2i, 2i+1, 2i+2
   const float c0[3][3] = {{0.75f, 0.25f, 0.f}, {0.25f, 0.75f, 0.f}, {0.f, 0.75f, 0.25f}};
   const float c1[3][3] = {{0.25f, 0.75f, 0.f}, {0.f, 0.75f, 0.25f}, {0.f, 0.25f, 0.75f}};
+  const float l0[3][3] = {{0.5f, 0.5f, 0.f}, {0.f, 1.f, 0.f}, {0.f, 0.5f, 0.5f}};
+  const float l1[3][3] = {{0.f, 1.f, 0.f}, {0.f, 0.5f, 0.5f}, {0.f, 0.f, 1.f}};
+  if (legacy) return a ? l1[dy][t] : l0[dy][t];
   return a ? c1[dy][t] : c0[dy][t];
 }
 
@@ -148,7 +153,7 @@ __global__ void k_policy_prepare(PrepParams p) {
     float acc = 0.f;
     for (int dy = 0; dy < 3; dy++)
       for (int dx = 0; dx < 3; dx++)
-        acc += p.w[p.src_k4 + (dy * 3 + dx) * 8 + ci] * (up_coef(a, dy, ty) * up_coef(b, dx, tx));
+        acc += p.w[p.src_k4 + (dy * 3 + dx) * 8 + ci] * (up_coef(a, dy, ty, p.legacy) * up_coef(b, dx, tx, p.legacy));
     p.prep[p.dst_w4eff_c + (ci * 4 + ph) * 9 + tap] = acc;
   }
   for (int e = tid; e < 72; e += nthr) p.prep[p.dst_w4raw + e] = p.w[p.src_k4 + e];
@@ -159,7 +164,7 @@ __global__ void k_policy_prepare(PrepParams p) {
     float acc = 0.f;
     for (int d = 0; d < 3; d++) {
       const int tap = isv ? d * 3 + (side ? 2 : 0) : (side ? 2 : 0) * 3 + d;
-      acc += p.w[p.src_k4 + tap * 8 + ci] * up_coef(b, d, o);
+      acc += p.w[p.src_k4 + tap * 8 + ci] * up_coef(b, d, o, p.legacy);
     }
     p.prep[p.dst_efr + e] = acc;
   }
@@ -175,7 +180,7 @@ __global__ void k_policy_prepare(PrepParams p) {
       float acc = 0.f;
       for (int dy = 0; dy < 3; dy++)
         for (int dx = 0; dx < 3; dx++)
-          acc += (p.w[p.src_k[6] + ((dy * 3 + dx) * cin + ci) * cout + co] * inv) * (up_coef(a, dy, ty) * up_coef(b, dx, tx));
+          acc += (p.w[p.src_k[6] + ((dy * 3 + dx) * cin + ci) * cout + co] * inv) * (up_coef(a, dy, ty, p.legacy) * up_coef(b, dx, tx, p.legacy));
       p.prep[p.dst_w3mf + ((co >> 2) * 36 + tap * 4 + ci) * 16 + ph * 4 + (co & 3)] = acc;
     }
   }
@@ -206,7 +211,7 @@ __global__ void k_policy_prepare(PrepParams p) {
         const float inv = g[co] / sqrtf(g[3 * cout + co] + 1e-3f);
         for (int dy = 0; dy < 3; dy++)
           for (int dx = 0; dx < 3; dx++)
-            acc += (p.w[p.src_k[5] + ((dy * 3 + dx) * cin + ci) * cout + co] * inv) * (up_coef(a, dy, ty) * up_coef(b, dx, tx));
+            acc += (p.w[p.src_k[5] + ((dy * 3 + dx) * cin + ci) * cout + co] * inv) * (up_coef(a, dy, ty, p.legacy) * up_coef(b, dx, tx, p.legacy));
       }
       p.prep[p.dst_w2mf + e] = acc;
     }
@@ -226,7 +231,7 @@ __global__ void k_policy_prepare(PrepParams p) {
           for (int dx = 0; dx < 3; dx++) {
             const bool drop = (v == 0 && a == 0 && dy == 0) || (v == 1 && a == 1 && dy == 2) || (v == 2 && b == 0 && dx == 0) ||
                               (v == 3 && b == 1 && dx == 2);
-            if (!drop) acc += (p.w[p.src_k[5] + ((dy * 3 + dx) * 2 + ci) * 4 + co] * inv) * (up_coef(a, dy, ty) * up_coef(b, dx, tx));
+            if (!drop) acc += (p.w[p.src_k[5] + ((dy * 3 + dx) * 2 + ci) * 4 + co] * inv) * (up_coef(a, dy, ty, p.legacy) * up_coef(b, dx, tx, p.legacy));
           }
       }
       p.prep[p.dst_w2fr + e] = acc;
@@ -239,7 +244,7 @@ __global__ void k_policy_prepare(PrepParams p) {
       for (int dy = 0; dy < 3; dy++)
         for (int dx = 0; dx < 3; dx++) {
           const bool drop = (v == 0 && dy == 0) || (v == 1 && dy == 2) || (v == 2 && dx == 0) || (v == 3 && dx == 2);
-          if (!drop) acc += (p.w[p.src_k[6] + ((dy * 3 + dx) * 4 + ci) * 8 + co] * inv) * (up_coef(a, dy, ty) * up_coef(b, dx, tx));
+          if (!drop) acc += (p.w[p.src_k[6] + ((dy * 3 + dx) * 4 + ci) * 8 + co] * inv) * (up_coef(a, dy, ty, p.legacy) * up_coef(b, dx, tx, p.legacy));
         }
       p.prep[p.dst_w3fr + e] = acc;
     }
@@ -268,9 +273,10 @@ struct ConvParams {
   const float *wbm;                // k_convm, CIN = 8: per-lane B operand [24][64] (PrepLayout::wbm)
   int H, W;                        // conv domain (input after any upsampling) = conv output size
   int tiles_x, tiles;              // tiles per row / per image
+  int legacy;                      // MODE 2: TF1 legacy source mapping (src = dst / 2) instead of half-pixel centres
 };
 
-// MODE: 0 planar f32 input, 1 two 1-bit maps, 2 planar f32 input upsampled x2 (bilinear, half-pixel)
+// MODE: 0 planar f32 input, 1 two 1-bit maps, 2 planar f32 input upsampled x2 (bilinear, half-pixel or legacy)
 template <int CIN, int COUT, int TH, int TW, int MODE, bool POOL, bool OUT_HWC>
 __global__ __launch_bounds__(((TH / 2) * (TW / 2) + 63) / 64 * 64) void k_conv(ConvParams p) {
   constexpr int NT = (TH / 2) * (TW / 2);
@@ -304,7 +310,8 @@ __global__ __launch_bounds__(((TH / 2) * (TW / 2) + 63) / 64 * 64) void k_conv(C
             v = (float)((p.bits[ci][(size_t)img * p.bits_stride + (cell >> 5)] >> (cell & 31)) & 1u);
           } else {
             const int Hs = H >> 1, Ws = W >> 1;
-            const float sy = ((float)gy + 0.5f) * 0.5f - 0.5f, sx = ((float)gx + 0.5f) * 0.5f - 0.5f;
+            const float sy = p.legacy ? (float)gy * 0.5f : ((float)gy + 0.5f) * 0.5f - 0.5f;
+            const float sx = p.legacy ? (float)gx * 0.5f : ((float)gx + 0.5f) * 0.5f - 0.5f;
             const float fy = floorf(sy), fx = floorf(sx);
             const float ly = sy - fy, lx = sx - fx;
             int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1, x1 = x0 + 1;
@@ -399,7 +406,7 @@ __device__ __forceinline__ float max_raw(float x, float floor) {
 // A[x][k] is gathered from an LDS copy of the input tile (one ds_read_b32 per lane per MFMA, immediate offsets);
 // the row pair of a column group shares one accumulator quad: lane (n = (co, r), kq) holds pixels 4 kq .. 4 kq + 3,
 // so the x-pool is in-lane and the y-pool is one DPP quad swap.
-// MODE 0: planar f32 input [img][CIN][H][W]; MODE 1: two 1-bit maps (CIN = 2).  Output: planar [img][8][H/2][W/2] or
+// MODE 0: planar f32 input [img][CIN][H][W] (the only mode left; conv1 reads the bit maps through k_conv1_lut).  Output: planar [img][8][H/2][W/2] or
 // (OUT_HWC) [img][H/2][W/2][8].  TH rows x 16 NG columns per workgroup, TH even, H % TH == 0; W is masked.
 // A workgroup walks TPW consecutive tiles of one image: the weights are fetched once, the global loads of tile i+1 are
 // in flight (in registers) while tile i computes, and the grid stays small (the dispatcher needs ~5 ns per workgroup:
@@ -437,31 +444,14 @@ __global__ __launch_bounds__(256) void k_convm(ConvParams p) {
   const int H2 = H >> 1, W2 = W >> 1;
 
   // ---- staging, split into fetch (global -> registers) and commit (registers -> LDS) ----
-  constexpr int WPR = (TW + 2 + 31) / 32 + 1;                      // MODE 1: words a tile row can touch
-  constexpr int NWI = MODE == 1 ? (ROWS * WPR + 255) / 256 : 1;    // word items per thread
   constexpr int V4 = TW / 4, RPW = VEC ? (ROWS + 3) / 4 : 1;       // VEC: float4 per row, rows per wave
   static_assert(!VEC || V4 + 2 <= 64, "tile row wider than one wave");
-  unsigned wpre[NWI];
   f32x4 vpre[RPW];  // native vectors: a float4 select is lowered to a pointer select + flat loads
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 
   auto fetch = [&](int t) {
     const int ty0 = (t / p.tiles_x) * TH, tx0 = (t % p.tiles_x) * TW;
-    if constexpr (MODE == 1) {
-#pragma unroll
-      for (int u = 0; u < NWI; u++) {
-        const int e = tid + 256 * u;
-        const int k = e % WPR, rr = (e / WPR) % (TH + 2), ci = e / (WPR * (TH + 2));
-        const int gy = ty0 - 1 + rr;
-        unsigned word = 0u;
-        if (e < ROWS * WPR && gy >= 0 && gy < H) {
-          const int cell0 = gy * W + tx0 - 1;
-          const int wi = ((cell0 >= 0 ? cell0 : 0) >> 5) + k;
-          if (wi < (PS * PS) >> 5) word = p.bits[ci][(size_t)img * p.bits_stride + wi];
-        }
-        wpre[u] = word;
-      }
-    } else if constexpr (VEC) {
+    if constexpr (VEC) {
       // a wave moves one tile row per step: lane i < V4 the i-th float4 of the interior, lanes V4 / V4+1 the float4
       // that holds the left / right halo column
       const int gxl = lane < V4 ? tx0 + 4 * lane : (lane == V4 ? tx0 - 4 : tx0 + TW);
@@ -482,30 +472,7 @@ __global__ __launch_bounds__(256) void k_convm(ConvParams p) {
 
   auto commit = [&](int t) {
     const int ty0 = (t / p.tiles_x) * TH, tx0 = (t % p.tiles_x) * TW;
-    if constexpr (MODE == 1) {
-#pragma unroll
-      for (int u = 0; u < NWI; u++) {
-        const int e = tid + 256 * u;
-        if (e >= ROWS * WPR) break;
-        const int k = e % WPR, rr = (e / WPR) % (TH + 2), ci = e / (WPR * (TH + 2));
-        const int gy = ty0 - 1 + rr;
-        float *trow = &tile[ci * PLS + rr * LS + 3];  // trow[c] <-> image column tx0 - 1 + c
-        if (gy < 0 || gy >= H) {
-          for (int c = k; c < TW + 2; c += WPR) trow[c] = 0.f;
-          continue;
-        }
-        const int cell0 = gy * W + tx0 - 1;            // cell index of column c = 0 (-1 at the left image edge)
-        const int wi = ((cell0 >= 0 ? cell0 : 0) >> 5) + k;
-        const int cbeg = max(wi * 32 - cell0, 0), cend = min(wi * 32 + 32 - cell0, TW + 2);
-        if (k == 0)
-          for (int c = 0; c < cbeg; c++) trow[c] = 0.f;
-        const unsigned sh = wpre[u] >> ((cell0 + cbeg) & 31);
-        for (int c = cbeg; c < cend; c++) {
-          const int gx = tx0 - 1 + c;
-          trow[c] = (gx >= 0 && gx < W && ((sh >> (c - cbeg)) & 1u)) ? 1.f : 0.f;
-        }
-      }
-    } else if constexpr (VEC) {
+    if constexpr (VEC) {
 #pragma unroll
       for (int u = 0; u < RPW; u++) {
         const int rr = wv + 4 * u;
@@ -954,6 +921,7 @@ static int policy_prepare(ofx_handle *h, const float *weights) {
   pp.dst_w4raw = L.w4raw; pp.dst_b4 = L.b4; pp.dst_efr = L.efr;
   pp.dst_w4eff_c = L.w4eff_c; pp.dst_w3mf = L.w3mf; pp.dst_w2mf = L.w2mf; pp.dst_w2fr = L.w2fr; pp.dst_w3fr = L.w3fr; pp.dst_lut1 = L.lut1;
   for (int i = 0; i < 3; i++) pp.dst_wbm[i] = L.wbm[i];
+  pp.legacy = h->opt_bilinear_legacy;
   pp.phase = 0;
   hipLaunchKernelGGL(k_policy_prepare, dim3(32), dim3(256), 0, h->stream, pp);
   pp.phase = 1;
@@ -985,6 +953,11 @@ extern "C" int ofx_set_option(ofx_handle *h, int32_t option, int32_t value) {
   switch (option) {
     case OFX_OPT_TRUNK_PLAIN: h->opt_trunk_plain = value != 0; return OFX_OK;
     case OFX_OPT_FRAMES_REF: h->opt_frames_ref = value != 0; return OFX_OK;
+    case OFX_OPT_BILINEAR_LEGACY:  // a different function, not a variant: the prepared phase weights depend on it
+      if (h->opt_bilinear_legacy == (value != 0)) return OFX_OK;
+      h->opt_bilinear_legacy = value != 0;
+      OFX_HIP(hipSetDevice(h->cfg.device));
+      return h->prep_pinned ? policy_prepare(h, h->prep_pinned) : OFX_OK;
     default: ofx_set_error("ofx_set_option: unknown option %d", option); return OFX_ERR_INVALID;
   }
 }
@@ -1060,7 +1033,7 @@ static int policy_forward_impl(ofx_handle *h, const float *weights, int N, int M
     return rc;
   ConvParams up;
   memset(&up, 0, sizeof(up));
-  up.mask = ship_mask;
+  up.mask = ship_mask; up.legacy = h->opt_bilinear_legacy;
   up.in = ws.u0; up.w = prep + L.uw[0]; up.b = prep + L.ub[0]; up.out = ws.up1;
   if ((rc = launch_conv<1, 2, 10, 50, 2, false, false>(h, up, S, 50))) return rc;
   OFX_HIP(hipMemsetAsync(ws.best, 0, sizeof(unsigned long long) * S, h->stream));
@@ -1072,7 +1045,7 @@ static int policy_forward_impl(ofx_handle *h, const float *weights, int N, int M
   hp2.w4eff_c = prep + L.w4eff_c; hp2.b4 = prep + L.b4; hp2.w4raw = prep + L.w4raw;
   hp2.w2fr = prep + L.w2fr; hp2.w3fr = prep + L.w3fr; hp2.efr = prep + L.efr;
   hp2.u2fr = ws.u2fr; hp2.u3fr = ws.u3fr; hp2.c4 = ws.c4;
-  hp2.frames_ref = h->opt_frames_ref;
+  hp2.frames_ref = h->opt_frames_ref; hp2.legacy = h->opt_bilinear_legacy;
   hp2.mask = ship_mask; hp2.best = ws.best; hp2.heat = heatmap; hp2.probe = probe; hp2.ptr_probe = probe ? ptr_probe : nullptr;
   const int pb = h->prof_base;  // ofx_policy_profile: events around the dominant kernel, until the ring is full
   hp2.event_base = pb;
@@ -1111,6 +1084,14 @@ extern "C" int ofx_policy_forward_obs(ofx_handle *h, const float *weights, int32
   const size_t words = (size_t)(PS * PS) >> 5;
   return policy_forward_impl(h, weights, n_obs, 1, (const unsigned *)bits, (const unsigned *)bits + words, 2 * words, vec8,
                              nullptr, act_values, iaction, ipointer, nullptr, ptr_max, probe, ptr_probe);
+}
+
+// model.predict on stored observations with the whole heat map written out (ofx_dqn_fit_reference, ofx_train.hip)
+int ofx_policy_predict_obs(ofx_handle *h, const float *weights, int32_t n_obs, const void *bits, const float *vec8,
+                           float *act_values, float *heatmap, float *ptr_max) {
+  const size_t words = (size_t)(PS * PS) >> 5;
+  return policy_forward_impl(h, weights, n_obs, 1, (const unsigned *)bits, (const unsigned *)bits + words, 2 * words, vec8,
+                             nullptr, act_values, nullptr, nullptr, heatmap, ptr_max, nullptr, nullptr);
 }
 
 // ---- TD targets of Trainer.replay (agents/qlearnIA_V2.py:251-270) -------------------------------------------------

@@ -215,34 +215,35 @@ __global__ void t_pool_bwd(int nc, int H, int W, const float *a, const float *dp
   }
 }
 
-// x2 bilinear, half-pixel centres, edge clamp: u[nc][2H][2W]
-__device__ inline void up_taps(int u, int n, int &i0, int &i1, float &w1) {
+// x2 bilinear, edge clamp: u[nc][2H][2W]; half-pixel centres, or (legacy, OFX_OPT_BILINEAR_LEGACY) src = dst / 2
+__device__ inline void up_taps(int u, int n, int &i0, int &i1, float &w1, int legacy) {
   const int k = u >> 1;
-  if (u & 1) { i0 = k; i1 = min(k + 1, n - 1); w1 = 0.25f; }
+  if (legacy) { i0 = k; i1 = min(k + 1, n - 1); w1 = (u & 1) ? 0.5f : 0.f; }
+  else if (u & 1) { i0 = k; i1 = min(k + 1, n - 1); w1 = 0.25f; }
   else { i0 = max(k - 1, 0); i1 = k; w1 = 0.75f; }
 }
-__global__ void t_up_fwd(int nc, int H, int W, const float *x, float *u) {
+__global__ void t_up_fwd(int nc, int H, int W, const float *x, float *u, int legacy) {
   const int H2 = 2 * H, W2 = 2 * W;
   const size_t total = (size_t)nc * H2 * W2;
   for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
     const int ux = e % W2, uy = (e / W2) % H2;
     const size_t c = e / ((size_t)W2 * H2);
     int y0, y1, x0, x1; float wy, wx;
-    up_taps(uy, H, y0, y1, wy); up_taps(ux, W, x0, x1, wx);
+    up_taps(uy, H, y0, y1, wy, legacy); up_taps(ux, W, x0, x1, wx, legacy);
     const float *q = x + c * H * W;
     const float top = q[(size_t)y0 * W + x0] * (1.f - wx) + q[(size_t)y0 * W + x1] * wx;
     const float bot = q[(size_t)y1 * W + x0] * (1.f - wx) + q[(size_t)y1 * W + x1] * wx;
     u[e] = top * (1.f - wy) + bot * wy;
   }
 }
-__global__ void t_up_bwd(int nc, int H, int W, const float *du, float *dx) {  // dx must be zero-filled
+__global__ void t_up_bwd(int nc, int H, int W, const float *du, float *dx, int legacy) {  // dx must be zero-filled
   const int H2 = 2 * H, W2 = 2 * W;
   const size_t total = (size_t)nc * H2 * W2;
   for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
     const int ux = e % W2, uy = (e / W2) % H2;
     const size_t c = e / ((size_t)W2 * H2);
     int y0, y1, x0, x1; float wy, wx;
-    up_taps(uy, H, y0, y1, wy); up_taps(ux, W, x0, x1, wx);
+    up_taps(uy, H, y0, y1, wy, legacy); up_taps(ux, W, x0, x1, wx, legacy);
     float *q = dx + c * H * W;
     const float g = du[e];
     if (g == 0.f) continue;
@@ -293,11 +294,11 @@ __global__ void t_dense_bwd_x(int n, int in_n, int out_n, const float *dy, const
 }
 
 // f[n][5008] = concat(vec8, flatten_hwc(x4 [n][8][25][25])) and its transpose for the gradient
-__global__ void t_concat_fwd(int n, const ofx_transition *rows, const float *x4, float *f) {
+__global__ void t_concat_fwd(int n, const ofx_transition *rows, const float *x4, float *f, int next_head) {
   const size_t total = (size_t)n * 5008;
   for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
     const int k = e % 5008, s = e / 5008;
-    if (k < 8) f[e] = rows[s].head_prev[k];
+    if (k < 8) f[e] = next_head ? rows[s].head_next[k] : rows[s].head_prev[k];
     else { const int j = k - 8, c = j % 8, p = j / 8; f[e] = x4[((size_t)s * 8 + c) * 625 + p]; }
   }
 }
@@ -324,6 +325,38 @@ __global__ void t_loss_seed(int n, const ofx_transition *rows, const float *o1, 
   do2[k] = 2.f * e2 / ((float)(TPS * TPS) * n);
   atomicAdd(&loss[0], e1 * e1 / (2.f * n));
   atomicAdd(&loss[1], e2 * e2 / ((float)(TPS * TPS) * n));
+}
+
+// Trainer.replay as written (ofx_dqn_fit_reference): the targets are whole predictions of `state` with one entry
+// replaced per head, so every output carries an error.  t1 [n][2], t2 [n][TPS][TPS].
+__global__ void t_reference_targets(int n, const ofx_transition *rows, float gamma, const float *act_next,
+                                    const float *max_next, float *t1, float *t2) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  const ofx_transition r = rows[s];
+  const float live = r.done ? 0.f : 1.f;                                     // int(not done)
+  const int px = min(max(r.px, 0), TPS - 1), py = min(max(r.py, 0), TPS - 1);
+  t1[2 * s + (r.iaction ? 1 : 0)] = (float)r.reward + gamma * fmaxf(act_next[2 * s], act_next[2 * s + 1]) * live;  // :279
+  // ptr_target[ipointer] with ipointer = (x, y) on the (400, 400, 1) prediction = [row][col][0]: row x, column y (:280)
+  t2[(size_t)s * TPS * TPS + (size_t)px * TPS + py] = (float)r.reward + gamma * max_next[s] * live;
+}
+__global__ void t_unpack_heads(int n, const ofx_transition *rows, float *vec_prev, float *vec_next) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  for (int k = 0; k < 8; k++) {
+    vec_prev[(size_t)s * 8 + k] = rows[s].head_prev[k];
+    vec_next[(size_t)s * 8 + k] = rows[s].head_next[k];
+  }
+}
+__global__ void t_loss_dense(size_t total, float scale, const float *o, const float *t, float *d, float *loss) {
+  float acc = 0.f;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const float err = o[e] - t[e];
+    d[e] = 2.f * err * scale;
+    acc += err * err * scale;
+  }
+  for (int o_ = 32; o_ > 0; o_ >>= 1) acc += __shfl_xor(acc, o_);
+  if ((threadIdx.x & 63) == 0 && acc != 0.f) atomicAdd(loss, acc);
 }
 
 __global__ void t_adam(size_t cnt, float *w, const float *g, float *m, float *v, float lr_t, float b1, float b2, float eps) {
@@ -378,13 +411,13 @@ __global__ void t_count_pads(int n, const ofx_transition *rows, int32_t *out) {
   if (i < n && rows[i].ship < 0) atomicAdd(out, 1);
 }
 
-extern "C" int ofx_dqn_fit(ofx_handle *h, float *weights, float *adam_m, float *adam_v, int32_t step, float lr, int32_t n,
-                           const ofx_transition *rows, const void *bits_prev, const float *y_act, const float *y_ptr,
-                           float *grad_out, float *loss_host) {
-  if (!h || !weights || !adam_m || !adam_v || !rows || !bits_prev || !y_act || !y_ptr || n < 1 || step < 1) {
-    ofx_set_error("ofx_dqn_fit: bad argument");
-    return OFX_ERR_INVALID;
-  }
+// One fit step.  Two forms of the targets: the sparse one of ofx_dqn_fit (one error per head and sample: y_act / y_ptr,
+// inputs = `state`) and the dense one of ofx_dqn_fit_reference (t1 [n][2] / t2 [n][400][400] whole target tensors,
+// inputs = bits_in + the rows' next_state head).
+static int dqn_fit_impl(ofx_handle *h, float *weights, float *adam_m, float *adam_v, int32_t step, float lr, int32_t n,
+                        const ofx_transition *rows, const void *bits_prev, const float *y_act, const float *y_ptr,
+                        const float *t1, const float *t2, float *grad_out, float *loss_host) {
+  const bool dense = t1 != nullptr;
   OFX_HIP(hipSetDevice(h->cfg.device));
   hipStream_t st = h->stream;
   ofx_policy_desc L;
@@ -405,6 +438,7 @@ extern "C" int ofx_dqn_fit(ofx_handle *h, float *weights, float *adam_m, float *
     }
   }
   const size_t N = (size_t)n;
+  const int legacy = h->opt_bilinear_legacy;
   // activations: trunk sizes 400,200,100,50 (z, a per layer + pooled), head-2 sizes 50,100,200 (+ upsampled inputs)
   size_t need = 0;
   auto sz = [&](size_t fl) { need += (fl * 4 + 255) & ~(size_t)255; };
@@ -452,7 +486,7 @@ extern "C" int ofx_dqn_fit(ofx_handle *h, float *weights, float *adam_m, float *
     tin = tp[i];
   }
   float *f = A.f(N * 5008), *d1 = A.f(N * 100), *d2 = A.f(N * 50), *o1 = A.f(N * 2), *u0 = A.f(N * 625);
-  K(t_concat_fwd, N * 5008, n, rows, tp[3], f);
+  K(t_concat_fwd, N * 5008, n, rows, tp[3], f, dense ? 1 : 0);
   K(t_dense_fwd, N * 100, n, 5008, 100, f, T(24), T(25), d1, 1);
   K(t_dense_fwd, N * 50, n, 100, 50, d1, T(26), T(27), d2, 1);
   K(t_dense_fwd, N * 2, n, 50, 2, d2, T(28), T(29), o1, 0);
@@ -462,7 +496,7 @@ extern "C" int ofx_dqn_fit(ofx_handle *h, float *weights, float *adam_m, float *
   for (int j = 0, s = 50; j < 3; j++, s *= 2) {
     const size_t per = (size_t)s * s;
     uu[j] = A.f(N * kUI[j] * per); uz[j] = A.f(N * kUO[j] * per); ua[j] = A.f(N * kUO[j] * per); ustat[j] = A.f(16);
-    K(t_up_fwd, N * kUI[j] * per, n * kUI[j], s / 2, s / 2, uin, uu[j]);
+    K(t_up_fwd, N * kUI[j] * per, n * kUI[j], s / 2, s / 2, uin, uu[j], legacy);
     K(t_conv_fwd, N * kUO[j] * per, n, kUI[j], kUO[j], s, s, uu[j], T(32 + 6 * j), T(33 + 6 * j), uz[j]);
     OFX_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 32, st));
     hipLaunchKernelGGL(t_chan_sums, dim3(kUO[j], 64), dim3(256), 0, st, n, kUO[j], per, uz[j], (const float *)nullptr, sums);
@@ -471,14 +505,19 @@ extern "C" int ofx_dqn_fit(ofx_handle *h, float *weights, float *adam_m, float *
     uin = ua[j];
   }
   float *up4 = A.f(N * 8 * 160000), *o2 = A.f(N * 160000);
-  K(t_up_fwd, N * 8 * 160000, n * 8, 200, 200, ua[2], up4);
+  K(t_up_fwd, N * 8 * 160000, n * 8, 200, 200, ua[2], up4, legacy);
   K(t_conv_fwd, N * 160000, n, 8, 1, 400, 400, up4, T(50), T(51), o2);
 
   // ---- loss seeds ----
   float *do1 = A.f(N * 2), *do2 = A.f(N * 160000);
   OFX_HIP(hipMemsetAsync(do1, 0, N * 2 * 4, st));
   OFX_HIP(hipMemsetAsync(do2, 0, N * 160000 * 4, st));
-  K(t_loss_seed, N, n, rows, o1, o2, y_act, y_ptr, do1, do2, loss);
+  if (dense) {
+    K(t_loss_dense, N * 2, N * 2, 1.f / (2.f * n), o1, t1, do1, loss);
+    K(t_loss_dense, N * 160000, N * 160000, 1.f / (160000.f * n), o2, t2, do2, loss + 1);
+  } else {
+    K(t_loss_seed, N, n, rows, o1, o2, y_act, y_ptr, do1, do2, loss);
+  }
 
   // ---- backward: head 2 ----
   float *gA = A.f(N * 8 * 160000), *gB = A.f(N * 8 * 160000);  // gradient scratch (largest tensors)
@@ -486,7 +525,7 @@ extern "C" int ofx_dqn_fit(ofx_handle *h, float *weights, float *adam_m, float *
   K(t_conv_bwd_data, N * 8 * 160000, n, 8, 1, 400, 400, do2, T(50), gA);   // d up4
   float *dcur = gB;                                                          // d ua[2]
   OFX_HIP(hipMemsetAsync(dcur, 0, N * 8 * 40000 * 4, st));
-  K(t_up_bwd, N * 8 * 160000, n * 8, 200, 200, gA, dcur);
+  K(t_up_bwd, N * 8 * 160000, n * 8, 200, 200, gA, dcur, legacy);
   for (int j = 2, s = 200; j >= 0; j--, s /= 2) {
     const size_t per = (size_t)s * s, tot = N * kUO[j] * per;
     float *xh = gA;                                                          // reuse as xhat
@@ -500,7 +539,7 @@ extern "C" int ofx_dqn_fit(ofx_handle *h, float *weights, float *adam_m, float *
     K(t_conv_bwd_data, N * kUI[j] * per, n, kUI[j], kUO[j], s, s, dz, T(32 + 6 * j), duu);
     float *dprev = gB;                                                       // d (previous activation / u0)
     OFX_HIP(hipMemsetAsync(dprev, 0, N * kUI[j] * per / 4 * 4, st));
-    K(t_up_bwd, N * kUI[j] * per, n * kUI[j], s / 2, s / 2, duu, dprev);
+    K(t_up_bwd, N * kUI[j] * per, n * kUI[j], s / 2, s / 2, duu, dprev, legacy);
     dcur = dprev;
   }
   // dcur = d u0 [n][625] (pre-mask)
@@ -566,4 +605,51 @@ extern "C" int ofx_dqn_fit(ofx_handle *h, float *weights, float *adam_m, float *
   (void)W_;
   if ((rc = ofx_policy_weights_updated(h, weights))) return rc;  // a pinned blob is prepared again
   return OFX_OK;  // `release` frees the block (the stream is idle: synchronised above)
+}
+
+extern "C" int ofx_dqn_fit(ofx_handle *h, float *weights, float *adam_m, float *adam_v, int32_t step, float lr, int32_t n,
+                           const ofx_transition *rows, const void *bits_prev, const float *y_act, const float *y_ptr,
+                           float *grad_out, float *loss_host) {
+  if (!h || !weights || !adam_m || !adam_v || !rows || !bits_prev || !y_act || !y_ptr || n < 1 || step < 1) {
+    ofx_set_error("ofx_dqn_fit: bad argument");
+    return OFX_ERR_INVALID;
+  }
+  return dqn_fit_impl(h, weights, adam_m, adam_v, step, lr, n, rows, bits_prev, y_act, y_ptr, nullptr, nullptr, grad_out,
+                      loss_host);
+}
+
+// Trainer.replay's loop body and fit exactly as written (agents/qlearnIA_V2.py:251-285), quirks included:
+//   [target, ptr_target]         = predict(state)                                   (:266, inference-mode BatchNorm)
+//   [prediction, ptr_prediction] = predict(next_state)                              (:274)
+//   target[iaction]      = reward + gamma max(prediction)     int(not done)         (:279)
+//   ptr_target[ipointer] = reward + gamma max(ptr_prediction) int(not done)         (:280) - ipointer = (x, y) indexes
+//                          the (400, 400, 1) prediction as [x][y]: row x, column y, the transpose of the pixel that
+//                          get_best_action's unravel_index(order='F') named
+//   inputs1[i] = img_input (re-bound to NEXT_state's maps at :273), inputs2[i] = next_obs.vector[:8]     (:282-283)
+//   fit(x = inputs, y = [target, ptr_target]): training-mode forward on next_state against targets built from state
+// so every output element carries an error, not one per head.
+extern "C" int ofx_dqn_fit_reference(ofx_handle *h, float *weights, float *adam_m, float *adam_v, int32_t step, float lr,
+                                     int32_t n, const ofx_transition *rows, const void *bits_prev, const void *bits_next,
+                                     float gamma, float *grad_out, float *loss_host) {
+  if (!h || !weights || !adam_m || !adam_v || !rows || !bits_prev || !bits_next || n < 1 || step < 1) {
+    ofx_set_error("ofx_dqn_fit_reference: bad argument");
+    return OFX_ERR_INVALID;
+  }
+  OFX_HIP(hipSetDevice(h->cfg.device));
+  hipStream_t st = h->stream;
+  const size_t N = (size_t)n;
+  float *buf = nullptr;  // vec_prev [n][8], vec_next [n][8], act_next [n][2], max_next [n], t1 [n][2], t2 [n][160000]
+  OFX_HIP(hipMalloc((void **)&buf, sizeof(float) * N * (8 + 8 + 2 + 1 + 2 + 160000)));
+  struct Release {
+    void *p; hipStream_t st;
+    ~Release() { (void)hipStreamSynchronize(st); (void)hipFree(p); }
+  } release{buf, st};
+  float *vec_prev = buf, *vec_next = vec_prev + 8 * N, *act_next = vec_next + 8 * N, *max_next = act_next + 2 * N;
+  float *t1 = max_next + N, *t2 = t1 + 2 * N;
+  K(t_unpack_heads, N, n, rows, vec_prev, vec_next);
+  int rc;
+  if ((rc = ofx_policy_predict_obs(h, weights, n, bits_prev, vec_prev, t1, t2, nullptr))) return rc;
+  if ((rc = ofx_policy_predict_obs(h, weights, n, bits_next, vec_next, act_next, nullptr, max_next))) return rc;
+  K(t_reference_targets, N, n, rows, gamma, act_next, max_next, t1, t2);
+  return dqn_fit_impl(h, weights, adam_m, adam_v, step, lr, n, rows, bits_next, nullptr, nullptr, t1, t2, grad_out, loss_host);
 }

@@ -432,6 +432,16 @@ class ArenaBatch:
                                          grad_buf.ptr if grad_buf else None, loss))
         return float(loss[0]), float(loss[1])
 
+    def dqn_fit_reference(self, weights_buf, adam_m_buf, adam_v_buf, step, lr, n, rows_ptr, bits_prev_ptr, bits_next_ptr,
+                          gamma=0.9, grad_buf=None):
+        """The fit step with Trainer.replay's quirks as written (qlearnIA_V2.py:251-285: whole-prediction targets,
+        ptr_target[x][y], inputs = next_state); computes its own targets.  Returns (mse(output1), mse(output2))."""
+        loss = (C.c_float * 2)()
+        nat.check(nat.lib().ofx_dqn_fit_reference(self._h, weights_buf.ptr, adam_m_buf.ptr, adam_v_buf.ptr, int(step),
+                                                   float(lr), int(n), rows_ptr, bits_prev_ptr, bits_next_ptr, float(gamma),
+                                                   grad_buf.ptr if grad_buf else None, loss))
+        return float(loss[0]), float(loss[1])
+
     def policy_explore(self, epsilon, seed, tick=None, collecting=False, ship_mask_ptr=None, iaction_ptr=None,
                        ipointer_ptr=None):
         """epsilon-greedy / collecting-phase random play over the last forward's results."""

@@ -2,7 +2,8 @@
 for an ArenaBatch: weights, Adam state and the replay memory live in HBM; `get_best_action` is
 ArenaBatch.policy_forward + policy_explore, `remember` is ArenaBatch.replay_capture, and `replay(batch_size)`
 (:240-285) is sample -> gather -> targets -> one fit step, all through the C-ABI (ofx_replay_sample, ofx_replay_gather,
-ofx_dqn_targets, ofx_dqn_fit)."""
+ofx_dqn_targets, ofx_dqn_fit - or ofx_dqn_fit_reference with `reference_quirks=True`: the reference's step as written,
+ptr_target[x][y] and the fit on next_state's inputs included, :280-283)."""
 import numpy as np
 
 from .engine import DeviceBuffer
@@ -11,7 +12,7 @@ from .lib.epsilon import Epsilon_cos
 
 class DeviceTrainer:
     def __init__(self, batch, weights, learning_rate=0.0001, epsilon=None, batch_size=8, memory_size=400, frames=0,
-                 seed=0x0F160003, fit_batch=64):
+                 seed=0x0F160003, fit_batch=64, reference_quirks=False):
         self.batch = batch                                  # the ArenaBatch this trainer plays and learns on
         w = np.ascontiguousarray(weights, np.float32)
         self.n_floats = w.size
@@ -26,6 +27,7 @@ class DeviceTrainer:
         self.seed = seed
         self.fit_batch = fit_batch                          # rows per optimisation step (the reference fits on 8; the
                                                             # fit kernels are reference-quality, keep this small)
+        self.reference_quirks = bool(reference_quirks)      # Trainer.replay as written instead of the textbook DQN step
         self.fit_steps = 0
         self.draws = 0
         self.losses = []
@@ -58,6 +60,12 @@ class DeviceTrainer:
         if got != n:
             raise Exception("DeviceTrainer.replay: gathered %d of %d rows" % (got, n))
         rows_p, prev_p, next_p = rows.ptr, bits_prev.ptr, bits_next.ptr
+        if self.reference_quirks:
+            self.fit_steps += 1
+            loss = b.dqn_fit_reference(self.weights, self.adam_m, self.adam_v, self.fit_steps, self.learning_rate, n,
+                                       rows_p, prev_p, next_p, self.gamma)
+            self.losses.append(loss)
+            return loss
         outs = [DeviceBuffer(4 * n) for _ in range(4)]     # q_sa, p_sp, y_act, y_ptr
         from . import _native as nat
         nat.check(nat.lib().ofx_dqn_targets(b.handle, self.weights.ptr, n, rows_p, prev_p, next_p, float(self.gamma),

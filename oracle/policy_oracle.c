@@ -21,10 +21,14 @@
  *   Flatten      (h, w, c) order ; Concatenate([vector, flat]) : vector FIRST
  *   Dense        kernel (in, out) ; y = act(x @ K + b)
  *   Reshape      (25,25,1) row-major
- *   UpSampling2D (2,2) bilinear with HALF-PIXEL centres (tf.image.resize in TF2 =
- *                torch interpolate(align_corners=False)); the legacy TF1
- *                resize_bilinear(align_corners=False) convention differs - the
- *                reference's version range admits both, we declare this one.
+ *   UpSampling2D (2,2) bilinear.  The reference's unpinned keras/tensorflow range (requirements.txt:1-2) admits two
+ *                conventions for UpSampling2D(interpolation='bilinear') (qlearnIA_V2.py:166,172,178,184):
+ *                  legacy_bilinear = 0 (declared default): HALF-PIXEL centres, src = (dst + 0.5)/2 - 0.5
+ *                      (tf.image.resize of TF2 / tf.keras = torch interpolate(align_corners=False));
+ *                  legacy_bilinear = 1: TF1 resize_bilinear(align_corners=False) without half-pixel centres,
+ *                      src = dst/2 (standalone Keras 2.x on TF 1.x): out[2k] = in[k],
+ *                      out[2k+1] = (in[k] + in[min(k+1, n-1)])/2.
+ *                Both clamp at the edges.  Neither can be pinned here (no keras/tensorflow in the image).
  *   outputs      act_values (2,), ptr_values (400,400)
  *   post         iaction = argmax(act) ; ipointer = unravel_index(argmax(ptr),
  *                (400,400), order='F') = (k % 400, k // 400) = (x, y)
@@ -113,18 +117,18 @@ static void maxpool2(const float *in, int H, int W, int c, float *out) {
       }
 }
 
-/* bilinear x2, half-pixel centres, edge clamp */
-static void upsample2(const float *in, int H, int W, int c, float *out) {
+/* bilinear x2, edge clamp; half-pixel centres, or (legacy) the TF1 mapping src = dst / 2 */
+static void upsample2(const float *in, int H, int W, int c, float *out, int legacy) {
   int Ho = 2 * H, Wo = 2 * W;
   for (int y = 0; y < Ho; y++) {
-    float sy = ((float)y + 0.5f) * 0.5f - 0.5f;
+    float sy = legacy ? (float)y * 0.5f : ((float)y + 0.5f) * 0.5f - 0.5f;
     float fy = floorf(sy);
     int y0 = (int)fy, y1 = y0 + 1;
     float ly = sy - fy;
     if (y0 < 0) y0 = 0;
     if (y1 > H - 1) y1 = H - 1;
     for (int x = 0; x < Wo; x++) {
-      float sx = ((float)x + 0.5f) * 0.5f - 0.5f;
+      float sx = legacy ? (float)x * 0.5f : ((float)x + 0.5f) * 0.5f - 0.5f;
       float fx = floorf(sx);
       int x0 = (int)fx, x1 = x0 + 1;
       float lx = sx - fx;
@@ -152,8 +156,8 @@ static void dense(const float *x, int nin, const float *k, const float *b, int n
 /* One forward.  ship_map / laser_map: uint8 [400][400] ([row=y][col=x]);
  * vec8: the 8-scalar head; weights: the blob above.
  * Outputs: act_values[2], heat[400*400] (may be NULL), iaction, ipointer[2]=(x,y). */
-void orc_policy_forward(const uint8_t *ship_map, const uint8_t *laser_map, const float *vec8, const float *w,
-                        float *act_values, float *heat, int32_t *iaction, int32_t *ipointer) {
+void orc_policy_forward2(const uint8_t *ship_map, const uint8_t *laser_map, const float *vec8, const float *w,
+                         float *act_values, float *heat, int32_t *iaction, int32_t *ipointer, int legacy_bilinear) {
   int32_t off[64], cnt[64];
   orc_policy_layout(off, cnt);
   const int S = 400;
@@ -182,7 +186,7 @@ void orc_policy_forward(const uint8_t *ship_map, const uint8_t *laser_map, const
   memcpy(a, ud, 625 * sizeof(float));
   H = 25;
   for (int i = 0; i < 4; i++) {
-    upsample2(a, H, H, UP_CIN[i], b);
+    upsample2(a, H, H, UP_CIN[i], b, legacy_bilinear);
     H *= 2;
     conv3x3(b, H, H, UP_CIN[i], w + off[t], w + off[t + 1], UP_COUT[i], a);
     if (i < 3) {
@@ -202,4 +206,10 @@ void orc_policy_forward(const uint8_t *ship_map, const uint8_t *laser_map, const
   if (heat) memcpy(heat, a, sizeof(float) * (size_t)S * S);
   free(a);
   free(b);
+}
+
+/* the declared default convention (half-pixel centres) */
+void orc_policy_forward(const uint8_t *ship_map, const uint8_t *laser_map, const float *vec8, const float *w,
+                        float *act_values, float *heat, int32_t *iaction, int32_t *ipointer) {
+  orc_policy_forward2(ship_map, laser_map, vec8, w, act_values, heat, iaction, ipointer, 0);
 }

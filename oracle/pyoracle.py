@@ -247,9 +247,9 @@ def policy_init(seed, trained_like=False):
     return w, {n: (int(o), shapes[n]) for n, o in zip(POLICY_TENSORS, off)}
 
 
-def policy_forward(ship_map, laser_map, vec8, weights, want_heat=True):
+def policy_forward(ship_map, laser_map, vec8, weights, want_heat=True, legacy_bilinear=False):
     L = lib()
-    L.orc_policy_forward.argtypes = [C.c_void_p] * 8
+    L.orc_policy_forward2.argtypes = [C.c_void_p] * 8 + [C.c_int]
     sm = np.ascontiguousarray(ship_map, np.uint8)
     lm = np.ascontiguousarray(laser_map, np.uint8)
     v = np.ascontiguousarray(vec8, np.float32)
@@ -258,7 +258,7 @@ def policy_forward(ship_map, laser_map, vec8, weights, want_heat=True):
     heat = np.zeros((400, 400), np.float32) if want_heat else None
     ia = np.zeros(1, np.int32)
     ip = np.zeros(2, np.int32)
-    L.orc_policy_forward(_p(sm), _p(lm), _p(v), _p(w), _p(act), _p(heat), _p(ia), _p(ip))
+    L.orc_policy_forward2(_p(sm), _p(lm), _p(v), _p(w), _p(act), _p(heat), _p(ia), _p(ip), int(bool(legacy_bilinear)))
     return act, heat, int(ia[0]), (int(ip[0]), int(ip[1]))
 
 

@@ -26,7 +26,21 @@ def _tensors(w, dtype):
     return T
 
 
-def forward(sm, lm, vec8s, w, dtype=torch.float64):
+def upsample2(u, legacy=False):
+    """UpSampling2D((2, 2), interpolation='bilinear') on NCHW.  Half-pixel centres by default; legacy = the TF1
+    resize_bilinear(align_corners=False) mapping src = dst / 2, written as an explicit gather (independent of the
+    restatement's loop): out[2k] = in[k], out[2k+1] = (in[k] + in[min(k+1, n-1)]) / 2 along each axis."""
+    if not legacy:
+        return F.interpolate(u, scale_factor=2, mode="bilinear", align_corners=False)
+    n = u.shape[-1]
+    k = torch.arange(2 * n)
+    i0, i1 = k // 2, torch.clamp(k // 2 + 1, max=n - 1)
+    w1 = ((k % 2) * 0.5).to(u.dtype)
+    u = u[..., i0, :] * (1 - w1)[:, None] + u[..., i1, :] * w1[:, None]
+    return u[..., :, i0] * (1 - w1) + u[..., :, i1] * w1
+
+
+def forward(sm, lm, vec8s, w, dtype=torch.float64, legacy_bilinear=False):
     """One arena: maps (400,400) uint8, vec8s [K][8] heads of K ships -> act [K][2], heat [K][400][400] (numpy, dtype)."""
     T = _tensors(w, dtype)
 
@@ -48,9 +62,9 @@ def forward(sm, lm, vec8s, w, dtype=torch.float64):
     act = d2 @ T["output1.kernel"] + T["output1.bias"]
     u = F.relu(d1 @ T["updense1.kernel"] + T["updense1.bias"]).reshape(-1, 1, 25, 25)
     for i in (1, 2, 3):
-        u = F.interpolate(u, scale_factor=2, mode="bilinear", align_corners=False)     # half-pixel centres
+        u = upsample2(u, legacy_bilinear)
         u = F.relu(bn(conv(u, "upconv%d" % i), "upconv%d" % i))
-    u = F.interpolate(u, scale_factor=2, mode="bilinear", align_corners=False)
+    u = upsample2(u, legacy_bilinear)
     heat = conv(u, "upconv4")[:, 0]
     return act.numpy(), heat.numpy()
 

@@ -122,6 +122,47 @@ def test_reference_variants_agree():
     b.close()
 
 
+def test_legacy_bilinear_option():
+    """OFX_OPT_BILINEAR_LEGACY: the TF1 resize_bilinear convention of UpSampling2D (src = dst / 2) - the second
+    meaning the reference's unpinned keras range admits (qlearnIA_V2.py:166-184).  Against the restatement with the
+    same switch, frame pixels included, through both frame-line kernels, pinned and unpinned; and it IS a different
+    function from the default."""
+    from ofighters_amd import DeviceBuffer, _native as nat
+    from oracle import pyoracle
+    N, M = 2, 3
+    b = _rollout(N, M, seed=17, ticks=30)
+    w, _ = pyoracle.policy_init(8, trained_like=True)
+    default = b.policy_forward_host(w, want_heat=True)
+    b.set_option(nat.OPT_BILINEAR_LEGACY, 1)
+    out = b.policy_forward_host(w, want_heat=True)
+    b.set_option(nat.OPT_FRAMES_REF, 1)
+    out_ref = b.policy_forward_host(w, want_heat=True)
+    b.set_option(nat.OPT_FRAMES_REF, 0)
+    head, _ = b.observe_head()
+    sm, lm = b.maps_host(nat.MAP_U8)
+    for g in range(N):
+        for i in range(M):
+            act, heat, ia, ip = pyoracle.policy_forward(sm[g], lm[g], head[g, i].astype(np.float32), w, legacy_bilinear=True)
+            hs = float(np.abs(heat).max())
+            for o in (out, out_ref):
+                np.testing.assert_allclose(o["act"][g, i], act, rtol=0, atol=TOL * max(1.0, float(np.abs(act).max())))
+                np.testing.assert_allclose(o["heat"][g, i], heat, rtol=0, atol=TOL * hs)
+                gx, gy = o["ipointer"][g, i]
+                assert heat[gy, gx] >= heat.max() - 2 * TOL * hs
+            assert np.abs(default["heat"][g, i] - heat).max() > 1e-3 * hs
+    # a pinned blob is re-prepared when the convention changes
+    S = N * M
+    dw = DeviceBuffer(w.nbytes).upload(w)
+    dp = DeviceBuffer(8 * S)
+    b.policy_pin_weights(dw.ptr)
+    b.policy_forward(dw.ptr, None, None, None, dp.ptr, None); b.sync()
+    assert np.array_equal(dp.download(np.int32, (N, M, 2)), out["ipointer"])
+    b.set_option(nat.OPT_BILINEAR_LEGACY, 0)
+    b.policy_forward(dw.ptr, None, None, None, dp.ptr, None); b.sync()
+    assert np.array_equal(dp.download(np.int32, (N, M, 2)), default["ipointer"])
+    b.close()
+
+
 def test_pinned_weights():
     """ofx_policy_pin_weights: the prepared weights (BatchNorm folded, phase weights, tables) are built once and reused
     by every forward on the same blob; a pinned forward is bit-identical to an unpinned one, and pinning again picks

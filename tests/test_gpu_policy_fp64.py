@@ -41,8 +41,10 @@ def _report(tag, rec):
     print(tag, rec)
 
 
-@pytest.mark.parametrize("trained", [False, True])
-def test_small_batch_against_fp64(trained):
+@pytest.mark.parametrize("trained,legacy", [(False, False), (True, False), (True, True)])
+def test_small_batch_against_fp64(trained, legacy):
+    """legacy: the TF1 bilinear convention (OFX_OPT_BILINEAR_LEGACY) - other phase weights, frame lines and corner
+    cells, same error bounds."""
     import torch
     from ofighters_amd import _native as nat
     from oracle import pyoracle
@@ -51,6 +53,7 @@ def test_small_batch_against_fp64(trained):
     N, M = 4, 4
     b = _rollout(N, M, seed=31, ticks=40)
     w, _ = pyoracle.policy_init(5, trained_like=trained)
+    b.set_option(nat.OPT_BILINEAR_LEGACY, int(legacy))
     out = b.policy_forward_host(w, want_heat=True)
     head, _ = b.observe_head()
     sm, lm = b.maps_host(nat.MAP_U8)
@@ -58,10 +61,10 @@ def test_small_batch_against_fp64(trained):
     worst_orc = np.zeros(3)
     same = 0
     for g in range(N):
-        a64, h64 = R.forward(sm[g], lm[g], head[g].astype(np.float32), w)
+        a64, h64 = R.forward(sm[g], lm[g], head[g].astype(np.float32), w, legacy_bilinear=legacy)
         for i in range(M):
             worst = np.maximum(worst, R.errors(out["act"][g, i], out["heat"][g, i], a64[i], h64[i]))
-            act, heat, ia, ip = pyoracle.policy_forward(sm[g], lm[g], head[g, i].astype(np.float32), w)
+            act, heat, ia, ip = pyoracle.policy_forward(sm[g], lm[g], head[g, i].astype(np.float32), w, legacy_bilinear=legacy)
             worst_orc = np.maximum(worst_orc, R.errors(act, heat, a64[i], h64[i]))
             k = int(np.argmax(h64[i]))
             gx, gy = out["ipointer"][g, i]
@@ -70,7 +73,7 @@ def test_small_batch_against_fp64(trained):
             assert h64[i][gy, gx] >= h64[i].max() - 2 * TOL_HEAT * float(np.abs(h64[i]).max())
             if abs(float(a64[i][0] - a64[i][1])) > 2 * TOL_ACT * max(1.0, float(np.abs(a64[i]).max())):
                 assert out["iaction"][g, i] == int(np.argmax(a64[i]))
-    _report("small_trained" if trained else "small_init",
+    _report(("small_trained" if trained else "small_init") + ("_legacy_bilinear" if legacy else ""),
             dict(hip=list(map(float, worst)), oracle=list(map(float, worst_orc)), argmax_same=int(same), ships=N * M))
     assert worst[0] <= TOL_ACT and worst[1] <= TOL_HEAT and worst[2] <= TOL_FRAME, worst
     assert worst_orc[0] <= TOL_ACT and worst_orc[1] <= TOL_HEAT and worst_orc[2] <= TOL_FRAME, worst_orc

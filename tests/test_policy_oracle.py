@@ -9,7 +9,8 @@ import torch.nn.functional as F
 from oracle import pyoracle
 
 
-def torch_forward(sm, lm, vec8, w, lay):
+def torch_forward(sm, lm, vec8, w, lay, legacy=False):
+    from tests.policy_ref64 import upsample2
     def T(name):
         o, shp = lay[name]
         return torch.from_numpy(w[o:o + int(np.prod(shp))].reshape(shp).copy())
@@ -31,9 +32,9 @@ def torch_forward(sm, lm, vec8, w, lay):
     act = d2 @ T("output1.kernel") + T("output1.bias")
     u = F.relu(d1 @ T("updense1.kernel") + T("updense1.bias")).reshape(1, 1, 25, 25)
     for i in (1, 2, 3):
-        u = F.interpolate(u, scale_factor=2, mode="bilinear", align_corners=False)
+        u = upsample2(u, legacy)
         u = F.relu(bn(conv(u, "upconv%d" % i), "upconv%d" % i))
-    u = F.interpolate(u, scale_factor=2, mode="bilinear", align_corners=False)
+    u = upsample2(u, legacy)
     heat = conv(u, "upconv4")[0, 0]
     return act[0].numpy(), heat.numpy()
 
@@ -62,12 +63,14 @@ def test_layout():
 
 
 def test_oracle_matches_torch():
+    """Both bilinear conventions the reference's version range admits (policy_oracle.c header): half-pixel centres
+    against torch's interpolate, the TF1 legacy mapping against an explicit torch gather."""
     torch.set_num_threads(4)
-    for seed, trained in ((0, False), (1, True)):
+    for seed, trained, legacy in ((0, False, False), (1, True, False), (1, True, True)):
         w, lay = pyoracle.policy_init(seed, trained_like=trained)
         sm, lm, vec8 = scene(seed)
-        act, heat, ia, ip = pyoracle.policy_forward(sm, lm, vec8, w)
-        tact, theat = torch_forward(sm, lm, vec8, w, lay)
+        act, heat, ia, ip = pyoracle.policy_forward(sm, lm, vec8, w, legacy_bilinear=legacy)
+        tact, theat = torch_forward(sm, lm, vec8, w, lay, legacy)
         np.testing.assert_allclose(act, tact, rtol=0, atol=2e-5 * max(1.0, float(np.abs(tact).max())))
         np.testing.assert_allclose(heat, theat, rtol=0, atol=2e-5 * float(np.abs(theat).max()))
         assert ia == int(np.argmax(act))
@@ -76,6 +79,20 @@ def test_oracle_matches_torch():
         assert ip == tuple(int(v) for v in np.unravel_index(k, (400, 400), order="F"))
         # the torch heat-map agrees on the arg-max up to fp32 noise
         assert theat[ip[1], ip[0]] >= theat.max() - 2e-5 * float(np.abs(theat).max())
+        if legacy:   # the two conventions are different functions, not rounding variants of one
+            other = pyoracle.policy_forward(sm, lm, vec8, w)[1]
+            assert np.abs(other - heat).max() > 1e-3 * float(np.abs(heat).max())
+
+
+def test_legacy_upsample_definition():
+    """The legacy mapping on a ramp: even outputs copy, odd outputs average with the next sample, the last one clamps
+    (resize_bilinear without half-pixel centres: src = dst * in/out, lower = floor, upper = min(lower + 1, n - 1))."""
+    from tests.policy_ref64 import upsample2
+    u = torch.arange(5, dtype=torch.float64).reshape(1, 1, 1, 5).expand(1, 1, 5, 5).contiguous()
+    o = upsample2(u, True)[0, 0, 0].numpy()
+    assert o.tolist() == [0, 0.5, 1, 1.5, 2, 2.5, 3, 3.5, 4, 4]
+    h = F.interpolate(u, scale_factor=2, mode="bilinear", align_corners=False)[0, 0, 0].numpy()
+    assert h.tolist() == [0, 0.25, 0.75, 1.25, 1.75, 2.25, 2.75, 3.25, 3.75, 4]
 
 
 def test_oracle_error_against_float64():
@@ -85,11 +102,12 @@ def test_oracle_error_against_float64():
     from ofighters_amd.agents.policy_weights import synthetic
     from tests import policy_ref64 as R
     torch.set_num_threads(4)
-    for w in (pyoracle.policy_init(3)[0], pyoracle.policy_init(3, trained_like=True)[0], synthetic(0x0F160002)):
+    for w, legacy in ((pyoracle.policy_init(3)[0], False), (pyoracle.policy_init(3, trained_like=True)[0], False),
+                      (synthetic(0x0F160002), False), (synthetic(0x0F160002), True)):
         for seed in range(2):
             sm, lm, vec8 = scene(seed)
-            act, heat, ia, ip = pyoracle.policy_forward(sm, lm, vec8, w)
-            a64, h64 = R.forward(sm, lm, vec8[None], w)
+            act, heat, ia, ip = pyoracle.policy_forward(sm, lm, vec8, w, legacy_bilinear=legacy)
+            a64, h64 = R.forward(sm, lm, vec8[None], w, legacy_bilinear=legacy)
             e = R.errors(act, heat, a64[0], h64[0])
             assert e[0] <= 1.5e-5 and e[1] <= 8e-6 and e[2] <= 8e-6, e
             k = int(np.argmax(h64[0]))

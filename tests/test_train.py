@@ -10,9 +10,11 @@ from oracle import pyoracle
 pytestmark = pytest.mark.gpu
 
 
-def _torch_reference(w, shapes, x0, vec8, iaction, px, py, y_act, y_ptr):
+def _torch_reference(w, shapes, x0, vec8, iaction, px, py, y_act, y_ptr, legacy=False, dense=None):
+    """dense = (t1 [n][2], t2 [n][400][400]): whole target tensors (ofx_dqn_fit_reference) instead of one error per head."""
     import torch
     import torch.nn.functional as F
+    from tests.policy_ref64 import upsample2
     torch.set_num_threads(8)
     P = {}
     for name, (o, shp) in shapes.items():
@@ -22,7 +24,7 @@ def _torch_reference(w, shapes, x0, vec8, iaction, px, py, y_act, y_ptr):
 
     def block(x, name, up=False):
         if up:
-            x = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+            x = upsample2(x, legacy)
         k = P[name + ".kernel"].permute(3, 2, 0, 1)           # HWIO -> OIHW
         z = F.conv2d(x, k, P[name + ".bias"], padding=1)
         stats[name] = (z.mean(dim=(0, 2, 3)).detach(), z.var(dim=(0, 2, 3), unbiased=False).detach())
@@ -39,11 +41,15 @@ def _torch_reference(w, shapes, x0, vec8, iaction, px, py, y_act, y_ptr):
     u = torch.relu(d1 @ P["updense1.kernel"] + P["updense1.bias"]).reshape(n, 1, 25, 25)
     for j in (1, 2, 3):
         u = block(u, "upconv%d" % j, up=True)
-    u = F.interpolate(u, scale_factor=2, mode="bilinear", align_corners=False)
+    u = upsample2(u, legacy)
     o2 = F.conv2d(u, P["upconv4.kernel"].permute(3, 2, 0, 1), P["upconv4.bias"], padding=1)
     idx = torch.arange(n)
-    e1 = o1[idx, torch.tensor(iaction)] - torch.tensor(y_act, dtype=torch.float64)
-    e2 = o2[idx, 0, torch.tensor(py), torch.tensor(px)] - torch.tensor(y_ptr, dtype=torch.float64)
+    if dense is not None:
+        e1 = o1 - torch.tensor(dense[0], dtype=torch.float64)
+        e2 = o2[:, 0] - torch.tensor(dense[1], dtype=torch.float64)
+    else:
+        e1 = o1[idx, torch.tensor(iaction)] - torch.tensor(y_act, dtype=torch.float64)
+        e2 = o2[idx, 0, torch.tensor(py), torch.tensor(px)] - torch.tensor(y_ptr, dtype=torch.float64)
     l1, l2 = (e1 ** 2).sum() / (2 * n), (e2 ** 2).sum() / (160000 * n)
     (l1 + l2).backward()
     g = np.zeros_like(w, dtype=np.float64)
@@ -53,10 +59,33 @@ def _torch_reference(w, shapes, x0, vec8, iaction, px, py, y_act, y_ptr):
     return float(l1.detach()), float(l2.detach()), g, stats
 
 
-def test_dqn_fit_vs_torch_autograd():
-    from ofighters_amd import ArenaBatch, DeviceBuffer
+def _compare_gradients(shapes, rg, g, loose=()):
+    """gradients tensor by tensor: fp32 kernels vs the float64 checker
+    (the bias of a convolution that feeds a BatchNorm has an exactly zero gradient: only rounding noise is left, so
+    the absolute part of the tolerance is tied to the layer's kernel gradient)"""
+    report = []
+    for name, (o, shp) in shapes.items():
+        c = int(np.prod(shp))
+        layer, kind = name.split(".")
+        if kind in ("mean", "var"):
+            continue
+        ref, got = rg[o:o + c], g[o:o + c]
+        ko, kshp = shapes[layer + ".kernel"]
+        kscale = float(np.abs(rg[ko:ko + int(np.prod(kshp))]).max())
+        scale, err = float(np.abs(ref).max()), float(np.abs(got - ref).max())
+        rel = 3e-3 if layer in loose else 1e-4
+        report.append((name, scale, err, err <= rel * scale + 5e-5 * kscale))
+    print("\n".join("%-18s scale %.3e  err %.3e  %s" % r for r in report))
+    assert all(r[3] for r in report), [r for r in report if not r[3]]
+
+
+@pytest.mark.parametrize("legacy", [False, True])
+def test_dqn_fit_vs_torch_autograd(legacy):
+    """legacy: OFX_OPT_BILINEAR_LEGACY - the fit's up-sampling (forward and backward) follows the same switch."""
+    from ofighters_amd import ArenaBatch, DeviceBuffer, _native as nat
     N, M, seed, batch, lr = 2, 4, 0x0F160001, 2, 1e-4
     b = ArenaBatch(N, M)
+    b.set_option(nat.OPT_BILINEAR_LEGACY, int(legacy))
     b.replay_create(16, 0)
     b.spawn_random(seed)
     w, shapes = pyoracle.policy_init(9, trained_like=True)
@@ -89,24 +118,10 @@ def test_dqn_fit_vs_torch_autograd():
     bits = bp_d.download(np.uint32, (n, 2, 5000))
     x0 = np.unpackbits(bits.view(np.uint8), bitorder="little").reshape(n, 2, 400, 400).astype(np.float64)
     rl1, rl2, rg, stats = _torch_reference(w.astype(np.float64), shapes, x0, rows["head_prev"], rows["iaction"].astype(np.int64),
-                                           rows["px"].astype(np.int64), rows["py"].astype(np.int64), y_act, y_ptr)
+                                           rows["px"].astype(np.int64), rows["py"].astype(np.int64), y_act, y_ptr,
+                                           legacy=legacy)
     assert abs(l1 - rl1) <= 1e-4 * max(1.0, abs(rl1)) and abs(l2 - rl2) <= 1e-4 * max(1e-9, abs(rl2)) + 1e-12
-    # gradients tensor by tensor: fp32 kernels vs the float64 checker
-    # (the bias of a convolution that feeds a BatchNorm has an exactly zero gradient: only rounding noise is left, so
-    # the absolute part of the tolerance is tied to the layer's kernel gradient)
-    report = []
-    for name, (o, shp) in shapes.items():
-        c = int(np.prod(shp))
-        layer, kind = name.split(".")
-        if kind in ("mean", "var"):
-            continue
-        ref, got = rg[o:o + c], g[o:o + c]
-        ko, kshp = shapes[layer + ".kernel"]
-        kscale = float(np.abs(rg[ko:ko + int(np.prod(kshp))]).max())
-        scale, err = float(np.abs(ref).max()), float(np.abs(got - ref).max())
-        report.append((name, scale, err, err <= 1e-4 * scale + 5e-5 * kscale))
-    print("\n".join("%-18s scale %.3e  err %.3e  %s" % r for r in report))
-    assert all(r[3] for r in report), [r for r in report if not r[3]]
+    _compare_gradients(shapes, rg, g)
     # Adam step 1 from the device's own gradient, and the moving statistics
     lr_t = lr * np.sqrt(1 - 0.999) / (1 - 0.9)
     for name, (o, shp) in shapes.items():
@@ -120,6 +135,63 @@ def test_dqn_fit_vs_torch_autograd():
             gi = g[o:o + c]
             want = w[o:o + c] - lr_t * (0.1 * gi) / (np.sqrt(0.001 * gi * gi) + 1e-7)
             np.testing.assert_allclose(w_new[o:o + c], want, rtol=0, atol=2e-7 + 1e-6 * np.abs(w[o:o + c]).max())
+    b.close()
+
+
+def test_dqn_fit_reference_quirks():
+    """ofx_dqn_fit_reference = Trainer.replay as written (qlearnIA_V2.py:251-285): targets are float64 predictions of
+    `state` (tests/policy_ref64.py) with target[iaction] and ptr_target[x][y] (row x, column y - the quirk) replaced by
+    reward + gamma * max(prediction(next_state)) * (not done); the fit runs in training mode on NEXT_state's maps and
+    head; dense mse on both outputs.  Checked against torch autograd in float64, like the textbook step above."""
+    from ofighters_amd import ArenaBatch, DeviceBuffer
+    from tests import policy_ref64 as R
+    N, M, seed, batch, lr, gamma = 2, 4, 0x0F160001, 2, 1e-4, 0.9
+    b = ArenaBatch(N, M)
+    b.replay_create(16, 0)
+    b.spawn_random(seed)
+    w, shapes = pyoracle.policy_init(9, trained_like=True)
+    mask = np.zeros((N, M), np.uint8)
+    mask[:, [1, 3]] = 1
+    mask_d = DeviceBuffer(mask.nbytes).upload(mask)
+    ia_d, ip_d = DeviceBuffer(4 * N * M), DeviceBuffer(8 * N * M)
+    for t in range(12):
+        b.bot_actions(["random"] * M, seed, tick=t)
+        b.policy_explore(1.0, seed, tick=t, collecting=True, ship_mask_ptr=mask_d.ptr, iaction_ptr=ia_d.ptr, ipointer_ptr=ip_d.ptr)
+        b.policy_actions(out_ptr=b._actions.ptr, ship_mask_ptr=mask_d.ptr, iaction_ptr=ia_d.ptr, ipointer_ptr=ip_d.ptr)
+        b.replay_capture(t, mask_d.ptr, ia_d.ptr, ip_d.ptr)
+        b.step(actions_ptr=b._actions.ptr)
+    slot, _ = b.replay_sample(5, 0, batch)
+    rows_d, bp_d, bn_d = b.replay_gather_device(slot, batch)
+    n = N * batch
+    rows = rows_d.download(b.TRANSITION_DTYPE, (n,))
+    assert (rows["ship"] >= 0).all()
+    assert (rows["px"] != rows["py"]).any()                  # the transposed index is a different cell
+    w_d = DeviceBuffer(w.nbytes).upload(w)
+    zeros = np.zeros_like(w)
+    m_d, v_d, g_d = DeviceBuffer(w.nbytes).upload(zeros), DeviceBuffer(w.nbytes).upload(zeros), DeviceBuffer(w.nbytes)
+    l1, l2 = b.dqn_fit_reference(w_d, m_d, v_d, 1, lr, n, rows_d.ptr, bp_d.ptr, bn_d.ptr, gamma, g_d)
+    g = g_d.download(np.float32, w.shape).astype(np.float64)
+
+    def maps(buf):
+        bits = buf.download(np.uint32, (n, 2, 5000))
+        return np.unpackbits(bits.view(np.uint8), bitorder="little").reshape(n, 2, 400, 400)
+
+    xp, xn = maps(bp_d), maps(bn_d)
+    t1, t2 = np.zeros((n, 2)), np.zeros((n, 400, 400))
+    for s in range(n):
+        a_prev, h_prev = R.forward(xp[s, 0], xp[s, 1], rows["head_prev"][s][None], w)
+        a_next, h_next = R.forward(xn[s, 0], xn[s, 1], rows["head_next"][s][None], w)
+        t1[s], t2[s] = a_prev[0], h_prev[0]
+        live = 0.0 if rows["done"][s] else 1.0
+        t1[s, int(rows["iaction"][s] != 0)] = rows["reward"][s] + gamma * a_next[0].max() * live
+        t2[s, rows["px"][s], rows["py"][s]] = rows["reward"][s] + gamma * h_next[0].max() * live     # [x][y]
+    rl1, rl2, rg, _ = _torch_reference(w.astype(np.float64), shapes, xn.astype(np.float64), rows["head_next"], None, None,
+                                       None, None, None, dense=(t1, t2))
+    assert abs(l1 - rl1) <= 2e-4 * max(1.0, abs(rl1)) and abs(l2 - rl2) <= 2e-4 * max(1e-9, abs(rl2)) + 1e-12, (l1, rl1, l2, rl2)
+    # with a dense error field d(u0) is, per element, a sum of ~10^5 mixed-sign terms that BatchNorm's backward makes
+    # cancel (sum dz = 0 per channel): the fp32 kernels' rounding shows at 1.25e-3 of updense1's gradient scale (measured),
+    # every other tensor stays inside the 1e-4 of the textbook step
+    _compare_gradients(shapes, rg, g, loose=("updense1",))
     b.close()
 
 
@@ -158,6 +230,11 @@ def test_device_trainer_replay_reduces_the_td_error():
     losses = [b.dqn_fit(tr.weights, tr.adam_m, tr.adam_v, tr.fit_steps + 1 + k, 1e-3, n, rows.ptr, bp.ptr, ya.ptr, yp.ptr)
               for k in range(12)]
     assert losses[-1][0] < 0.7 * losses[0][0], losses
+    # the reference's step as written, through the same DeviceTrainer.replay
+    tr.reference_quirks = True
+    steps = tr.fit_steps
+    quirky = tr.replay()
+    assert np.isfinite(quirky).all() and tr.fit_steps == steps + 1 and np.isfinite(tr.weights_host()).all()
     b.close()
 
 
