@@ -18,11 +18,15 @@ struct HeadParams2 {
   float *u3fr;                  // [S][4][200][8] exact frame lines of uprelu3
   float *c4;                    // [S][4][400]   zero-padding corrections of the heat-map frame pixels
   const uint8_t *mask;          // [S] or null
+  int32_t *live;                // with a mask: scratch [1 + S], filled here with the count and the ordered list of the
+                                // selected ships - workgroup i works on live[1 + i], so the live workgroups are the
+                                // FIRST ones of the grid whatever the mask's pattern (spread over XCDs and CUs)
   unsigned long long *best;     // [S] packed (ordered value << 32) | ~index, zeroed by the caller
   float *heat;                  // [S][400][400] or null
   const int32_t *probe;         // [S][2] (x, y) or null
   float *ptr_probe;             // [S] heat-map value at the probe
-  int frames_ref; int legacy;               // frame lines through the from-the-definition kernel (OFX_OPT_FRAMES_REF)
+  int frames_ref;               // frame lines through the from-the-definition kernel (OFX_OPT_FRAMES_REF)
+  int legacy;                   // TF1 legacy bilinear instead of half-pixel centres (OFX_OPT_BILINEAR_LEGACY)
   int event_base;               // >= 0: ofx_event_record(event_base / event_base + 1) around k_head_stream
   int ablate;                   // diagnostics (OFX_HEAD_HOOKS builds only)
   unsigned long long *dbg;      // diagnostics: [blocks][8 waves][6] s_memtime sums

@@ -45,6 +45,38 @@ __device__ __forceinline__ unsigned hd_ordered_f32(float v) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Ship mask -> ordered list.  A masked launch used to give every ship a workgroup and let the unselected ones exit:
+// with a regular mask (the reference's own line-up has ONE policy ship per arena, lib/ofighters.py:53) the live
+// workgroups then fall on a fraction of the CUs - the dispatcher hands workgroups out round-robin - and the kernel
+// ran at half speed (3.8 ms for 4096 ships against 15.5 ms for 32768).  Work item i of a masked launch is the i-th
+// selected ship instead.  One workgroup; live[0] = count, live[1 + i] = ship.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_head_compact(int S, const uint8_t *mask, int32_t *live) {
+  __shared__ int cnt[1024];
+  const int t = threadIdx.x, per = (S + 1023) / 1024, lo = min(t * per, S), hi = min(lo + per, S);
+  int c = 0;
+  for (int s = lo; s < hi; s++) c += mask[s] != 0;
+  cnt[t] = c;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {  // inclusive scan
+    const int v = t >= d ? cnt[t - d] : 0;
+    __syncthreads();
+    cnt[t] += v;
+    __syncthreads();
+  }
+  int o = cnt[t] - c;
+  for (int s = lo; s < hi; s++)
+    if (mask[s]) live[1 + o++] = s;
+  if (t == 1023) live[0] = cnt[1023];
+}
+
+// ship of work item i (block-uniform), -1 when there is none
+__device__ __forceinline__ int hd_ship(const HeadParams2 &p, int i) {
+  if (p.live) return i < p.live[0] ? p.live[1 + i] : -1;
+  return i < p.S ? i : -1;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // k_head_frames: exact frame lines.  One workgroup per ship.
 // ---------------------------------------------------------------------------------------------------------------
 
@@ -84,8 +116,9 @@ constexpr int HF_TOTAL = HF_U3L + 6400;        // 17048 floats = 68 KB
 // for the agreement test of the phase-form version below (OFX_OPT_FRAMES_REF).
 __global__ __launch_bounds__(HF_THREADS) void k_head_frames_ref(HeadParams2 p) {
   __shared__ __align__(16) float sm[HF_TOTAL];
-  const int s = blockIdx.x, tid = threadIdx.x;
-  if (p.mask && !p.mask[s]) return;  // block-uniform
+  const int tid = threadIdx.x;
+  const int s = hd_ship(p, (int)blockIdx.x);
+  if (s < 0) return;  // block-uniform
   float *l1 = sm + HF_L1, *U1r = sm + HF_U1R, *U1c = sm + HF_U1C, *U2r = sm + HF_U2R, *U2c = sm + HF_U2C;
   float *u2rb = sm + HF_B2R, *u2cb = sm + HF_B2C, *u3l = sm + HF_U3L;
 
@@ -280,10 +313,9 @@ __global__ __launch_bounds__(HG_THREADS) void k_head_frames(HeadParams2 p) {
   __shared__ float efr_s[192];
   // the ship of a block rotates inside its group of 8 (blocks go round-robin over the 8 XCDs: a regular ship mask
   // must not leave all the live workgroups on one of them)
-  const int s = min((int)((blockIdx.x & ~7u) | ((blockIdx.x + (blockIdx.x >> 3)) & 7u)), p.S - 1);
+  const int s = hd_ship(p, (int)((blockIdx.x & ~7u) | ((blockIdx.x + (blockIdx.x >> 3)) & 7u)));
   const int tid = threadIdx.x, lane = tid & 63;
-  if ((int)((blockIdx.x & ~7u) | ((blockIdx.x + (blockIdx.x >> 3)) & 7u)) >= p.S) return;
-  if (p.mask && !p.mask[s]) return;  // block-uniform
+  if (s < 0) return;  // block-uniform
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n16 = lane & 15, kq = lane >> 4;
   float *l1p = sm + HG_L1, *u2rb = sm + HG_RB, *u2cb = sm + HG_CB, *u3l = sm + HG_U3;
@@ -500,9 +532,8 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
   // rotates with the group of 16 blocks, so that a regular ship mask (say the first ship of every arena: the
   // reference's own line-up has one policy ship) does not put all the live workgroups on one XCD
   const int blk = blockIdx.x;
-  const int s = (blk >> 4) * 8 + ((blk + (blk >> 4)) & 7), side = (blk >> 3) & 1;
-  if (s >= p.S) return;
-  if (p.mask && !p.mask[s]) return;  // block-uniform
+  const int s = hd_ship(p, (blk >> 4) * 8 + ((blk + (blk >> 4)) & 7)), side = (blk >> 3) & 1;
+  if (s < 0) return;  // block-uniform
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   for (int g = tid; g < 4 * HS_NTILES; g += HS_THREADS) {
@@ -937,6 +968,12 @@ int ofx_launch_head(ofx_handle *h, const HeadParams2 &p0) {
     if (++dbg_calls == 20) p.dbg = dbg;
   }
 #endif
+  if (p.mask) {
+    if (!p.live) { ofx_set_error("ofx_launch_head: a mask needs the live-list scratch"); return OFX_ERR_STATE; }
+    hipLaunchKernelGGL(k_head_compact, dim3(1), dim3(1024), 0, h->stream, p.S, p.mask, p.live);
+  } else {
+    p.live = nullptr;
+  }
   if (p.frames_ref) hipLaunchKernelGGL(k_head_frames_ref, dim3((unsigned)p.S), dim3(HF_THREADS), 0, h->stream, p);
   else hipLaunchKernelGGL(k_head_frames, dim3((unsigned)((p.S + 7) & ~7)), dim3(HG_THREADS), 0, h->stream, p);
   OFX_HIP(hipGetLastError());

@@ -848,7 +848,7 @@ __global__ void k_policy_actions(int S, const ofx_state st, const int32_t *iacti
 struct PolicyWs {
   float *p1, *p2, *p3, *p4, *g1, *d1, *u0, *up1, *u2fr, *u3fr, *c4;
   unsigned long long *best;
-  int32_t *iaction, *ipointer;
+  int32_t *iaction, *ipointer, *live;
 };
 
 static size_t al(size_t b) { return (b + 255) & ~(size_t)255; }
@@ -862,7 +862,8 @@ static int policy_workspace(ofx_handle *h, PolicyWs *ws, size_t N, size_t S) {
   const size_t sz[] = {al(4ull * N * 8 * 200 * 200), al(4ull * N * 8 * 100 * 100), al(4ull * N * 8 * 50 * 50),
                        al(4ull * N * 5000),          al(4ull * N * 100 * kDense1Chunks), al(4ull * S * 100),
                        al(4ull * S * 625),           al(4ull * S * 2 * 50 * 50),   al(f2), al(f3), al(f4),
-                       al(8ull * S),                 al(4ull * S),                 al(8ull * S)};
+                       al(8ull * S),                 al(4ull * S),                 al(8ull * S),
+                       al(4ull * (S + 1))};
   size_t total = 0;
   for (size_t b : sz) total += b;
   int rc = ofx_ensure_scratch(h, total);
@@ -870,8 +871,9 @@ static int policy_workspace(ofx_handle *h, PolicyWs *ws, size_t N, size_t S) {
   char *base = (char *)h->scratch;
   void **dst[] = {(void **)&ws->p1,   (void **)&ws->p2,   (void **)&ws->p3,      (void **)&ws->p4,      (void **)&ws->g1,
                   (void **)&ws->d1,   (void **)&ws->u0,   (void **)&ws->up1,     (void **)&ws->u2fr,    (void **)&ws->u3fr,
-                  (void **)&ws->c4,   (void **)&ws->best, (void **)&ws->iaction, (void **)&ws->ipointer};
-  for (int i = 0; i < 14; i++) { *dst[i] = base; base += sz[i]; }
+                  (void **)&ws->c4,   (void **)&ws->best, (void **)&ws->iaction, (void **)&ws->ipointer,
+                  (void **)&ws->live};
+  for (size_t i = 0; i < sizeof(sz) / sizeof(sz[0]); i++) { *dst[i] = base; base += sz[i]; }
   return OFX_OK;
 }
 
@@ -1046,7 +1048,7 @@ static int policy_forward_impl(ofx_handle *h, const float *weights, int N, int M
   hp2.w2fr = prep + L.w2fr; hp2.w3fr = prep + L.w3fr; hp2.efr = prep + L.efr;
   hp2.u2fr = ws.u2fr; hp2.u3fr = ws.u3fr; hp2.c4 = ws.c4;
   hp2.frames_ref = h->opt_frames_ref; hp2.legacy = h->opt_bilinear_legacy;
-  hp2.mask = ship_mask; hp2.best = ws.best; hp2.heat = heatmap; hp2.probe = probe; hp2.ptr_probe = probe ? ptr_probe : nullptr;
+  hp2.mask = ship_mask; hp2.live = ws.live; hp2.best = ws.best; hp2.heat = heatmap; hp2.probe = probe; hp2.ptr_probe = probe ? ptr_probe : nullptr;
   const int pb = h->prof_base;  // ofx_policy_profile: events around the dominant kernel, until the ring is full
   hp2.event_base = pb;
   if ((rc = ofx_launch_head(h, hp2))) return rc;
