@@ -274,6 +274,7 @@ struct ConvParams {
   int H, W;                        // conv domain (input after any upsampling) = conv output size
   int tiles_x, tiles;              // tiles per row / per image
   int legacy;                      // MODE 2: TF1 legacy source mapping (src = dst / 2) instead of half-pixel centres
+  int images;                      // k_convm: number of images (the grid is padded to a multiple of 8 of them)
 };
 
 // MODE: 0 planar f32 input, 1 two 1-bit maps, 2 planar f32 input upsampled x2 (bilinear, half-pixel or legacy)
@@ -422,8 +423,13 @@ __global__ __launch_bounds__(256) void k_convm(ConvParams p) {
   constexpr bool VEC = MODE == 0 && !OUT_HWC;                // rows of W floats are 16-byte aligned (W % 4 == 0)
   __shared__ __align__(16) float tile[CIN * PLS];
   const unsigned bid = blockIdx.x;
-  const int first = (int)bid * TPW;                          // p.tiles % TPW == 0: all tiles of a workgroup share the image
-  const int img = first / p.tiles, t_first = first - img * p.tiles;
+  // XCD-aware order: workgroups go round-robin over the 8 XCDs (each with its own L2), so workgroup b works on image
+  // 8 (b / 8 / wpi) + b % 8: the tiles of one image run back to back on ONE XCD and the halo rows a tile shares with
+  // its vertical neighbour come out of that L2 (conv2: FETCH_SIZE 10.6 -> 5.1 GB for a 5.24 GB input; same time - the
+  // kernel is bound by its compute phase, 2.45 ms with the staging ablated, 1.19 ms with only the staging)
+  const int wpi = p.tiles / TPW, j = (int)(bid >> 3);        // p.tiles % TPW == 0: all tiles of a workgroup share the image
+  const int img = (j / wpi) * 8 + (int)(bid & 7u), t_first = (j % wpi) * TPW;
+  if (img >= p.images) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = p.H, W = p.W;
@@ -585,7 +591,8 @@ static int launch_convm(ofx_handle *h, ConvParams p, int images, int H) {
   p.tiles_x = (H + 16 * NG - 1) / (16 * NG);
   p.tiles = p.tiles_x * (H / TH);
   if (p.tiles % TPW) { ofx_set_error("launch_convm: %d tiles per image not divisible by %d", p.tiles, TPW); return OFX_ERR_INVALID; }
-  hipLaunchKernelGGL((k_convm<CIN, TH, NG, MODE, OUT_HWC, TPW>), dim3((unsigned)(images * (p.tiles / TPW))), dim3(256), 0,
+  p.images = images;
+  hipLaunchKernelGGL((k_convm<CIN, TH, NG, MODE, OUT_HWC, TPW>), dim3((unsigned)((images + 7) / 8 * 8 * (p.tiles / TPW))), dim3(256), 0,
                      h->stream, p);
   OFX_HIP(hipGetLastError());
   return OFX_OK;
