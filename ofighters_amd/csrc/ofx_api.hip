@@ -143,6 +143,8 @@ extern "C" int ofx_create(const ofx_config *cfg, ofx_handle **out) {
   A(overflow, 1) A(episode_sums, (size_t)cfg->n_ships + 1)
 #undef A
   if ((rc = dev_alloc_zero(&h->bot_behaviours, (size_t)cfg->n_ships))) { ofx_destroy(h); return rc; }
+  h->n_cus = 256;  // MI355X; read from the device below
+  { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && v > 0) h->n_cus = v; }
   hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { ofx_set_error("hipStreamCreate: %s", hipGetErrorString(e)); ofx_destroy(h); return OFX_ERR_HIP; }
   h->own_stream = true;

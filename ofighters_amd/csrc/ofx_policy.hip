@@ -682,6 +682,199 @@ __global__ __launch_bounds__(256) void k_conv1_lut(ConvParams p, const float *lu
   }
 }
 
+// ---- conv1 -> conv2 fused: the 5.2 GB pooled conv1 activation never exists -----------------------------------------
+// One 1024-thread workgroup walks ONE image top to bottom in 20 steps of F12_TH = 10 conv2 rows.  Per step:
+//   phase A (all threads, VALU + LDS): the table form of conv1 (see k_conv1_lut) for the 10 NEW rows of p1 = pool(relu(
+//            bn(conv1))) - a thread owns two adjacent p1 pixels, 1000 of the 1024 threads busy - written straight into
+//            the planar LDS tile the GEMM reads (rows R0 - 1 .. R0 + 10 of p1, zero outside the image);
+//   phase B (MFMA): conv2 as k_convm's banded GEMM on that tile, M-tiles of 16 pixels enumerated FLAT over the 5 row
+//            pairs x 200 columns (62.5 M-tiles: no masked columns), 4 per wave in two chain pairs; the global loads of
+//            the next step's bit rows are in flight meanwhile;
+//            (the step's last two p1 rows are also kept aside: they are the first two tile rows of the next step).
+// f32 MFMA and VALU share the SIMD's issue port, so separating the phases in time costs nothing as long as each phase
+// has its four waves per SIMD busy; one workgroup per CU (120 KB of LDS).  Output = k_convm's: planar [img][8][100][100].
+constexpr int F12_TH = 10, F12_LS = 216, F12_ROWS = F12_TH + 2;
+constexpr int F12_PLS = (F12_ROWS * F12_LS + 63) / 64 * 64 + 16;  // plane stride = 16 mod 64, as k_convm
+constexpr int F12_WR = 14, F12_BR = 2 * (F12_TH + 1) + 2;         // words per staged bit row; bit rows of the first step
+constexpr int F12_THREADS = 1024;
+static_assert(F12_PLS % 64 == 16 && F12_PLS % 4 == 0 && F12_LS % 4 == 0, "tile layout");
+static_assert(2 * F12_BR * F12_WR <= F12_THREADS, "one staged word per thread");
+static_assert((F12_TH + 1) * 100 <= 2 * F12_THREADS && F12_TH * 100 <= F12_THREADS, "pixel pairs per step");
+
+__global__ __launch_bounds__(F12_THREADS) void k_trunk12(ConvParams p, const float *lut) {
+  constexpr int W = PS, H = PS, H1 = PS / 2, H2 = PS / 4, LS = F12_LS, PLS = F12_PLS, NK = 24;
+  __shared__ __align__(16) float slut[2 * 512 * 8];
+  __shared__ __align__(16) float tile[8 * F12_PLS];
+  __shared__ unsigned rows[2][2][F12_BR][F12_WR];  // [buffer][channel][bit row][word]
+  __shared__ __align__(16) float halo[2][8][2][F12_LS];  // the last two p1 rows of a step = the first two of the next
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n16 = lane & 15, kq = lane >> 4, co = n16 >> 1, r = n16 & 1;
+
+  // bit rows of the p1 rows [pa, pb): image rows 2 pa - 1 .. 2 pb, re-aligned like k_conv1_lut (bit x + 1 of a staged
+  // row <-> image column x; bit 0 and the bits past column W - 1 are the zero padding).  One word per thread.
+  auto bits_fetch = [&](int img, int pa, int pb) -> unsigned {
+    const int nrows = 2 * (pb - pa) + 2;
+    unsigned out = 0u;
+    if (tid < 2 * nrows * F12_WR) {
+      const int w = tid % F12_WR, rr = (tid / F12_WR) % nrows, ci = tid / (F12_WR * nrows);
+      const int gy = 2 * pa - 1 + rr;
+      if (gy >= 0 && gy < H) {
+        const long long s0 = (long long)gy * W + 32 * w - 1;      // cell of output bit 0 (-1 only for gy = 0, w = 0)
+        const unsigned *bits = p.bits[ci] + (size_t)img * p.bits_stride;
+        const long long sw = s0 >> 5;                             // arithmetic shift: -1 -> word -1
+        const unsigned lo = (sw >= 0 && sw < (PS * PS) >> 5) ? bits[sw] : 0u;
+        const unsigned hi = (sw + 1 < (PS * PS) >> 5) ? bits[sw + 1] : 0u;
+        out = __funnelshift_r(lo, hi, (unsigned)(s0 & 31));
+        const int xlo = 32 * w - 1;
+        if (xlo < 0) out &= ~1u;
+        const int over = xlo + 32 - W;                            // bits past the last column
+        if (over > 0) out = over >= 32 ? 0u : (out & (0xFFFFFFFFu >> over));
+      }
+    }
+    return out;
+  };
+  auto bits_commit = [&](int buf, int pa, int pb, unsigned word) {
+    const int nrows = 2 * (pb - pa) + 2;
+    if (tid < 2 * nrows * F12_WR) {
+      const int w = tid % F12_WR, rr = (tid / F12_WR) % nrows, ci = tid / (F12_WR * nrows);
+      rows[buf][ci][rr][w] = word;
+    }
+  };
+
+  // ---- prologue: table, weights, zeroed tile (halo columns and the row above the image stay zero), first bit rows ----
+  for (int e = tid; e < 2 * 512 * 8 / 4; e += F12_THREADS)
+    reinterpret_cast<f32x4 *>(slut)[e] = reinterpret_cast<const f32x4 *>(lut)[e];
+  for (int e = tid; e < 8 * PLS / 4; e += F12_THREADS) reinterpret_cast<f32x4 *>(tile)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int e = tid; e < 2 * 8 * 2 * LS / 4; e += F12_THREADS) reinterpret_cast<f32x4 *>(&halo[0][0][0][0])[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bw[NK];
+#pragma unroll
+  for (int j = 0; j < NK; j++) bw[j] = p.wbm[j * 64 + lane];     // per-lane B operand of k_convm (PrepLayout::wbm)
+  const float bias = p.b[co];
+  const f32x4 binit = {bias, bias, bias, bias};
+  bits_commit(0, 0, F12_TH + 1, bits_fetch((int)blockIdx.x, 0, F12_TH + 1));
+  __syncthreads();
+
+  const float *abase = &tile[kq * PLS + 3];
+  auto aof = [&](int j) -> int { return (4 * (j & 1)) * PLS + ((j >> 1) / 3) * LS + ((j >> 1) % 3); };
+
+  // persistent: a workgroup takes images blockIdx.x, blockIdx.x + gridDim.x, ... (table, weights and the zero frame of
+  // the tile are set up once; the first bit rows of the next image are fetched under the last step of this one)
+#pragma unroll 1
+  for (int img = (int)blockIdx.x; img < p.images; img += (int)gridDim.x)
+#pragma unroll 1
+  for (int step = 0; step < H1 / F12_TH; step++) {
+    const int R0 = step * F12_TH;                                  // first conv2 row of the step
+    // new p1 rows [pa, pb) -> tile rows pa - (R0 - 1) ..; the first step also makes row 0 (its row -1 is the zero row),
+    // the last one leaves row 200 zero
+    const int pa = step ? R0 + 1 : 0, pb = min(R0 + F12_TH + 1, H1);
+    const int buf = step & 1;
+
+    // ---- phase A: conv1 table look-up + pool + ReLU, two adjacent p1 pixels per thread ----
+    if (step && pb - pa < F12_TH)  // last step: p1 row 200 does not exist - the tile row behind the image is zero
+      for (int e = tid; e < 8 * LS; e += F12_THREADS) tile[(e / LS) * PLS + (F12_TH + 1) * LS + e % LS] = 0.f;
+    if (!step)  // the row above the image
+      for (int e = tid; e < 8 * LS; e += F12_THREADS) tile[(e / LS) * PLS + e % LS] = 0.f;
+    if (step && tid < 8 * 2 * (LS / 4)) {  // rows R0 - 1, R0: kept by the previous step (nobody reads the tile in phase A)
+      const int c4 = tid % (LS / 4), rr = (tid / (LS / 4)) & 1, ci = tid / (2 * (LS / 4));
+      reinterpret_cast<f32x4 *>(&tile[ci * PLS + rr * LS])[c4] = reinterpret_cast<const f32x4 *>(&halo[buf][ci][rr][0])[c4];
+    }
+    for (int q = tid; q < (pb - pa) * 100; q += F12_THREADS) {
+      const int py = q / 100, pp = q - py * 100;
+      const int x0 = 4 * pp;                                       // window = staged bits x0 .. x0 + 5 of rows 2 py .. 2 py + 3
+      unsigned f[2][4];
+#pragma unroll
+      for (int ci = 0; ci < 2; ci++)
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+          const unsigned *rw = &rows[buf][ci][2 * py + rr][x0 >> 5];
+          f[ci][rr] = __funnelshift_r(rw[0], rw[1], (unsigned)(x0 & 31)) & 63u;
+        }
+      float m2[8][2];
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        f32x4 acc[4][2];                                           // [2x2 pixel][channels 0-3 | 4-7]
+#pragma unroll
+        for (int ci = 0; ci < 2; ci++)
+#pragma unroll
+          for (int qq = 0; qq < 4; qq++) {
+            const int dy = qq >> 1, sh = 2 * j + (qq & 1);
+            const unsigned pat = ((f[ci][dy] >> sh) & 7u) | (((f[ci][dy + 1] >> sh) & 7u) << 3) | (((f[ci][dy + 2] >> sh) & 7u) << 6);
+            const f32x4 *e = reinterpret_cast<const f32x4 *>(&slut[(ci * 512 + pat) * 8]);
+            if (ci == 0) { acc[qq][0] = e[0]; acc[qq][1] = e[1]; }  // the table of channel 0 carries the bias
+            else { acc[qq][0] += e[0]; acc[qq][1] += e[1]; }
+          }
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+          float m;  // the operands are ordinary VALU results (interlocked), not MFMA results: asm is safe here
+          asm("v_max3_f32 %0, %1, %2, 0" : "=v"(m) : "v"(acc[0][c >> 2][c & 3]), "v"(acc[1][c >> 2][c & 3]));
+          asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(acc[2][c >> 2][c & 3]), "v"(acc[3][c >> 2][c & 3]), "v"(m));
+          m2[c][j] = m;
+        }
+      }
+      const int trow = pa + py - (R0 - 1);
+      float *dst = &tile[trow * LS + 4 + 2 * pp];
+#pragma unroll
+      for (int c = 0; c < 8; c++) *reinterpret_cast<float2 *>(dst + c * PLS) = make_float2(m2[c][0], m2[c][1]);
+      if (trow >= F12_TH) {  // also the next step's first two rows
+#pragma unroll
+        for (int c = 0; c < 8; c++)
+          *reinterpret_cast<float2 *>(&halo[buf ^ 1][c][trow - F12_TH][4 + 2 * pp]) = make_float2(m2[c][0], m2[c][1]);
+      }
+    }
+    __syncthreads();
+
+    // ---- phase B: conv2 on the tile; the next step's bit rows are fetched meanwhile ----
+    const bool last = step + 1 == H1 / F12_TH;
+    const int nimg = last ? img + (int)gridDim.x : img;
+    const bool more = nimg < p.images;
+    const int na = last ? 0 : R0 + F12_TH + 1, nb = last ? F12_TH + 1 : min(R0 + 2 * F12_TH + 1, H1);
+    unsigned nextw = 0u;
+    if (more) nextw = bits_fetch(nimg, na, nb);
+
+    auto finish = [&](const f32x4 d, int T) {
+      float q0, q1;
+      q0 = max_raw(max_raw(d[0], 0.f), d[1]);  // compiler-visible reads of the MFMA result (see max_raw)
+      q1 = max_raw(max_raw(d[2], 0.f), d[3]);
+      q0 = max_raw(q0, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, q0), 0xB1, 0xF, 0xF, true)));
+      q1 = max_raw(q1, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, q1), 0xB1, 0xF, 0xF, true)));
+      const int P = 16 * T + 4 * kq;                               // the lane's four pixels P .. P + 3 of one row pair
+      const int rp = P / 200, x = P - rp * 200;
+      if (r == 0 && P < (F12_TH / 2) * 200)
+        *reinterpret_cast<float2 *>(p.out + (((size_t)img * 8 + co) * H2 + (R0 >> 1) + rp) * H2 + (x >> 1)) = make_float2(q0, q1);
+    };
+    auto a_of_tile = [&](int T) -> const float * {                 // the lane's A row: pixel 16 T + n16 (clamped past the end)
+      const int P = min(16 * T + n16, (F12_TH / 2) * 200 - 1);
+      const int rp = P / 200, x = P - rp * 200;
+      return abase + 2 * rp * LS + x;
+    };
+    constexpr int NT = ((F12_TH / 2) * 200 + 15) / 16;             // 63 M-tiles
+#pragma unroll 1
+    for (int T = wv; T < NT; T += 32) {
+      const int T1 = T + 16;
+      const float *a0 = a_of_tile(T);
+      if (T1 < NT) {  // wave-uniform
+        const float *a1 = a_of_tile(T1);
+        f32x4 d0 = binit, d1 = binit;
+#pragma unroll
+        for (int j = 0; j < NK; j++) {
+          d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[aof(j)], bw[j], d0, 0, 0, 0);
+          d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[aof(j)], bw[j], d1, 0, 0, 0);
+        }
+        finish(d0, T);
+        finish(d1, T1);
+      } else {
+        f32x4 d0 = binit;
+#pragma unroll
+        for (int j = 0; j < NK; j++) d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[aof(j)], bw[j], d0, 0, 0, 0);
+        finish(d0, T);
+      }
+    }
+    if (more) bits_commit(buf ^ 1, na, nb, nextw);  // the other buffer: phase A of this step is behind every wave
+    __syncthreads();
+  }
+}
+
 // ---- fp32 MFMA GEMM for the dense layers -------------------------------------------
 // C[M][N] = act(A[M][K] (lda) x B[K][N] (ldb) + bias[N])   one wave per 32x32 tile,
 // v_mfma_f32_32x32x2_f32: lane l holds A[row l&31][k l>>5], B[k l>>5][col l&31];
@@ -961,6 +1154,9 @@ extern "C" int ofx_set_option(ofx_handle *h, int32_t option, int32_t value) {
   if (!h) { ofx_set_error("ofx_set_option: null handle"); return OFX_ERR_INVALID; }
   switch (option) {
     case OFX_OPT_TRUNK_PLAIN: h->opt_trunk_plain = value != 0; return OFX_OK;
+    case OFX_OPT_TRUNK_FUSE:
+      if (value < 0 || value > 2) { ofx_set_error("ofx_set_option: OFX_OPT_TRUNK_FUSE takes 0 (auto), 1 (always), 2 (never)"); return OFX_ERR_INVALID; }
+      h->opt_trunk_fuse = value; return OFX_OK;
     case OFX_OPT_FRAMES_REF: h->opt_frames_ref = value != 0; return OFX_OK;
     case OFX_OPT_BILINEAR_LEGACY:  // a different function, not a variant: the prepared phase weights depend on it
       if (h->opt_bilinear_legacy == (value != 0)) return OFX_OK;
@@ -998,8 +1194,16 @@ static int policy_forward_impl(ofx_handle *h, const float *weights, int N, int M
   cp.bits_stride = bits_stride;
   cp.w = prep + L.tw[0]; cp.b = prep + L.tb[0]; cp.out = ws.p1;
   const bool plain = h->opt_trunk_plain;  // OFX_OPT_TRUNK_PLAIN: every trunk layer through the plain VALU kernel
+  // conv1 -> conv2 fused (k_trunk12, one persistent workgroup per CU) once the images fill the CUs a few times over;
+  // below that the two-kernel form has the shorter critical path (OFX_OPT_TRUNK_FUSE: 1 always, 2 never)
+  const bool fused12 = !plain && (h->opt_trunk_fuse == 1 || (h->opt_trunk_fuse == 0 && N >= 4 * h->n_cus));
   if (plain) rc = launch_conv<2, 8, 10, 100, 1, true, false>(h, cp, N, 400);
-  else {
+  else if (fused12) {
+    cp.out = ws.p2; cp.b = prep + L.tb[1]; cp.wbm = prep + L.wbm[0]; cp.images = N;
+    hipLaunchKernelGGL(k_trunk12, dim3((unsigned)(N < h->n_cus ? N : h->n_cus)), dim3(F12_THREADS), 0, h->stream, cp,
+                       (const float *)(prep + L.lut1));
+    OFX_HIP(hipGetLastError());
+  } else {
     cp.H = 400; cp.W = 400;
     hipLaunchKernelGGL(k_conv1_lut<40>, dim3((unsigned)(N * (400 / 40))), dim3(256), 0, h->stream, cp,
                        (const float *)(prep + L.lut1));
@@ -1009,7 +1213,7 @@ static int policy_forward_impl(ofx_handle *h, const float *weights, int N, int M
   // k_convm tile shapes from an A/B on the chip (conv2: 2 row pairs x 208 columns, 29 KB of LDS, five workgroups per CU)
   cp.in = ws.p1; cp.w = prep + L.tw[1]; cp.b = prep + L.tb[1]; cp.out = ws.p2; cp.wbm = prep + L.wbm[0];
   if (plain) rc = launch_conv<8, 8, 10, 100, 0, true, false>(h, cp, N, 200);
-  else rc = launch_convm<8, 2, 13, 0, false, 1>(h, cp, N, 200);
+  else if (!fused12) rc = launch_convm<8, 2, 13, 0, false, 1>(h, cp, N, 200);
   if (rc) return rc;
   cp.in = ws.p2; cp.w = prep + L.tw[2]; cp.b = prep + L.tb[2]; cp.out = ws.p3; cp.wbm = prep + L.wbm[1];
   if (plain) rc = launch_conv<8, 8, 10, 100, 0, true, false>(h, cp, N, 100);

@@ -122,6 +122,33 @@ def test_reference_variants_agree():
     b.close()
 
 
+def test_trunk_fused_matches_split():
+    """OFX_OPT_TRUNK_FUSE: conv1 -> conv2 in one persistent kernel (k_trunk12: the pooled conv1 activation lives only in
+    LDS) against the two-kernel form - same table sums, same banded-GEMM k order, so the results are bit-identical.
+    300 arenas on 256 CUs: some workgroups walk two images (the persistent loop), some one."""
+    from ofighters_amd import _native as nat
+    from oracle import pyoracle
+    N, M = 300, 2
+    b = _rollout(N, M, seed=19, ticks=25)
+    w, _ = pyoracle.policy_init(7, trained_like=True)
+    b.set_option(nat.OPT_TRUNK_FUSE, 2)
+    split = b.policy_forward_host(w)
+    b.set_option(nat.OPT_TRUNK_FUSE, 1)
+    fused = b.policy_forward_host(w)
+    b.set_option(nat.OPT_TRUNK_FUSE, 0)
+    for k in split:
+        assert np.array_equal(fused[k], split[k]), k
+    # and against the restatement for a few ships (the fused path is the one the full-size workloads run)
+    head, _ = b.observe_head()
+    sm, lm = b.maps_host(nat.MAP_U8)
+    for g, i in ((0, 0), (255, 1), (256, 0), (299, 1)):
+        act, heat, ia, ip = pyoracle.policy_forward(sm[g], lm[g], head[g, i].astype(np.float32), w)
+        np.testing.assert_allclose(fused["act"][g, i], act, rtol=0, atol=TOL * max(1.0, float(np.abs(act).max())))
+        gx, gy = fused["ipointer"][g, i]
+        assert heat[gy, gx] >= heat.max() - 2 * TOL * float(np.abs(heat).max())
+    b.close()
+
+
 def test_legacy_bilinear_option():
     """OFX_OPT_BILINEAR_LEGACY: the TF1 resize_bilinear convention of UpSampling2D (src = dst / 2) - the second
     meaning the reference's unpinned keras range admits (qlearnIA_V2.py:166-184).  Against the restatement with the
