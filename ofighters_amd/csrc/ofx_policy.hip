@@ -688,7 +688,7 @@ __global__ __launch_bounds__(256) void k_conv1_lut(ConvParams p, const float *lu
 //            bn(conv1))) - a thread owns two adjacent p1 pixels, 1000 of the 1024 threads busy - written straight into
 //            the planar LDS tile the GEMM reads (rows R0 - 1 .. R0 + 10 of p1, zero outside the image);
 //   phase B (MFMA): conv2 as k_convm's banded GEMM on that tile, M-tiles of 16 pixels enumerated FLAT over the 5 row
-//            pairs x 200 columns (62.5 M-tiles: no masked columns), 4 per wave in two chain pairs; the global loads of
+//            pairs x 200 columns (62.5 M-tiles: no masked columns), 4 per wave as four accumulator chains; the global loads of
 //            the next step's bit rows are in flight meanwhile;
 //            (the step's last two p1 rows are also kept aside: they are the first two tile rows of the next step).
 // f32 MFMA and VALU share the SIMD's issue port, so separating the phases in time costs nothing as long as each phase
@@ -849,8 +849,20 @@ __global__ __launch_bounds__(F12_THREADS) void k_trunk12(ConvParams p, const flo
       return abase + 2 * rp * LS + x;
     };
     constexpr int NT = ((F12_TH / 2) * 200 + 15) / 16;             // 63 M-tiles
+    if (wv + 48 < NT) {  // all four M-tiles of the wave at once: four accumulator chains (3.0 -> 2.84 ms against two pairs)
+      const float *a0 = a_of_tile(wv), *a1 = a_of_tile(wv + 16), *a2 = a_of_tile(wv + 32), *a3 = a_of_tile(wv + 48);
+      f32x4 d0 = binit, d1 = binit, d2 = binit, d3 = binit;
+#pragma unroll
+      for (int j = 0; j < NK; j++) {
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[aof(j)], bw[j], d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[aof(j)], bw[j], d1, 0, 0, 0);
+        d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[aof(j)], bw[j], d2, 0, 0, 0);
+        d3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[aof(j)], bw[j], d3, 0, 0, 0);
+      }
+      finish(d0, wv); finish(d1, wv + 16); finish(d2, wv + 32); finish(d3, wv + 48);
+    } else
 #pragma unroll 1
-    for (int T = wv; T < NT; T += 32) {
+    for (int T = wv; T < NT; T += 32) {  // the wave with three M-tiles: a pair and a single
       const int T1 = T + 16;
       const float *a0 = a_of_tile(T);
       if (T1 < NT) {  // wave-uniform
@@ -1056,10 +1068,18 @@ constexpr int kDense1Chunks = 25;  // split-K of dense1: 5000 = 25 x 200
 
 // N images (trunk runs), S policy samples (heads); the layout depends on both, so a forward with other sizes
 // (ofx_policy_forward_obs) invalidates the results a previous forward left in the workspace
+// conv1 -> conv2 fused (k_trunk12, one persistent workgroup per CU) once the images fill the CUs a few times over;
+// below that the two-kernel form has the shorter critical path (OFX_OPT_TRUNK_FUSE: 1 always, 2 never)
+static bool trunk_fused(const ofx_handle *h, size_t N) {
+  if (h->opt_trunk_plain) return false;
+  return h->opt_trunk_fuse == 1 || (h->opt_trunk_fuse == 0 && N >= 4 * (size_t)h->n_cus);
+}
+
 static int policy_workspace(ofx_handle *h, PolicyWs *ws, size_t N, size_t S) {
   size_t f2, f3, f4;
   ofx_head_frame_bytes(S, &f2, &f3, &f4);
-  const size_t sz[] = {al(4ull * N * 8 * 200 * 200), al(4ull * N * 8 * 100 * 100), al(4ull * N * 8 * 50 * 50),
+  // p1 (5.2 GB at 4096 arenas) exists only in the two-kernel form of the trunk
+  const size_t sz[] = {trunk_fused(h, N) ? 0 : al(4ull * N * 8 * 200 * 200), al(4ull * N * 8 * 100 * 100), al(4ull * N * 8 * 50 * 50),
                        al(4ull * N * 5000),          al(4ull * N * 100 * kDense1Chunks), al(4ull * S * 100),
                        al(4ull * S * 625),           al(4ull * S * 2 * 50 * 50),   al(f2), al(f3), al(f4),
                        al(8ull * S),                 al(4ull * S),                 al(8ull * S),
@@ -1194,9 +1214,7 @@ static int policy_forward_impl(ofx_handle *h, const float *weights, int N, int M
   cp.bits_stride = bits_stride;
   cp.w = prep + L.tw[0]; cp.b = prep + L.tb[0]; cp.out = ws.p1;
   const bool plain = h->opt_trunk_plain;  // OFX_OPT_TRUNK_PLAIN: every trunk layer through the plain VALU kernel
-  // conv1 -> conv2 fused (k_trunk12, one persistent workgroup per CU) once the images fill the CUs a few times over;
-  // below that the two-kernel form has the shorter critical path (OFX_OPT_TRUNK_FUSE: 1 always, 2 never)
-  const bool fused12 = !plain && (h->opt_trunk_fuse == 1 || (h->opt_trunk_fuse == 0 && N >= 4 * h->n_cus));
+  const bool fused12 = trunk_fused(h, (size_t)N);
   if (plain) rc = launch_conv<2, 8, 10, 100, 1, true, false>(h, cp, N, 400);
   else if (fused12) {
     cp.out = ws.p2; cp.b = prep + L.tb[1]; cp.wbm = prep + L.wbm[0]; cp.images = N;
