@@ -682,6 +682,69 @@ __global__ __launch_bounds__(256) void k_conv1_lut(ConvParams p, const float *lu
   }
 }
 
+// ---- streaming trunk kernel (k_trunk12): the GEMM phase ---------------------------------------------
+// k_convm's banded GEMM over an LDS tile of RP row pairs x WD columns (planes PLS apart, rows LS apart; abase = the
+// lane's k-quarter plane at column -1 of tile row 0).  M-tiles of 16 pixels are enumerated FLAT over (row pair, column):
+// RP * WD / 16 of them, no masked columns; wave w takes tiles w, w + 16, w + 32, w + 48 as four interleaved accumulator
+// chains (a wave with three: a pair and a single).  Epilogue as k_convm: 2x2 pool + ReLU, one 8-byte store per lane to
+// orow = the lane's channel plane at the step's first pooled row (planar [.][WD/2]).
+template <int WD, int RP, int LS, int PLS>
+__device__ __forceinline__ void ts_gemm_phase(const float *abase, const float (&bw)[24], const f32x4 binit, int wv, int n16,
+                                              int kq, int r, float *orow) {
+  constexpr int NK = 24, NPX = RP * WD, NT = (NPX + 15) / 16;
+  static_assert(WD % 4 == 0 && NT <= 64, "four M-tiles per wave at most");
+  auto aof = [&](int j) -> int { return (4 * (j & 1)) * PLS + ((j >> 1) / 3) * LS + ((j >> 1) % 3); };
+  auto finish = [&](const f32x4 d, int T) {
+    float q0, q1;
+    q0 = max_raw(max_raw(d[0], 0.f), d[1]);  // compiler-visible reads of the MFMA result (see max_raw)
+    q1 = max_raw(max_raw(d[2], 0.f), d[3]);
+    q0 = max_raw(q0, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, q0), 0xB1, 0xF, 0xF, true)));
+    q1 = max_raw(q1, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, q1), 0xB1, 0xF, 0xF, true)));
+    const int P = 16 * T + 4 * kq;                                 // the lane's four pixels P .. P + 3 of one row pair
+    const int rp = P / WD, x = P - rp * WD;
+    if (r == 0 && P < NPX) *reinterpret_cast<float2 *>(orow + rp * (WD / 2) + (x >> 1)) = make_float2(q0, q1);
+  };
+  auto a_of_tile = [&](int T) -> const float * {                   // the lane's A row: pixel 16 T + n16 (clamped past the end)
+    const int P = min(16 * T + n16, NPX - 1);
+    const int rp = P / WD, x = P - rp * WD;
+    return abase + 2 * rp * LS + x;
+  };
+  if (wv + 48 < NT) {  // all four M-tiles of the wave at once (k_trunk12: 3.0 -> 2.84 ms against two pairs)
+    const float *a0 = a_of_tile(wv), *a1 = a_of_tile(wv + 16), *a2 = a_of_tile(wv + 32), *a3 = a_of_tile(wv + 48);
+    f32x4 d0 = binit, d1 = binit, d2 = binit, d3 = binit;
+#pragma unroll
+    for (int j = 0; j < NK; j++) {
+      d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[aof(j)], bw[j], d0, 0, 0, 0);
+      d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[aof(j)], bw[j], d1, 0, 0, 0);
+      d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[aof(j)], bw[j], d2, 0, 0, 0);
+      d3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[aof(j)], bw[j], d3, 0, 0, 0);
+    }
+    finish(d0, wv); finish(d1, wv + 16); finish(d2, wv + 32); finish(d3, wv + 48);
+  } else {
+#pragma unroll 1
+    for (int T = wv; T < NT; T += 32) {
+      const int T1 = T + 16;
+      const float *a0 = a_of_tile(T);
+      if (T1 < NT) {  // wave-uniform
+        const float *a1 = a_of_tile(T1);
+        f32x4 d0 = binit, d1 = binit;
+#pragma unroll
+        for (int j = 0; j < NK; j++) {
+          d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[aof(j)], bw[j], d0, 0, 0, 0);
+          d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[aof(j)], bw[j], d1, 0, 0, 0);
+        }
+        finish(d0, T);
+        finish(d1, T1);
+      } else {
+        f32x4 d0 = binit;
+#pragma unroll
+        for (int j = 0; j < NK; j++) d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[aof(j)], bw[j], d0, 0, 0, 0);
+        finish(d0, T);
+      }
+    }
+  }
+}
+
 // ---- conv1 -> conv2 fused: the 5.2 GB pooled conv1 activation never exists -----------------------------------------
 // One 1024-thread workgroup walks ONE image top to bottom in 20 steps of F12_TH = 10 conv2 rows.  Per step:
 //   phase A (all threads, VALU + LDS): the table form of conv1 (see k_conv1_lut) for the 10 NEW rows of p1 = pool(relu(
@@ -756,7 +819,6 @@ __global__ __launch_bounds__(F12_THREADS) void k_trunk12(ConvParams p, const flo
   __syncthreads();
 
   const float *abase = &tile[kq * PLS + 3];
-  auto aof = [&](int j) -> int { return (4 * (j & 1)) * PLS + ((j >> 1) / 3) * LS + ((j >> 1) % 3); };
 
   // persistent: a workgroup takes images blockIdx.x, blockIdx.x + gridDim.x, ... (table, weights and the zero frame of
   // the tile are set up once; the first bit rows of the next image are fetched under the last step of this one)
@@ -832,56 +894,8 @@ __global__ __launch_bounds__(F12_THREADS) void k_trunk12(ConvParams p, const flo
     unsigned nextw = 0u;
     if (more) nextw = bits_fetch(nimg, na, nb);
 
-    auto finish = [&](const f32x4 d, int T) {
-      float q0, q1;
-      q0 = max_raw(max_raw(d[0], 0.f), d[1]);  // compiler-visible reads of the MFMA result (see max_raw)
-      q1 = max_raw(max_raw(d[2], 0.f), d[3]);
-      q0 = max_raw(q0, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, q0), 0xB1, 0xF, 0xF, true)));
-      q1 = max_raw(q1, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, q1), 0xB1, 0xF, 0xF, true)));
-      const int P = 16 * T + 4 * kq;                               // the lane's four pixels P .. P + 3 of one row pair
-      const int rp = P / 200, x = P - rp * 200;
-      if (r == 0 && P < (F12_TH / 2) * 200)
-        *reinterpret_cast<float2 *>(p.out + (((size_t)img * 8 + co) * H2 + (R0 >> 1) + rp) * H2 + (x >> 1)) = make_float2(q0, q1);
-    };
-    auto a_of_tile = [&](int T) -> const float * {                 // the lane's A row: pixel 16 T + n16 (clamped past the end)
-      const int P = min(16 * T + n16, (F12_TH / 2) * 200 - 1);
-      const int rp = P / 200, x = P - rp * 200;
-      return abase + 2 * rp * LS + x;
-    };
-    constexpr int NT = ((F12_TH / 2) * 200 + 15) / 16;             // 63 M-tiles
-    if (wv + 48 < NT) {  // all four M-tiles of the wave at once: four accumulator chains (3.0 -> 2.84 ms against two pairs)
-      const float *a0 = a_of_tile(wv), *a1 = a_of_tile(wv + 16), *a2 = a_of_tile(wv + 32), *a3 = a_of_tile(wv + 48);
-      f32x4 d0 = binit, d1 = binit, d2 = binit, d3 = binit;
-#pragma unroll
-      for (int j = 0; j < NK; j++) {
-        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[aof(j)], bw[j], d0, 0, 0, 0);
-        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[aof(j)], bw[j], d1, 0, 0, 0);
-        d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[aof(j)], bw[j], d2, 0, 0, 0);
-        d3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[aof(j)], bw[j], d3, 0, 0, 0);
-      }
-      finish(d0, wv); finish(d1, wv + 16); finish(d2, wv + 32); finish(d3, wv + 48);
-    } else
-#pragma unroll 1
-    for (int T = wv; T < NT; T += 32) {  // the wave with three M-tiles: a pair and a single
-      const int T1 = T + 16;
-      const float *a0 = a_of_tile(T);
-      if (T1 < NT) {  // wave-uniform
-        const float *a1 = a_of_tile(T1);
-        f32x4 d0 = binit, d1 = binit;
-#pragma unroll
-        for (int j = 0; j < NK; j++) {
-          d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[aof(j)], bw[j], d0, 0, 0, 0);
-          d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[aof(j)], bw[j], d1, 0, 0, 0);
-        }
-        finish(d0, T);
-        finish(d1, T1);
-      } else {
-        f32x4 d0 = binit;
-#pragma unroll
-        for (int j = 0; j < NK; j++) d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[aof(j)], bw[j], d0, 0, 0, 0);
-        finish(d0, T);
-      }
-    }
+    ts_gemm_phase<200, F12_TH / 2, F12_LS, F12_PLS>(abase, bw, binit, wv, n16, kq, r,
+                                                     p.out + (((size_t)img * 8 + co) * H2 + (R0 >> 1)) * H2);
     if (more) bits_commit(buf ^ 1, na, nb, nextw);  // the other buffer: phase A of this step is behind every wave
     __syncthreads();
   }
