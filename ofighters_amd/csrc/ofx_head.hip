@@ -320,20 +320,25 @@ __global__ __launch_bounds__(HG_THREADS) void k_head_frames(HeadParams2 p) {
   const int n16 = lane & 15, kq = lane >> 4;
   float *l1p = sm + HG_L1, *u2rb = sm + HG_RB, *u2cb = sm + HG_CB, *u3l = sm + HG_U3;
 
-  {  // uprelu1 -> LDS, clamp-extended by one cell: all loads of a thread in flight before the first store
-    constexpr int NE = 2 * 52 * 52, PER = (NE + HG_THREADS - 1) / HG_THREADS;  // 22
+  {  // uprelu1 -> LDS, clamp-extended by one cell.  Only the three outer rows / columns on each side are ever read (the
+     // frame bands and the corner cells): 588 of the 2704 cells of a channel; all loads of a thread in flight before
+     // the first store
+    constexpr int NB = 6 * 52 + 46 * 6, NE = 2 * NB, PER = (NE + HG_THREADS - 1) / HG_THREADS;  // 588 per channel, 5 per thread
     float v[PER];
+    int at[PER];
 #pragma unroll
     for (int u = 0; u < PER; u++) {
       const int e = min(u * HG_THREADS + tid, NE - 1);
-      const int c = e % 52, r = (e / 52) % 52, ci = e / 2704;
+      const int ci = e / NB, k = e - ci * NB;
+      int r, c;
+      if (k < 6 * 52) { const int rr = k / 52; r = rr < 3 ? rr : rr + 46; c = k - rr * 52; }
+      else { const int k2 = k - 6 * 52, cc = k2 % 6; r = 3 + k2 / 6; c = cc < 3 ? cc : cc + 46; }
+      at[u] = (ci * 52 + r) * 52 + c;
       v[u] = p.up1[(size_t)s * 5000 + (ci * 50 + min(max(r - 1, 0), 49)) * 50 + min(max(c - 1, 0), 49)];
     }
 #pragma unroll
-    for (int u = 0; u < PER; u++) {
-      const int e = u * HG_THREADS + tid;
-      if (e < NE) l1p[e] = v[u];
-    }
+    for (int u = 0; u < PER; u++)
+      if (u * HG_THREADS + tid < NE) l1p[at[u]] = v[u];
   }
   if (tid < 192) efr_s[tid] = p.efr[tid];
   __syncthreads();
