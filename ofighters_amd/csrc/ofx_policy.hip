@@ -264,7 +264,7 @@ __global__ void k_policy_prepare(PrepParams p) {
 
 // ---- generic direct 3x3 convolution ------------------------------------------------
 struct ConvParams {
-  const float *in;                 // MODE 0 / 2: planar [img][CIN][Hin][Win]
+  const float *in;                 // MODE 0: planar [img][CIN][H][W]; k_upconv1: [img][625]
   const unsigned *bits[2];         // MODE 1: word bits[ci][img * bits_stride + w], LSB-first (ch0 ship, ch1 laser)
   size_t bits_stride;              // words between consecutive images (PS*PS/32, or twice that for interleaved maps)
   const float *w, *b;              // folded [9][CIN][COUT], [COUT]
@@ -273,11 +273,11 @@ struct ConvParams {
   const float *wbm;                // k_convm, CIN = 8: per-lane B operand [24][64] (PrepLayout::wbm)
   int H, W;                        // conv domain (input after any upsampling) = conv output size
   int tiles_x, tiles;              // tiles per row / per image
-  int legacy;                      // MODE 2: TF1 legacy source mapping (src = dst / 2) instead of half-pixel centres
+  int legacy;                      // k_upconv1: TF1 legacy source mapping (src = dst / 2) instead of half-pixel centres
   int images;                      // k_convm: number of images (the grid is padded to a multiple of 8 of them)
 };
 
-// MODE: 0 planar f32 input, 1 two 1-bit maps, 2 planar f32 input upsampled x2 (bilinear, half-pixel or legacy)
+// MODE: 0 planar f32 input, 1 two 1-bit maps
 template <int CIN, int COUT, int TH, int TW, int MODE, bool POOL, bool OUT_HWC>
 __global__ __launch_bounds__(((TH / 2) * (TW / 2) + 63) / 64 * 64) void k_conv(ConvParams p) {
   constexpr int NT = (TH / 2) * (TW / 2);
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(((TH / 2) * (TW / 2) + 63) / 64 * 64) void k_conv(C
   // ---- stage the (TH+2) x (TW+2) x CIN input patch (zero outside the image: padding 'same').
   // Loads are issued in batches of SU before any LDS store so one memory latency covers SU elements.
   constexpr int TOTAL = CIN * (TH + 2) * TWP;
-  constexpr int SU = (MODE == 2) ? 4 : 8;
+  constexpr int SU = 8;
   for (int base = 0; base < TOTAL; base += NTB * SU) {
     float vals[SU];
 #pragma unroll
@@ -309,18 +309,6 @@ __global__ __launch_bounds__(((TH / 2) * (TW / 2) + 63) / 64 * 64) void k_conv(C
           } else if (MODE == 1) {
             const int cell = gy * W + gx;
             v = (float)((p.bits[ci][(size_t)img * p.bits_stride + (cell >> 5)] >> (cell & 31)) & 1u);
-          } else {
-            const int Hs = H >> 1, Ws = W >> 1;
-            const float sy = p.legacy ? (float)gy * 0.5f : ((float)gy + 0.5f) * 0.5f - 0.5f;
-            const float sx = p.legacy ? (float)gx * 0.5f : ((float)gx + 0.5f) * 0.5f - 0.5f;
-            const float fy = floorf(sy), fx = floorf(sx);
-            const float ly = sy - fy, lx = sx - fx;
-            int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1, x1 = x0 + 1;
-            y0 = max(y0, 0); x0 = max(x0, 0); y1 = min(y1, Hs - 1); x1 = min(x1, Ws - 1);
-            const float *sp = p.in + ((size_t)img * CIN + ci) * Hs * Ws;
-            const float a = sp[y0 * Ws + x0], b = sp[y0 * Ws + x1], d = sp[y1 * Ws + x0], g = sp[y1 * Ws + x1];
-            const float top = a + (b - a) * lx, bot = d + (g - d) * lx;
-            v = top + (bot - top) * ly;
           }
         }
       }
@@ -679,6 +667,66 @@ __global__ __launch_bounds__(256) void k_conv1_lut(ConvParams p, const float *lu
     const unsigned off = (unsigned)(py * W2 + 4 * pq);
 #pragma unroll
     for (int co = 0; co < 8; co++) *reinterpret_cast<f32x4 *>(obase + (size_t)co * (H / 2) * W2 + off) = m4[co];
+  }
+}
+
+// ---- upconv1 (1 -> 2 channels @ 50x50 behind a x2 bilinear up-sampling of the 25x25 dense output) --------------------
+// One workgroup per policy sample: the 625 inputs and the zero-padded up-sampled plane live in LDS (the generic k_conv
+// gathered every staged cell from global memory with four loads: 0.26 ms for 32768 ships; this form 0.22, bound by its
+// 0.66 GB of output).  Up-sample x first, then y (the restatement's order), taps in (dy, dx) order with fma, bias
+// behind the sum, ReLU.  A thread owns 10 adjacent pixels of a row.
+__global__ __launch_bounds__(256) void k_upconv1(ConvParams p) {
+  __shared__ float u0s[625];
+  __shared__ float up[52][53];   // up-sampled plane with its zero frame; pitch 53: the 5 segments of a row start on different banks
+  const int img = blockIdx.x, tid = threadIdx.x;
+  if (p.mask && !p.mask[img]) return;  // block-uniform
+  for (int e = tid; e < 625; e += 256) u0s[e] = p.in[(size_t)img * 625 + e];
+  __syncthreads();
+  for (int e = tid; e < 52 * 52; e += 256) {
+    const int c = e % 52, r = e / 52, gy = r - 1, gx = c - 1;
+    float v = 0.f;
+    if (gy >= 0 && gy < 50 && gx >= 0 && gx < 50) {
+      const float sy = p.legacy ? (float)gy * 0.5f : ((float)gy + 0.5f) * 0.5f - 0.5f;
+      const float sx = p.legacy ? (float)gx * 0.5f : ((float)gx + 0.5f) * 0.5f - 0.5f;
+      const float fy = floorf(sy), fx = floorf(sx);
+      const float ly = sy - fy, lx = sx - fx;
+      int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1, x1 = x0 + 1;
+      y0 = max(y0, 0); x0 = max(x0, 0); y1 = min(y1, 24); x1 = min(x1, 24);
+      const float a = u0s[y0 * 25 + x0], b = u0s[y0 * 25 + x1], d = u0s[y1 * 25 + x0], g = u0s[y1 * 25 + x1];
+      const float top = a + (b - a) * lx, bot = d + (g - d) * lx;
+      v = top + (bot - top) * ly;
+    }
+    up[r][c] = v;
+  }
+  __syncthreads();
+  if (tid >= 250) return;
+  const int row = tid / 5, x0 = 10 * (tid - 5 * row);
+  float acc[2][10];
+#pragma unroll
+  for (int co = 0; co < 2; co++)
+#pragma unroll
+    for (int i = 0; i < 10; i++) acc[co][i] = 0.f;
+#pragma unroll
+  for (int dy = 0; dy < 3; dy++) {
+    float v[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) v[i] = up[row + dy][x0 + i];
+#pragma unroll
+    for (int dx = 0; dx < 3; dx++)
+#pragma unroll
+      for (int co = 0; co < 2; co++) {
+        const float wv = p.w[(dy * 3 + dx) * 2 + co];  // uniform -> scalar load
+#pragma unroll
+        for (int i = 0; i < 10; i++) acc[co][i] = __builtin_fmaf(v[i + dx], wv, acc[co][i]);
+      }
+  }
+#pragma unroll
+  for (int co = 0; co < 2; co++) {
+    const float bias = p.b[co];
+    float *o = p.out + (((size_t)img * 2 + co) * 50 + row) * 50 + x0;
+#pragma unroll
+    for (int i = 0; i < 10; i += 2)
+      *reinterpret_cast<float2 *>(o + i) = make_float2(fmaxf(acc[co][i] + bias, 0.f), fmaxf(acc[co][i + 1] + bias, 0.f));
   }
 }
 
@@ -1280,7 +1328,8 @@ static int policy_forward_impl(ofx_handle *h, const float *weights, int N, int M
   memset(&up, 0, sizeof(up));
   up.mask = ship_mask; up.legacy = h->opt_bilinear_legacy;
   up.in = ws.u0; up.w = prep + L.uw[0]; up.b = prep + L.ub[0]; up.out = ws.up1;
-  if ((rc = launch_conv<1, 2, 10, 50, 2, false, false>(h, up, S, 50))) return rc;
+  hipLaunchKernelGGL(k_upconv1, dim3((unsigned)S), dim3(256), 0, h->stream, up);
+  OFX_HIP(hipGetLastError());
   OFX_HIP(hipMemsetAsync(ws.best, 0, sizeof(unsigned long long) * S, h->stream));
   HeadParams2 hp2;
   memset(&hp2, 0, sizeof(hp2));
