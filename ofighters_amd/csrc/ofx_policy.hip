@@ -77,6 +77,7 @@ struct PrepLayout {
   int efr;            // [line h|v][side first|last][parity 2][low-res offset 3][ci 8]: phase weights of the taps of
                       // upconv4 that fall into the zero padding of a frame pixel (k_head_tail border pass)
   int b4;             // [1]
+  int zero16;         // [4] zeros (never written: the block is cleared when it is allocated)
   int wbm[3];         // conv2..4: the banded B operand of k_convm laid out per lane: [j 24][lane 64]
   int lut1;           // conv1 on the binary maps as a table: [ci 2][3x3 bit pattern 512][co 8] = sum of the folded
                       // weights of the set taps (k_conv1_lut)
@@ -96,8 +97,8 @@ static PrepLayout prep_layout() {
   L.w4raw = off; off += 72;
   L.efr = off; off += 2 * 2 * 2 * 3 * 8;
   L.b4 = off; off += 1;
-  off += 8;                      // 8 zeros: the background of conv1's binary input
   off = (off + 3) & ~3;
+  L.zero16 = off; off += 4;      // 16 zero bytes, 16-byte aligned: the source of the padding cells of k_conv3_stream's LDS-direct loads
   L.lut1 = off; off += 2 * 512 * 8;
   for (int i = 0; i < 3; i++) { L.wbm[i] = off; off += 24 * 64; }
   L.total = (off + 63) & ~63;
@@ -949,6 +950,66 @@ __global__ __launch_bounds__(F12_THREADS) void k_trunk12(ConvParams p, const flo
   }
 }
 
+// ---- conv3 as a streaming kernel: k_trunk12's GEMM phase on tiles that arrive by LDS-direct loads --------------------
+// Planar f32 input [img][8][100][100] -> planar [img][8][50][50].  One persistent 1024-thread workgroup per CU walks an
+// image in 5 steps of 20 rows over TWO tiles (8 planes x 22 rows x 108 floats each, 157 KB): while the GEMM phase
+// (ts_gemm_phase: 10 row pairs x 100 columns = 62.5 M-tiles, four chains per wave) runs on one, the 22 rows of the next
+// step land in the other by global_load_lds_dwordx4 - no staging registers (a register prefetch of 20 rows spills next
+// to four accumulator chains), no LDS store instructions.  An LDS-direct load writes lane l's 16 bytes at base + 16 l, so a
+// plane is filled front to back in pieces of 64 float4: lane q of a plane -> (row q / 27, float4 q % 27); float4 0 and
+// 26 of a row (the halo columns) and the rows outside the image read 16 zero bytes instead (PrepLayout::zero16).
+constexpr int C3_W = 100, C3_TH = 20, C3_LS = 108, C3_ROWS = C3_TH + 2, C3_F4 = C3_LS / 4;
+constexpr int C3_PLS = (C3_ROWS * C3_LS + 63) / 64 * 64 + 16;
+constexpr int C3_PF4 = C3_ROWS * C3_F4, C3_NI = (C3_PF4 + 63) / 64;  // float4 of a plane, wave-instructions per plane
+static_assert(C3_PLS % 64 == 16 && C3_W % C3_TH == 0 && C3_W / 4 + 2 == C3_F4 && 64 * C3_NI * 4 <= C3_PLS + 64 * 4, "tile layout");
+static_assert(2 * 8 * C3_PLS * 4 <= 160 * 1024, "two tiles in LDS");
+
+__global__ __launch_bounds__(F12_THREADS) void k_conv3_stream(ConvParams p, const float *zero16) {
+  constexpr int W = C3_W, H = C3_W, H2 = C3_W / 2, PLS = C3_PLS, NK = 24, STEPS = H / C3_TH;
+  __shared__ __align__(16) float tiles[2][8 * C3_PLS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n16 = lane & 15, kq = lane >> 4, co = n16 >> 1, r = n16 & 1;
+
+  // rows R0 - 1 .. R0 + C3_TH of image img -> tiles[buf]; 80 wave-instructions spread over the 16 waves
+  auto stage = [&](int buf, int img, int R0) {
+#pragma unroll 1
+    for (int i = wv; i < 8 * C3_NI; i += F12_THREADS / 64) {
+      const int ci = i / C3_NI, k = i - ci * C3_NI;
+      const int q = 64 * k + lane;
+      if (q < C3_PF4) {
+        const int row = q / C3_F4, c4 = q - row * C3_F4, gy = R0 - 1 + row;
+        const float *src = zero16;
+        if (c4 >= 1 && c4 <= W / 4 && gy >= 0 && gy < H) src = p.in + (((size_t)img * 8 + ci) * H + gy) * W + 4 * (c4 - 1);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)&tiles[buf][ci * PLS + 256 * k], 16, 0, 0);
+      }
+    }
+  };
+
+  float bw[NK];
+#pragma unroll
+  for (int j = 0; j < NK; j++) bw[j] = p.wbm[j * 64 + lane];
+  const float bias = p.b[co];
+  const f32x4 binit = {bias, bias, bias, bias};
+  if ((int)blockIdx.x < p.images) stage(0, (int)blockIdx.x, 0);
+  __syncthreads();  // drains the LDS-direct loads (the barrier's fence waits vmcnt(0))
+  int buf = 0;
+#pragma unroll 1
+  for (int img = (int)blockIdx.x; img < p.images; img += (int)gridDim.x)
+#pragma unroll 1
+  for (int step = 0; step < STEPS; step++) {
+    const int R0 = step * C3_TH;
+    const bool last = step + 1 == STEPS;
+    const int nimg = last ? img + (int)gridDim.x : img;
+    if (nimg < p.images) stage(buf ^ 1, nimg, last ? 0 : R0 + C3_TH);
+    ts_gemm_phase<W, C3_TH / 2, C3_LS, C3_PLS>(&tiles[buf][kq * PLS + 3], bw, binit, wv, n16, kq, r,
+                                               p.out + (((size_t)img * 8 + co) * H2 + (R0 >> 1)) * H2);
+    __syncthreads();
+    buf ^= 1;
+  }
+}
+
 // ---- fp32 MFMA GEMM for the dense layers -------------------------------------------
 // C[M][N] = act(A[M][K] (lda) x B[K][N] (ldb) + bias[N])   one wave per 32x32 tile,
 // v_mfma_f32_32x32x2_f32: lane l holds A[row l&31][k l>>5], B[k l>>5][col l&31];
@@ -1297,7 +1358,12 @@ static int policy_forward_impl(ofx_handle *h, const float *weights, int N, int M
   if (rc) return rc;
   cp.in = ws.p2; cp.w = prep + L.tw[2]; cp.b = prep + L.tb[2]; cp.out = ws.p3; cp.wbm = prep + L.wbm[1];
   if (plain) rc = launch_conv<8, 8, 10, 100, 0, true, false>(h, cp, N, 100);
-  else rc = launch_convm<8, 4, 7, 0, false, 1>(h, cp, N, 100);
+  else if (fused12) {  // large batches: the streaming form, like conv1 -> conv2
+    cp.images = N;
+    hipLaunchKernelGGL(k_conv3_stream, dim3((unsigned)(N < h->n_cus ? N : h->n_cus)), dim3(F12_THREADS), 0, h->stream, cp,
+                       (const float *)(prep + L.zero16));
+    OFX_HIP(hipGetLastError());
+  } else rc = launch_convm<8, 4, 7, 0, false, 1>(h, cp, N, 100);
   if (rc) return rc;
   cp.in = ws.p3; cp.w = prep + L.tw[3]; cp.b = prep + L.tb[3]; cp.out = ws.p4; cp.wbm = prep + L.wbm[2];
   if (plain) rc = launch_conv<8, 8, 10, 50, 0, true, true>(h, cp, N, 50);  // (h,w,c) = Flatten order
