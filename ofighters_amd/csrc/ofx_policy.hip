@@ -478,29 +478,26 @@ __global__ __launch_bounds__(256) void k_convm(ConvParams p) {
         else if (lane == V4) trow[3] = vpre[u][3];
         else if (lane == V4 + 1) trow[TW + 4] = vpre[u][0];
       }
-    } else {  // unaligned rows (W % 4 != 0): element-wise, no prefetch (the 50x50 layer only)
-      constexpr int RW = TW + 2, TOTAL = CIN * (TH + 2) * RW, SU = 8;
-      for (int base = 0; base < TOTAL; base += 256 * SU) {
-        float vals[SU];
+    } else {  // rows that are not a multiple of 16 bytes (the 50x50 layer: W even, W <= TW): 8-byte pieces, every load of
+              // a thread in flight before the first LDS store; the halo columns are zeroed once (see below)
+      constexpr int TOTAL = CIN * (TH + 2) * (TW / 2), SU = (TOTAL + 255) / 256;
+      (void)tx0;  // one tile per image row (launch_convm checks)
+      f32x2 vals[SU];
+      const int W2c = W >> 1;
 #pragma unroll
-        for (int u = 0; u < SU; u++) {
-          const int e = base + u * 256 + tid;
-          float v = 0.f;
-          if (e < TOTAL) {
-            const int c = e % RW, rr = (e / RW) % (TH + 2), ci = e / (RW * (TH + 2));
-            const int gy = ty0 - 1 + rr, gx = tx0 - 1 + c;
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = p.in[(((size_t)img * CIN + ci) * H + gy) * W + gx];
-          }
-          vals[u] = v;
-        }
+      for (int u = 0; u < SU; u++) {
+        const int e = u * 256 + tid;
+        const int j = e % (TW / 2), rr = (e / (TW / 2)) % (TH + 2), ci = e / ((TW / 2) * (TH + 2));
+        const int gy = ty0 - 1 + rr;
+        vals[u] = (f32x2){0.f, 0.f};
+        if (e < TOTAL && j < W2c && gy >= 0 && gy < H)
+          vals[u] = *reinterpret_cast<const f32x2 *>(p.in + (((size_t)img * CIN + ci) * H + gy) * W + 2 * j);
+      }
 #pragma unroll
-        for (int u = 0; u < SU; u++) {
-          const int e = base + u * 256 + tid;
-          if (e < TOTAL) {
-            const int c = e % RW, rr = (e / RW) % (TH + 2), ci = e / (RW * (TH + 2));
-            tile[ci * PLS + rr * LS + 3 + c] = vals[u];
-          }
-        }
+      for (int u = 0; u < SU; u++) {
+        const int e = u * 256 + tid;
+        const int j = e % (TW / 2), rr = (e / (TW / 2)) % (TH + 2), ci = e / ((TW / 2) * (TH + 2));
+        if (e < TOTAL && j <= W2c) *reinterpret_cast<f32x2 *>(&tile[ci * PLS + rr * LS + 4 + 2 * j]) = vals[u];
       }
     }
   };
@@ -514,6 +511,9 @@ __global__ __launch_bounds__(256) void k_convm(ConvParams p) {
   };
 
   auto lda = [&](const float *a, int j) -> float { return a[aof(j)]; };
+  if constexpr (!VEC) {  // left halo column (image column -1): never written by the staging above
+    for (int e = tid; e < CIN * (TH + 2); e += 256) tile[(e / (TH + 2)) * PLS + (e % (TH + 2)) * LS + 3] = 0.f;
+  }
   fetch(t_first);
 #pragma unroll 1
   for (int i = 0; i < TPW; i++) {
@@ -580,6 +580,7 @@ static int launch_convm(ofx_handle *h, ConvParams p, int images, int H) {
   p.tiles_x = (H + 16 * NG - 1) / (16 * NG);
   p.tiles = p.tiles_x * (H / TH);
   if (p.tiles % TPW) { ofx_set_error("launch_convm: %d tiles per image not divisible by %d", p.tiles, TPW); return OFX_ERR_INVALID; }
+  if (OUT_HWC && (H % 2 || H > 16 * NG)) { ofx_set_error("launch_convm: the 8-byte staging takes even rows of one tile width"); return OFX_ERR_INVALID; }
   p.images = images;
   hipLaunchKernelGGL((k_convm<CIN, TH, NG, MODE, OUT_HWC, TPW>), dim3((unsigned)((images + 7) / 8 * 8 * (p.tiles / TPW))), dim3(256), 0,
                      h->stream, p);
