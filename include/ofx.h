@@ -259,8 +259,9 @@ int ofx_policy_pin_weights(ofx_handle *h, const float *weights);
 /* Diagnostic switches of the policy forward (value 0 / 1): results agree up to fp32 summation order.              */
 #define OFX_OPT_TRUNK_PLAIN 1 /* the four trunk layers through the plain VALU convolution (test reference)        */
 #define OFX_OPT_FRAMES_REF  2 /* frame lines of the head from the definition instead of the phase form (reference) */
-#define OFX_OPT_TRUNK_FUSE  4 /* conv1 -> conv2 in one kernel: 0 auto (when the images fill the CUs), 1 always, 2 never;
-                                bit-identical results either way                                                   */
+#define OFX_OPT_TRUNK_FUSE  4 /* the streaming form of the trunk (conv1 -> conv2 fused in one persistent kernel, conv3 on
+                                LDS-direct loads): 0 auto (when the images fill the CUs four times over), 1 always,
+                                2 never; bit-identical results either way                                          */
 /* NOT a diagnostic: which bilinear UpSampling2D((2,2), interpolation='bilinear') (qlearnIA_V2.py:166,172,178,184) means.
  * The reference's unpinned keras / tensorflow range admits two: 0 (default) half-pixel centres (TF2 tf.image.resize),
  * 1 the TF1 legacy resize_bilinear(align_corners=False), src = dst / 2.  Weights trained under one give a different
