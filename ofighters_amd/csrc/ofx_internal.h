@@ -61,6 +61,7 @@ struct ofx_handle {
   void *aux;                       // temporaries of ofx_dqn_targets (grown on demand)
   size_t aux_bytes;
   float *prep;                     // prepared policy weights (BN folded, phase weights, tables): ofx_policy.hip
+  float *prep_tmp;                 // the same for a blob that is not the pinned one (rebuilt per forward)
   const float *prep_pinned;        // the blob `prep` was built from while it is pinned (ofx_policy_pin_weights)
   int opt_trunk_fuse;              // OFX_OPT_TRUNK_FUSE: 0 auto, 1 always, 2 never
   int n_cus;                       // compute units of the device (grid of the persistent trunk kernel)

@@ -994,7 +994,10 @@ __global__ __launch_bounds__(F12_THREADS) void k_conv3_stream(ConvParams p, cons
   const float bias = p.b[co];
   const f32x4 binit = {bias, bias, bias, bias};
   if ((int)blockIdx.x < p.images) stage(0, (int)blockIdx.x, 0);
-  __syncthreads();  // drains the LDS-direct loads (the barrier's fence waits vmcnt(0))
+  // the LDS-direct loads are published to the other waves by vmcnt(0) BEFORE the barrier: the memory model only
+  // promises lgkmcnt(0) at a workgroup fence, so the wait is written out rather than left to the compiler
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+  __syncthreads();
   int buf = 0;
 #pragma unroll 1
   for (int img = (int)blockIdx.x; img < p.images; img += (int)gridDim.x)
@@ -1006,6 +1009,7 @@ __global__ __launch_bounds__(F12_THREADS) void k_conv3_stream(ConvParams p, cons
     if (nimg < p.images) stage(buf ^ 1, nimg, last ? 0 : R0 + C3_TH);
     ts_gemm_phase<W, C3_TH / 2, C3_LS, C3_PLS>(&tiles[buf][kq * PLS + 3], bw, binit, wv, n16, kq, r,
                                                p.out + (((size_t)img * 8 + co) * H2 + (R0 >> 1)) * H2);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the next tile's LDS-direct loads have landed (see above)
     __syncthreads();
     buf ^= 1;
   }
@@ -1159,10 +1163,13 @@ __global__ void k_policy_finish(int S, const uint8_t *mask, const unsigned long 
                                 float *ptr_max) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= S || (mask && !mask[s])) return;
-  const unsigned k = ~(unsigned)(best[s] & 0xFFFFFFFFull);
+  // best == 0: no value ever beat the initial -inf, i.e. the whole map is NaN (a diverged fit) or -inf: np.argmax
+  // answers 0 there (the first NaN / the first element) and np.max NaN / -inf; never an out-of-range pointer
+  const bool none = best[s] == 0ull;
+  const unsigned k = none ? 0u : ~(unsigned)(best[s] & 0xFFFFFFFFull);
   ipointer[2 * s] = (int)(k % PS);      // unravel_index(order='F') of a C-order flat index = (x, y)
   ipointer[2 * s + 1] = (int)(k / PS);  // qlearnIA_V2.py:218-220
-  if (ptr_max) ptr_max[s] = unordered_f32((unsigned)(best[s] >> 32));  // np.max(ptr_prediction)
+  if (ptr_max) ptr_max[s] = none ? __builtin_nanf("") : unordered_f32((unsigned)(best[s] >> 32));  // np.max(ptr_prediction)
 }
 
 // QlearnIA.play packing (qlearnIA_V2.py:447-454): exactly one of shoot / thrust, pointer always set
@@ -1245,16 +1252,18 @@ static int launch_gemm(ofx_handle *h, const float *A, int lda, const float *B, i
 static const int t_d1 = 24, t_d2 = 26, t_o1 = 28, t_ud = 30, t_up = 32, t_u4 = 50;  // tensor indices of the blob
 
 // BN folding, phase weights, tables: `weights` -> the handle's prepared-weights buffer (two small launches)
-static int policy_prepare(ofx_handle *h, const float *weights) {
+// `slot`: &h->prep (the pinned blob's buffer) or &h->prep_tmp (any other blob: a target network or a one-off forward
+// next to a pinned blob must not overwrite the pinned blob's prepared weights)
+static int policy_prepare(ofx_handle *h, const float *weights, float **slot) {
   const PrepLayout L = prep_layout();
-  if (!h->prep) {
-    OFX_HIP(hipMalloc((void **)&h->prep, sizeof(float) * L.total));
-    OFX_HIP(hipMemsetAsync(h->prep, 0, sizeof(float) * L.total, h->stream));
+  if (!*slot) {
+    OFX_HIP(hipMalloc((void **)slot, sizeof(float) * L.total));
+    OFX_HIP(hipMemsetAsync(*slot, 0, sizeof(float) * L.total, h->stream));
   }
   int32_t off[64], cnt[64];
   policy_layout(off, cnt);
   PrepParams pp;
-  pp.w = weights; pp.prep = h->prep;
+  pp.w = weights; pp.prep = *slot;
   for (int i = 0; i < 4; i++) {
     pp.src_k[i] = off[6 * i]; pp.src_b[i] = off[6 * i + 1]; pp.src_g[i] = off[6 * i + 2];
     pp.cin[i] = kTrunkCin[i]; pp.cout[i] = 8; pp.dst_w[i] = L.tw[i]; pp.dst_b[i] = L.tb[i];
@@ -1283,14 +1292,14 @@ extern "C" int ofx_policy_pin_weights(ofx_handle *h, const float *weights) {
   OFX_HIP(hipSetDevice(h->cfg.device));
   h->prep_pinned = nullptr;
   if (!weights) return OFX_OK;
-  int rc = policy_prepare(h, weights);
+  int rc = policy_prepare(h, weights, &h->prep);
   if (rc) return rc;
   h->prep_pinned = weights;
   return OFX_OK;
 }
 
 int ofx_policy_weights_updated(ofx_handle *h, const float *weights) {  // ofx_train.hip: the blob changed in place
-  if (h->prep_pinned && h->prep_pinned == weights) return policy_prepare(h, weights);
+  if (h->prep_pinned && h->prep_pinned == weights) return policy_prepare(h, weights, &h->prep);
   return OFX_OK;
 }
 
@@ -1306,7 +1315,7 @@ extern "C" int ofx_set_option(ofx_handle *h, int32_t option, int32_t value) {
       if (h->opt_bilinear_legacy == (value != 0)) return OFX_OK;
       h->opt_bilinear_legacy = value != 0;
       OFX_HIP(hipSetDevice(h->cfg.device));
-      return h->prep_pinned ? policy_prepare(h, h->prep_pinned) : OFX_OK;
+      return h->prep_pinned ? policy_prepare(h, h->prep_pinned, &h->prep) : OFX_OK;
     default: ofx_set_error("ofx_set_option: unknown option %d", option); return OFX_ERR_INVALID;
   }
 }
@@ -1326,9 +1335,10 @@ static int policy_forward_impl(ofx_handle *h, const float *weights, int N, int M
   const PrepLayout L = prep_layout();
 
   // 0. prepared weights: reused when the blob is pinned
-  if (h->prep_pinned != weights || !h->prep)
-    if ((rc = policy_prepare(h, weights))) return rc;
-  const float *prep = h->prep;
+  //    (h->prep holds exactly the pinned blob's preparation; every other blob goes through h->prep_tmp)
+  const bool pinned = h->prep && h->prep_pinned == weights;
+  if (!pinned && (rc = policy_prepare(h, weights, &h->prep_tmp))) return rc;
+  const float *prep = pinned ? h->prep : h->prep_tmp;
 
   // 1. trunk, once per arena
   ConvParams cp;

@@ -81,3 +81,95 @@ class ShardedRollout:
         for _ in range(ticks):
             self.lockstep()
         return self.score_log
+
+
+class TrainingRollout(ShardedRollout):
+    """The learning agent as a whole: `QlearnIA.play` + `Trainer` (agents/qlearnIA_V2.py:372-418, 199-287) for every
+    policy ship of every arena of the shard, in lock-step, all on the device.
+
+    One lock-step =
+        scripted bots for the other ships                                      agent.py:99-155
+        forward on the trainer's (pinned) weights -> epsilon-greedy / the      :397, :199-235
+          collecting phase's random play (first `collecting_steps` steps)      :393-395
+        transition capture (remember previous_obs ... obs, done latch)         :388-391, :401-403
+        action packing, step, rasterise                                        :447-454, battleground.py:153-166
+        epsilon decay (once per lock-step: "all bots share the same trainer")  :398-400
+        `trainer.replay(batch_size)` every `replay_every` total steps          :414-415  (total_steps % 50 == 0)
+          and on the lock-steps where a learning agent first sees its death    :376-378
+        a snapshot every `snapshot_every` episodes                             :416-417
+
+    The reference calls replay once per dying agent; the batched form does ONE replay on a lock-step with deaths (its
+    minibatch already draws from every arena's memory).  After a fit the trainer's blob has changed in place and
+    libofx re-prepares the pinned copy itself (ofx_dqn_fit -> ofx_policy_weights_updated), so the next forward plays
+    with the new weights like Keras' shared model does.
+
+    engine    ArenaBatch
+    trainer   DeviceTrainer built on that engine (owns weights, Adam state, epsilon, the replay memory)
+    policy_ships  ship slots driven by the policy (the stock line-up has ONE, lib/ofighters.py:53); the others
+              follow `behaviours`
+    """
+
+    def __init__(self, engine, trainer, behaviours, seed, policy_ships=(0,), is_learning=True, collecting_steps=20,
+                 replay_every=50, replay_on_death=True, snapshot_every=50, snapshot_folder=None, **kw):
+        super().__init__(engine, behaviours, seed, **kw)
+        self.trainer = trainer
+        self.is_learning = bool(is_learning)
+        self.collecting_steps = collecting_steps
+        self.replay_every = replay_every
+        self.replay_on_death = bool(replay_on_death)
+        self.snapshot_every = snapshot_every
+        self.snapshot_folder = snapshot_folder     # None: no files are written
+        self.total_steps = 0                       # Agent.total_steps of the learning agents (agent.py:68)
+        self.episode = 0
+        self.losses = []                           # QlearnIA.losses: history['loss'][0] = mse(output1) + mse(output2)
+        self.epsilons = []                         # QlearnIA.epsilons: one per episode (:364-365)
+        self.snapshots = []
+        from .engine import DeviceBuffer
+        mk = np.zeros((engine.N, engine.M), np.uint8)
+        mk[:, list(policy_ships)] = 1
+        self.policy_mask = mk
+        engine.sync()
+        self._mask = DeviceBuffer(mk.nbytes).upload(mk)
+        self._seen_done = np.zeros((engine.N, engine.M), bool)
+        engine.policy_pin_weights(trainer.weights.ptr)
+        self.policy = self._play
+        self.capture_tick = 0                      # ofx_replay_capture's clock: never restarts at episode ends
+
+    def _episode_end(self):
+        total = super()._episode_end()
+        self.episode += 1
+        self.epsilons.append(self.trainer.epsilon.get())
+        self._seen_done[:] = False
+        if (self.is_learning and self.snapshot_folder is not None and self.snapshot_every
+                and self.episode % self.snapshot_every == 0):
+            self.snapshots.append(self.trainer.save(id="iteration-%s" % self.episode, overwrite=True,
+                                                    folder=self.snapshot_folder))
+        return total
+
+    def _replay(self):
+        loss = self.trainer.replay()
+        if loss is not None:
+            self.losses.append(float(loss[0]) + float(loss[1]))
+        return loss
+
+    def _play(self, e):
+        """QlearnIA.play for every policy ship (the device keeps each agent's done latch and previous_*)."""
+        self.total_steps += 1                      # Agent.step increments before bot_play (agent.py:67-68)
+        t, m = self.trainer, self._mask.ptr
+        collecting = self.total_steps < self.collecting_steps
+        if self.is_learning and self.replay_on_death:
+            from . import _native as nat
+            done = (e.get(nat.F_SHIP_ALIVE) == 0) & (self.policy_mask == 1)
+            deaths = done & ~self._seen_done       # obs.done seen for the first time this lock-step (:375-378)
+            self._seen_done |= done
+            if deaths.any():
+                self._replay()
+        e.policy_forward(t.weights.ptr, m)
+        e.policy_explore(t.epsilon.get(), self.seed, tick=self.capture_tick, collecting=collecting, ship_mask_ptr=m)
+        e.replay_capture(self.capture_tick, ship_mask_ptr=m)
+        e.policy_actions(ship_mask_ptr=m)
+        self.capture_tick += 1
+        if not collecting and self.is_learning:
+            t.decay_epsilon()
+        if self.is_learning and self.replay_every and self.total_steps % self.replay_every == 0:
+            self._replay()

@@ -40,6 +40,20 @@ class DeviceTrainer:
         self.batch.sync()
         return self.weights.download(np.float32, (self.n_floats,))
 
+    def save(self, id=None, overwrite=False, folder="networks", name="bi_head_pointer"):
+        """Trainer.save (qlearnIA_V2.py:289-298): `keras-model-<name>[-<id>]` under the networks folder, as the .npz
+        of `model.get_weights()` (agents/policy_weights.py) that the facade's Trainer.load and a Keras
+        `model.set_weights(list(np.load(f).values()))` read back."""
+        import os
+        from .agents.policy_weights import save_npz
+        fname = "keras-model-" + name + ("-" + str(id) if id else "") + ".npz"
+        os.makedirs(folder, exist_ok=True)
+        path = os.path.join(folder, fname)
+        if os.path.exists(path) and not overwrite:
+            raise Exception("%s exists (overwrite=False)" % path)
+        save_npz(path, self.weights_host())
+        return path
+
     def replay(self, batch_size=None):
         """One Trainer.replay: a minibatch of min(batch_size, len(memory)) rows per arena, targets, one fit step.
         Returns (mse(output1), mse(output2)) or None while every memory is still empty."""
@@ -53,7 +67,11 @@ class DeviceTrainer:
         # the sampled transitions of all arenas, WITHOUT the -1 pads of arenas that hold fewer than bs (a pad would enter
         # the BatchNorm batch statistics and the loss scale of the fit; the reference's batch is min(bs, len(memory)) real
         # rows); one optimisation step takes a window of them that moves with the draw counter
-        n_valid = int(np.minimum(cnt, bs).sum())
+        # n_sampled, not min(len, bs): a row whose `state` frame has left the arena's frame ring is not sampled
+        b.sync()
+        n_valid = int(n_s.download(np.int32, (b.N,)).sum())
+        if n_valid == 0:
+            return None
         n = min(n_valid, int(self.fit_batch))
         start = ((self.draws - 1) * n) % (n_valid - n + 1)
         rows, bits_prev, bits_next, got = b.replay_gather_valid(slot, n_s, bs, start, n)

@@ -47,3 +47,13 @@ def test_single_rank_line_has_the_contract_fields():
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1
     assert d["cpu_baseline"]["all_cores"]["cores"] >= 1 and d["cpu_baseline"]["cpu_model"]
     assert d["config"]["episodes_in_timed_region"] >= 1
+
+
+def test_two_rank_strong_scaling_line():
+    """--scaling strong: a FIXED total (BASELINE configs[4] uses 32768; 256 here) split over the ranks by global arena id."""
+    d = _bench(["--gpus", "2", "--scaling", "strong", "--total-arenas", "256", "--steps", "24", "--warmup", "4",
+                "--no-cpu-baseline"], nproc=2, env={"OFX_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["arenas_per_gpu"] == 128
+    assert d["config"]["episodes_in_timed_region"] >= 1
+    assert d["config"]["last_episode_arenas"] == 256             # both shards' counts went through the all-reduce

@@ -52,6 +52,7 @@ def test_qlearnia_flow_on_cpu_engine():
     qlearn.TRAINER.epsilon.set(0.5)
     bg = Battleground(ships={"idle": 2, "QlearnIA": 1}, engine=OracleEngine(3))
     q = bg.ships[2].agent
+    q.is_learning = False                    # the CPU stand-in engine has no fit: forward only
     assert isinstance(q, qlearn.QlearnIA) and q.trainer is qlearn.TRAINER
     forwards = 0
     for t in range(24):
@@ -112,6 +113,7 @@ def test_qlearnia_flow_on_gpu():
     qlearn.TRAINER = qlearn.Trainer(epsilon=Epsilon_decay())
     qlearn.TRAINER.epsilon.set(0.0)           # always the network after the collecting phase
     bg = Battleground(ships={"idle": 6, "QlearnIA": 1})
+    bg.ships[6].agent.is_learning = False
     for t in range(23):
         bg.frame()
     a = bg.actions[6]

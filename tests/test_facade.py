@@ -74,7 +74,8 @@ def _qlearnia_collecting_run(engine_factory):
     def setup(bg):
         for s in bg.ships:
             if s.agent.behavior == "QlearnIA":
-                s.agent.collecting_steps = 10 ** 9       # same harness setting as oracle/gen_golden.py
+                s.agent.collecting_steps = 10 ** 9       # same harness settings as oracle/gen_golden.py
+                s.agent.is_learning = False
     try:
         replay_seeded("replay_open", engine_factory, setup)
         z = load_trace("replay_open")

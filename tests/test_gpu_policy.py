@@ -226,6 +226,45 @@ def test_pinned_weights():
     b.close()
 
 
+def test_pinned_blob_survives_a_forward_on_another_blob():
+    """A target network next to a pinned online network: with blob A pinned, a forward that names blob B must not
+    overwrite A's prepared weights - the next forward on A is bit-identical to an unpinned forward on A.  Also the
+    heat map's values: a NaN weight gives np.argmax's answer (0, 0) for an all-NaN map, never an out-of-range pointer."""
+    from ofighters_amd import DeviceBuffer
+    from oracle import pyoracle
+    N, M = 3, 4
+    b = _rollout(N, M, seed=22, ticks=15)
+    wa, _ = pyoracle.policy_init(13, trained_like=True)
+    wb, _ = pyoracle.policy_init(14, trained_like=True)
+    S = N * M
+    da_, db_ = DeviceBuffer(wa.nbytes).upload(wa), DeviceBuffer(wb.nbytes).upload(wb)
+    oa, op = DeviceBuffer(8 * S), DeviceBuffer(8 * S)
+
+    def run(w):
+        b.policy_forward(w.ptr, None, oa.ptr, None, op.ptr, None)
+        b.sync()
+        return oa.download(np.float32, (N, M, 2)), op.download(np.int32, (N, M, 2))
+
+    a_ref, p_ref = run(da_)              # unpinned
+    b_ref, q_ref = run(db_)
+    b.policy_pin_weights(da_.ptr)
+    a1, p1 = run(da_)
+    b2, q2 = run(db_)                    # another blob while A is pinned
+    a3, p3 = run(da_)                    # A again: must still be A's preparation
+    assert np.array_equal(a_ref, a1) and np.array_equal(p_ref, p1)
+    assert np.array_equal(b_ref, b2) and np.array_equal(q_ref, q2)
+    assert np.array_equal(a_ref, a3) and np.array_equal(p_ref, p3)
+    assert not np.array_equal(p_ref, q_ref)
+    # NaN in the last convolution's bias: every heat-map value is NaN
+    off, cnt, _ = b.policy_layout()
+    wn = wa.copy()
+    wn[off[51]] = np.nan
+    dn = DeviceBuffer(wn.nbytes).upload(wn)
+    _, pn = run(dn)
+    assert np.array_equal(pn, np.zeros_like(pn))
+    b.close()
+
+
 def test_policy_full_size_properties():
     """BASELINE configs[3] size (4096 x 8): determinism, mask consistency (a masked forward equals the same ships of
     a full forward), pointer range, and a sample of ships against the CPU restatement."""

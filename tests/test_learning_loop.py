@@ -1,0 +1,154 @@
+"""The learning agent as a whole (agents/qlearnIA_V2.py:372-418 `QlearnIA.play` + :240-287 `Trainer.replay`): forward ->
+epsilon-greedy -> remember -> step -> replay on the reference's schedule (every 50 total steps and at the agent's
+death) -> the next forward plays with the updated weights; snapshots every N episodes.
+
+CPU: the schedule of TrainingRollout against a recording stand-in for the engine / trainer.
+GPU: the batched loop (TrainingRollout + DeviceTrainer) learns - the TD loss falls - and the facade's
+QlearnIA(is_learning=True) trains through the same device fit."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+from ofighters_amd.rollout import TrainingRollout
+
+
+class _Buf:
+    ptr = 1
+
+
+class _Eps:
+    def __init__(self): self.v, self.n = 0.5, 0
+    def get(self): return self.v
+    def next(self): self.n += 1
+
+
+class _FakeTrainer:
+    def __init__(self):
+        self.weights, self.epsilon, self.replays, self.saved = _Buf(), _Eps(), [], []
+    def decay_epsilon(self): self.epsilon.next()
+    def replay(self):
+        self.replays.append(self.clock())
+        return (1.0, 2.0)
+    def save(self, id=None, overwrite=False, folder=None):
+        self.saved.append(id)
+        return "%s/%s" % (folder, id)
+
+
+class _FakeEngine:
+    """Records the call order of one lock-step; ship 0 of arena 1 dies at tick 7 of every episode."""
+    def __init__(self, N=3, M=2):
+        self.N, self.M, self.episode, self.log, self.t = N, M, 0, [], 0
+        self.alive = np.ones((N, M), np.uint8)
+    def sync(self): pass
+    def spawn_random(self, seed): pass
+    def restart_random(self, seed):
+        self.episode += 1; self.alive[:] = 1; self.t = 0
+    def episode_scores(self): return np.arange(self.M + 1, dtype=np.int64)
+    def policy_pin_weights(self, p): self.log.append("pin")
+    def get(self, field): return self.alive.copy()
+    def bot_actions(self, beh, seed, tick=None): self.log.append("bots")
+    def policy_forward(self, w, m): self.log.append("forward")
+    def policy_explore(self, eps, seed, tick=None, collecting=False, ship_mask_ptr=None):
+        self.log.append("explore:%d:%d" % (tick, collecting))
+    def replay_capture(self, tick, ship_mask_ptr=None): self.log.append("capture:%d" % tick)
+    def policy_actions(self, ship_mask_ptr=None): self.log.append("actions")
+    def step(self):
+        self.log.append("step"); self.t += 1
+        if self.t == 7: self.alive[1, 0] = 0
+    def rasterise(self): self.log.append("raster")
+
+
+def test_training_rollout_schedule(tmp_path, monkeypatch):
+    import ofighters_amd.engine as eng
+
+    class _DB:
+        def __init__(self, n): self.ptr = 7
+        def upload(self, a): return self
+    monkeypatch.setattr(eng, "DeviceBuffer", _DB)
+    e, t = _FakeEngine(), _FakeTrainer()
+    r = TrainingRollout(e, t, ["idle", "idle"], seed=3, policy_ships=(0,), episode_ticks=40, snapshot_every=2,
+                        snapshot_folder=str(tmp_path), collecting_steps=20, replay_every=50)
+    t.clock = lambda: r.total_steps
+    r.run(1)
+    assert e.log == ["pin", "bots", "forward", "explore:0:1", "capture:0", "actions", "step", "raster"]
+    r.run(164)                                        # 165 lock-steps: episodes end at 40, 80, 120, 160
+    # replay at the first lock-step on which a learning agent SEES its death (one after the kill: tick 8 of each
+    # episode = total steps 8, 48, 88, 128, 168 -> the last one not reached) and at total_steps % 50 == 0
+    assert t.replays == [8, 48, 50, 88, 100, 128, 150]
+    assert r.losses == [3.0] * 7
+    assert t.epsilon.n == 165 - 19                    # no decay while collecting (total_steps < 20)
+    assert [l for l in e.log if l.startswith("explore")][18:21] == ["explore:18:1", "explore:19:0", "explore:20:0"]
+    assert r.episode == 4 and len(r.score_log) == 4 and len(r.epsilons) == 4
+    assert t.saved == ["iteration-2", "iteration-4"] and len(r.snapshots) == 2
+    # capture's clock never restarts at an episode end
+    assert [l for l in e.log if l.startswith("capture")][-1] == "capture:164"
+
+
+@pytest.mark.gpu
+def test_batched_agent_learns_td_loss_falls(tmp_path):
+    """64 arenas, the stock line-up's shape (ONE policy ship, lib/ofighters.py:53) against idle targets: a few hundred
+    lock-steps with a replay every 5 total steps.  The TD loss of the fit falls, scores / losses / epsilons are
+    populated like the reference's lists, the forward plays with the weights the fit wrote, a snapshot round-trips."""
+    from ofighters_amd import ArenaBatch
+    from ofighters_amd.agents.policy_weights import load_npz, synthetic
+    from ofighters_amd.lib.epsilon import Epsilon_decay
+    from ofighters_amd.trainer import DeviceTrainer
+    N, M, seed = 64, 8, 0x0F160001
+    b = ArenaBatch(N, M)
+    w0 = synthetic(7)
+    eps = Epsilon_decay()
+    eps.set(0.3)
+    tr = DeviceTrainer(b, w0, learning_rate=1e-3, epsilon=eps, batch_size=8, memory_size=100, fit_batch=64)
+    roll = TrainingRollout(b, tr, ["idle"] * M, seed, policy_ships=(0,), episode_ticks=60, replay_every=5,
+                           snapshot_every=2, snapshot_folder=str(tmp_path))
+    roll.run(260)
+    assert roll.episode == 4 and len(roll.score_log) == 4 and len(roll.epsilons) == 4
+    assert all(int(s[M]) == N for s in roll.score_log)
+    L = np.array(roll.losses)
+    assert len(L) >= 50 and np.isfinite(L).all()
+    k = len(L) // 4
+    assert L[-k:].mean() < 0.5 * L[:k].mean(), (L[:k].mean(), L[-k:].mean())
+    w1 = tr.weights_host()
+    assert not np.array_equal(w0, w1)
+    # the rollout's forward is the pinned blob re-prepared by the fit: equal to an unpinned forward on the same values
+    pinned = b.policy_forward_host(w1)     # unpinned host path, fresh preparation
+    from ofighters_amd import DeviceBuffer
+    S = N * M
+    oa = DeviceBuffer(8 * S)
+    b.policy_forward(tr.weights.ptr, None, oa.ptr, None, None, None)
+    b.sync()
+    assert np.array_equal(oa.download(np.float32, (N, M, 2)), pinned["act"])
+    assert len(roll.snapshots) == 2 and os.path.basename(roll.snapshots[-1]) == "keras-model-bi_head_pointer-iteration-4.npz"
+    assert load_npz(roll.snapshots[-1]).shape == w0.shape
+    cnt, app = b.replay_count()
+    assert cnt.min() > 0 and app.min() >= cnt.min()
+    b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("quirks", [True, False])
+def test_facade_qlearnia_learns(quirks):
+    """QlearnIA(is_learning=True) behind the reference's API: replay every 50 total steps and at death, through the
+    device fit; `losses` fills like the reference's list and the shared Trainer's weights move."""
+    from ofighters_amd.agents import qlearn
+    from ofighters_amd.lib.battleground import Battleground, Ship
+    from ofighters_amd.lib.epsilon import Epsilon_decay
+    random.seed(2)
+    np.random.seed(2)
+    qlearn.QlearnIA.max_id = 1
+    qlearn.TRAINER = qlearn.Trainer(epsilon=Epsilon_decay(), reference_quirks=quirks)
+    w0 = qlearn.TRAINER.weights.copy()
+    bg = Battleground(ships={"turret": 2, "QlearnIA": 1})      # lib/ship.py:69-74 builds the agent
+    q = agent = bg.ships[2].agent
+    assert isinstance(q, qlearn.QlearnIA) and q.is_learning and q.trainer is qlearn.TRAINER
+    for t in range(105):
+        bg.frame()
+    n_sched = agent.total_steps // 50
+    assert len(q.losses) >= n_sched >= 2 and np.isfinite(q.losses).all()
+    assert qlearn.TRAINER.fit_steps == len(q.losses)
+    assert not np.array_equal(w0, qlearn.TRAINER.weights)
+    assert len(qlearn.TRAINER.memory) > 0
+    bg.restart()
+    assert len(agent.scores) == 1
