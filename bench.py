@@ -32,27 +32,55 @@ sys.path.insert(0, ROOT)
 SEED = 0x0F160001
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 FP32_PEAK_TF = 157.3    # fp32 vector = f32-input MFMA peak
-PMC_FILE = os.path.join("profiles", "r02_full_pmc_hbm.txt")
 METRIC = "arena-steps/sec (env.step+obs+policy fwd) at 4096 arenas, 1/2/4/8 MI355X"
 
 
-def pmc_traffic(kernel_prefix):
-    """HBM bytes per launch of a kernel from this round's committed PMC summary (rocprofv3 --pmc FETCH_SIZE /
+def pmc_files():
+    """The newest round's committed PMC summary + kernel stats (tools/final_profile.sh <tag> writes both; profiles/
+    keeps them as r<NN>_full_pmc_hbm.txt / r<NN>_full_kernel_stats.csv)."""
+    import glob
+    import re
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_full_pmc_hbm.txt")):
+        m = re.match(r"r(\d+)([a-z]?)_full_pmc_hbm\.txt$", os.path.basename(f))
+        if m and (best is None or (int(m.group(1)), m.group(2)) > best[0]):
+            best = ((int(m.group(1)), m.group(2)), f)
+    if best is None:
+        return None, None
+    return best[1], best[1].replace("_pmc_hbm.txt", "_kernel_stats.csv")
+
+
+def pmc_traffic(kernel_prefix, live_ms=None):
+    """(HBM bytes per launch of a kernel, source file) from the newest committed PMC summary (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE in separate passes of this same command, tools/final_profile.sh; counters cannot be collected from
-    inside a timed run).  FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950.  None when the file
-    or the kernel is missing - e.g. after the kernel was renamed: never a stale number."""
+    inside a timed run).  FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950.  (None, reason) when the
+    file or the kernel is missing - e.g. after the kernel was renamed - or when the kernel's duration in that round's
+    kernel stats is more than 15 % away from the one measured live (the counters describe another build): never a stale
+    number."""
+    import csv
+    pmc, stats = pmc_files()
+    if pmc is None:
+        return None, "no profiles/r*_full_pmc_hbm.txt"
     try:
         kb = {}
-        for line in open(os.path.join(ROOT, PMC_FILE)):
+        for line in open(pmc):
             f = line.rstrip("\n").split("\t")
             if len(f) == 2 and f[0].startswith(kernel_prefix) and "=" in f[1]:
                 name, val = f[1].split("=")
                 kb[name] = float(val)
-        if "FETCH_SIZE" in kb and "WRITE_SIZE" in kb:
-            return (2.0 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024.0
-    except OSError:
-        pass
-    return None
+        if not ("FETCH_SIZE" in kb and "WRITE_SIZE" in kb):
+            return None, "kernel not in " + os.path.relpath(pmc, ROOT)
+        if live_ms is not None:
+            prof_ms = None
+            for r in csv.DictReader(open(stats)):
+                if r["Name"].startswith(kernel_prefix):
+                    prof_ms = float(r["AverageNs"]) / 1e6
+                    break
+            if prof_ms is None or abs(prof_ms - live_ms) > 0.15 * live_ms:
+                return None, "stale: %s has %s ms for this kernel, live %.3f ms" % (os.path.relpath(stats, ROOT), prof_ms, live_ms)
+        return (2.0 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024.0, os.path.relpath(pmc, ROOT)
+    except (OSError, KeyError, ValueError) as e:
+        return None, "unreadable: %s" % e
 
 
 def cpu_model():
@@ -65,28 +93,10 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_policy_sample(pyoracle, cfg, w, arenas, ticks, n_pol, seed):
-    """CPU-oracle leg of the full workload for the given global arenas: per tick and arena, n_pol policy forwards (the
-    oracle has no trunk sharing: one full forward per ship, like the reference), step, rasterise."""
-    import numpy as np
-    M = cfg.n_ships
-    for g in arenas:
-        a = pyoracle.Arena(cfg=cfg)
-        a.spawn(pyoracle.reset_draws(cfg, seed, g, 0))
-        for t in range(ticks):
-            sm, lm = a.rasterise()
-            head, _ = a.obs_head()
-            act = a.bot_actions(np.ones(M, np.int32), seed, g, t)
-            for i in range(n_pol):
-                _, _, ia, ip = pyoracle.policy_forward(sm, lm, head[i].astype(np.float32), w, want_heat=False)
-                act[i, 1], act[i, 2], act[i, 3], act[i, 4] = int(ia == 0), int(ia == 1), ip[0], ip[1]
-            a.step(act)
-
-
 def cpu_baseline(workload, M, n_pol, w_host, ep_ticks):
-    """The C oracle (a port) on the box's host cores: one thread, then all cores (threads over arenas: the C calls
-    release the GIL).  Bounded samples of the same workload."""
-    from concurrent.futures import ThreadPoolExecutor
+    """The C oracle (a port) on the box's host cores: one thread, then all cores - both as ONE C call
+    (oracle/ofx_oracle.c orc_bench_run: POSIX threads over arenas, no Python in the loop).  Bounded samples of the same
+    workload; the policy legs run one full forward per policy ship (no trunk sharing), like the reference."""
     from oracle import pyoracle
     cfg = pyoracle.default_cfg(M)
     cores = os.cpu_count() or 1
@@ -94,34 +104,31 @@ def cpu_baseline(workload, M, n_pol, w_host, ep_ticks):
         cores = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         pass
-
+    try:  # a container's CPU quota (cgroup v2 cpu.max = "<quota> <period>"): more threads than that only contend
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
     if workload == "step+obs+policy":
-        t_s = 2
-
-        def run(arenas):
-            cpu_policy_sample(pyoracle, cfg, w_host, arenas, t_s, n_pol, SEED)
-        n_one, n_all = 8, max(64, 4 * cores) // t_s      # 16 arena-steps on one thread, >= 64 over all cores
+        # ~0.27 s per arena-step with 8 forwards on one core: 64 arena-steps on one thread, 4 per thread on all cores
+        n_one, t_one, n_all, t_all, obs, pol = 8, 8, cores, 4, 1, n_pol
+    elif workload == "step+obs":
+        n_one, t_one, n_all, t_all, obs, pol = 2048, 200, 512 * cores, 200, 1, 0
     else:
-        t_s = 200
-        do_obs = workload == "step+obs"
-
-        def run(arenas):
-            pyoracle.run_random(cfg, len(arenas), t_s, SEED, int(do_obs), ep_ticks)
-        n_one, n_all = (1024, 1024 * cores) if do_obs else (4096, 4096 * cores)
-
+        n_one, t_one, n_all, t_all, obs, pol = 8192, 200, 2048 * cores, 200, 0, 0
     c0 = time.perf_counter()
-    run(list(range(n_one)))
-    one = n_one * t_s / (time.perf_counter() - c0)
-    chunks = [list(range(i, n_all, cores)) for i in range(cores)]
+    pyoracle.bench_run(cfg, w_host, n_one, t_one, SEED, obs, ep_ticks, pol, 1)
+    d_one = time.perf_counter() - c0
     c0 = time.perf_counter()
-    with ThreadPoolExecutor(cores) as ex:
-        list(ex.map(run, chunks))
-    allc = n_all * t_s / (time.perf_counter() - c0)
+    pyoracle.bench_run(cfg, w_host, n_all, t_all, SEED, obs, ep_ticks, pol, cores)
+    d_all = time.perf_counter() - c0
     return {
-        "value": one, "unit": "arena-steps/s", "cores": 1, "kind": "port",
-        "sample": "%d arenas x %d ticks of the same workload (C oracle, single thread)" % (n_one, t_s),
-        "all_cores": {"value": allc, "cores": cores,
-                      "sample": "%d arenas x %d ticks, threads over arenas" % (n_all, t_s)},
+        "value": n_one * t_one / d_one, "unit": "arena-steps/s", "cores": 1, "kind": "port",
+        "sample": "%d arenas x %d ticks of the same workload (C oracle, single thread, %.1f s)" % (n_one, t_one, d_one),
+        "all_cores": {"value": n_all * t_all / d_all, "cores": cores,
+                      "sample": "%d arenas x %d ticks, %d POSIX threads over arenas in one C call, %.1f s"
+                                % (n_all, t_all, cores, d_all)},
         "cpu_model": cpu_model(),
     }
 
@@ -156,7 +163,8 @@ class Workload:
         self.roll = ShardedRollout(b, ["random"] * M, SEED, episode_ticks=ep_ticks, dist=dist, observe=self.do_obs,
                                    policy=self._policy if self.do_policy else None,
                                    to_tensor=lambda a: torch.from_numpy(a.copy()).cuda(), start_tick=start_tick,
-                                   probe=self._probe)
+                                   probe=self._probe, use_rollout=not self.do_policy)
+        self.chunks = []   # lock-steps per ofx_rollout call of the timed region (headless workloads)
 
     def _policy(self, e):
         # request_actions: the policy ships' actions overwrite the scripted ones
@@ -167,11 +175,14 @@ class Workload:
             self.ev += 2
         e.policy_actions(ship_mask_ptr=self.mask_ptr)
 
-    def _probe(self, stage, begin):
-        if self.timed and stage == self.stage and self.ev < 60000:
-            self.b.event_record(self.ev if begin else self.ev + 1)
-            if not begin:
-                self.ev += 2
+    def _probe(self, stage, begin, n=1):
+        # headless workloads (no policy): K lock-steps per ofx_rollout call; the library itself brackets the call's
+        # dominant kernel with one event pair (the K-tick k_step launch / the last lock-step's k_raster)
+        if self.timed and stage == self.stage and begin and self.ev < 60000:
+            if self.ev == 0:
+                self.b.policy_profile(0)
+            self.chunks.append(n)
+            self.ev += 2
 
     def run(self, warmup, steps, fence, torch, dist):
         self.roll.run(warmup)
@@ -190,7 +201,11 @@ class Workload:
             dt = float(tmax.item())
         n_ev = min(self.ev // 2, 30000)
         k_ms = [self.b.event_elapsed(2 * i, 2 * i + 1) for i in range(n_ev)]
-        return dt, (float(self.np.mean(k_ms)) if k_ms else float("nan"))
+        if not k_ms:
+            return dt, float("nan")
+        if self.stage == "step":     # one launch = chunks[i] lock-steps: report the time per lock-step
+            return dt, float(self.np.sum(k_ms) / max(1, sum(self.chunks[:n_ev])))
+        return dt, float(self.np.mean(k_ms))
 
     def roofline(self, k_avg_ms, dt, steps, full_config):
         b, np, nat = self.b, self.np, self.nat
@@ -207,7 +222,7 @@ class Workload:
             ach = alg / (k_avg_ms * 1e-3) / 1e12
             r = {"bound": "mfma", "kernel": "k_head_stream", "achieved": ach, "peak": FP32_PEAK_TF, "unit": "TFLOP/s",
                  "frac": ach / FP32_PEAK_TF,
-                 "traffic": pmc_traffic("k_head_stream") if full_config else None,
+                 "traffic": None,
                  "avg_kernel_ms": k_avg_ms, "algorithmic_flops_per_launch": alg,
                  "note": "fp32 (exact f32-input MFMA + fp32 VALU, both 157.3 TFLOP/s peak); whole tick = %.0f GFLOP dense "
                          "algorithmic (trunk once per arena + per-ship heads) = %.1f TFLOP/s over ms_per_step = %.3f of peak"
@@ -216,15 +231,20 @@ class Workload:
             if self.do_obs:
                 kernel, alg = "k_raster<u8>", N * 2 * b.W * b.H * 1   # two u8 maps written per arena (SURVEY 8d cfg 3)
             else:
-                kernel, alg = "k_step", N * 3200                       # SURVEY 8d cfg 2: ~3.2 KB per arena-step
+                kernel, alg = "k_step<bots>", N * 3200                 # SURVEY 8d cfg 2: ~3.2 KB per arena-step
             ach = alg / (k_avg_ms * 1e-3) / 1e9
             r = {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                  "frac": ach / HBM_PEAK_GBS,
-                 "traffic": pmc_traffic("void k_raster<0>") if (full_config and self.do_obs) else None,
+                 "traffic": None,
                  "avg_kernel_ms": k_avg_ms, "algorithmic_bytes_per_launch": alg}
-        if r["traffic"] is not None:
+            if not self.do_obs:
+                r["note"] = ("ofx_rollout: all lock-steps up to the next episode end run inside ONE k_step launch (bots' law "
+                             "in the kernel); avg_kernel_ms / algorithmic bytes are per lock-step = launch time / its "
+                             "lock-steps (launches of %s lock-steps)" % sorted(set(self.chunks)))
+        if full_config and (self.do_policy or self.do_obs):
+            r["traffic"], src = pmc_traffic("k_head_stream" if self.do_policy else "void k_raster<0>", k_avg_ms)
             r["traffic_source"] = ("HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE in separate "
-                                   "passes of this command: " + PMC_FILE)
+                                   "passes of this command: " + src) if r["traffic"] is not None else "none (%s)" % src
         return r
 
     def describe(self):

@@ -198,6 +198,18 @@ int ofx_observe_head(ofx_handle *h, double *head, uint8_t *done);
 int ofx_bot_actions(ofx_handle *h, const int32_t *behaviours_host, uint64_t seed,
                     uint32_t tick, ofx_action *actions);
 
+/* ---- the headless loop ---------------------------------------------------
+ * Battleground.run (lib/battleground.py:169-173) for arenas flown by the scripted bots: n_ticks lock-steps of
+ * request_actions (the ofx_bot_actions law, counter ticks tick0 .. tick0 + n_ticks - 1) -> generate_frame (ofx_step)
+ * -> Observation(battleground) (ofx_rasterise into the handle's maps of observe_map_type, or -1 = no maps) enqueued by
+ * ONE host call; state afterwards is bit-identical to n_ticks x (ofx_bot_actions, ofx_step[, ofx_rasterise]).  The
+ * bots' law is evaluated inside the step kernel, and without an observer between them all n_ticks lock-steps run
+ * inside one launch (an arena belongs to one wavefront for the whole launch).  Episode ends stay with the caller
+ * (ofx_restart* between two calls).  With ofx_policy_profile switched on, one event pair brackets the call's
+ * dominant kernel (the K-tick step launch, or the last lock-step's rasteriser).                                  */
+int ofx_rollout(ofx_handle *h, const int32_t *behaviours_host, uint64_t seed, uint32_t tick0, int32_t n_ticks,
+                int32_t observe_map_type);
+
 /* ---- state access ------------------------------------------------------ */
 int ofx_get_host(ofx_handle *h, int field, void *dst_host, size_t bytes);
 void *ofx_device_ptr(ofx_handle *h, int field);
@@ -212,6 +224,11 @@ int ofx_overflow_count(ofx_handle *h, int64_t *count_host);
  * scores.append(score), agents/agent.py:61-63) and, last, the arena count.
  * The caller all-reduces it (RCCL via torch.distributed).                    */
 int ofx_episode_scores(ofx_handle *h, int64_t *sums);
+/* The same followed by the all-reduce itself, for a host that is not torch: ncclAllReduce(sum, int64, in place) of the
+ * [M+1] vector over the ranks of `nccl_comm` - an ncclComm_t the caller made with ncclCommInitRank, one rank per GPU
+ * (RCCL over xGMI) - enqueued on the handle's stream.  libofx.so does not link RCCL; the symbol is resolved in the
+ * process (or librccl.so.1 is opened) at the first call.  SURVEY 8b / 8e: the only collective of the path.          */
+int ofx_scores_allreduce(ofx_handle *h, void *nccl_comm, int64_t *sums);
 
 /* ---- scratch MLP forward -----------------------------------------------
  * Neural_network.feed (agents/neural_network.py:396-420): a <- sigmoid(W a + b)

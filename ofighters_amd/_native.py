@@ -89,11 +89,13 @@ SIGNATURES = {
     "ofx_map_ptr": (_vp, [_vp, _i, _i]),
     "ofx_observe_head": (_i, [_vp, _vp, _vp]),
     "ofx_bot_actions": (_i, [_vp, _vp, _u64, _u32, _vp]),
+    "ofx_rollout": (_i, [_vp, _vp, _u64, _u32, C.c_int32, C.c_int32]),
     "ofx_get_host": (_i, [_vp, _i, _vp, _sz]),
     "ofx_device_ptr": (_vp, [_vp, _i]),
     "ofx_field_bytes": (_sz, [_vp, _i]),
     "ofx_overflow_count": (_i, [_vp, C.POINTER(C.c_int64)]),
     "ofx_episode_scores": (_i, [_vp, _vp]),
+    "ofx_scores_allreduce": (_i, [_vp, _vp, _vp]),
     "ofx_scratch_feed": (_i, [_vp, _vp, C.c_int32, _vp, _vp, _vp, C.c_int32, _vp, _vp]),
     "ofx_scratch_feed_obs": (_i, [_vp, _vp, C.c_int32, _vp, _vp, _vp, _vp]),
     "ofx_policy_layout": (_i, [_vp, C.POINTER(OfxPolicyDesc)]),

@@ -394,6 +394,49 @@ extern "C" int ofx_bot_actions(ofx_handle *h, const int32_t *behaviours_host, ui
   return OFX_OK;
 }
 
+// ------------------------------------------------ headless loop: K lock-steps per host call
+// Battleground.run (lib/battleground.py:169-173: `while True: self.frame()`) for the scripted bots: request_actions,
+// generate_frame and - when observing - Observation(battleground) for n_ticks lock-steps enqueued by ONE call.
+int ofx_launch_step_bots(ofx_handle *h, uint64_t seed, uint32_t tick0, int n_ticks);  // ofx_step.hip
+
+extern "C" int ofx_rollout(ofx_handle *h, const int32_t *behaviours_host, uint64_t seed, uint32_t tick0, int32_t n_ticks,
+                           int32_t observe_map_type) {
+  if (!h || !behaviours_host) { ofx_set_error("ofx_rollout: null argument"); return OFX_ERR_INVALID; }
+  if (!h->spawned) { ofx_set_error("ofx_rollout before ofx_spawn"); return OFX_ERR_STATE; }
+  if (n_ticks < 0 || observe_map_type < -1 || observe_map_type > OFX_MAP_BITS) {
+    ofx_set_error("ofx_rollout: n_ticks must be >= 0 and observe_map_type -1 (none) or an OFX_MAP_* type");
+    return OFX_ERR_INVALID;
+  }
+  for (int i = 0; i < h->cfg.n_ships; i++)
+    if (behaviours_host[i] < OFX_BOT_IDLE || behaviours_host[i] > OFX_BOT_SHOOT) {
+      ofx_set_error("You must give a bot in parameter or select an existing behavior.");  // agents/agent.py:51
+      return OFX_ERR_INVALID;
+    }
+  if (n_ticks == 0) return OFX_OK;
+  OFX_HIP(hipSetDevice(h->cfg.device));
+  OFX_HIP(hipMemcpyAsync(h->bot_behaviours, behaviours_host, sizeof(int32_t) * h->cfg.n_ships, hipMemcpyHostToDevice,
+                         h->stream));
+  int rc;
+  const int pb = h->prof_base;  // ofx_policy_profile: one event pair around this call's dominant kernel
+  const bool prof = pb >= 0 && pb + 1 < OFX_RING_MAX;
+  if (observe_map_type < 0) {
+    // no observer between the lock-steps: all of them inside ONE launch (an arena belongs to one wavefront)
+    if (prof && (rc = ofx_event_record(h, pb))) return rc;
+    if ((rc = ofx_launch_step_bots(h, seed, tick0, n_ticks))) return rc;
+    if (prof && (rc = ofx_event_record(h, pb + 1))) return rc;
+  } else {
+    for (int t = 0; t < n_ticks; t++) {
+      if ((rc = ofx_launch_step_bots(h, seed, tick0 + (uint32_t)t, 1))) return rc;
+      const bool last = t + 1 == n_ticks;  // the rasteriser of the last lock-step stands for the launch pair
+      if (prof && last && (rc = ofx_event_record(h, pb))) return rc;
+      if ((rc = ofx_launch_raster(h, observe_map_type, nullptr, nullptr))) return rc;
+      if (prof && last && (rc = ofx_event_record(h, pb + 1))) return rc;
+    }
+  }
+  if (pb >= 0) h->prof_base = pb + 3 < OFX_RING_MAX ? pb + 2 : -1;
+  return OFX_OK;
+}
+
 // ------------------------------------------------------------------ obs head
 // Observation.analyse_ship + toVector head (observation.py:101-123)
 __global__ void k_obs_head(int N, int M, int W, int H, ofx_state st, double *head, uint8_t *done) {
@@ -523,6 +566,32 @@ extern "C" int ofx_episode_scores(ofx_handle *h, int64_t *sums) {
   OFX_HIP(hipSetDevice(h->cfg.device));
   OFX_HIP(hipMemcpyAsync(sums, h->st.episode_sums, sizeof(int64_t) * (h->cfg.n_ships + 1), hipMemcpyDeviceToDevice,
                          h->stream));
+  return OFX_OK;
+}
+
+// The one collective of the path for a C consumer of libofx.so: ofx_episode_scores + an in-place RCCL sum over the
+// ranks of `nccl_comm` (an ncclComm_t the caller created with ncclCommInitRank, one rank per GPU), on the handle's
+// stream.  libofx.so does not link RCCL: ncclAllReduce is looked up in the process at the first call (the library the
+// caller's communicator came from; otherwise librccl.so.1 is opened), so a single-GPU user never loads it.
+#include <dlfcn.h>
+typedef int (*ofx_nccl_allreduce_fn)(const void *, void *, size_t, int, int, void *, hipStream_t);
+extern "C" int ofx_scores_allreduce(ofx_handle *h, void *nccl_comm, int64_t *sums) {
+  if (!h || !nccl_comm || !sums) { ofx_set_error("ofx_scores_allreduce: null argument"); return OFX_ERR_INVALID; }
+  static ofx_nccl_allreduce_fn fn = nullptr;
+  if (!fn) {
+    fn = (ofx_nccl_allreduce_fn)dlsym(RTLD_DEFAULT, "ncclAllReduce");
+    if (!fn) {
+      void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+      if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+      if (lib) fn = (ofx_nccl_allreduce_fn)dlsym(lib, "ncclAllReduce");
+    }
+    if (!fn) { ofx_set_error("ofx_scores_allreduce: ncclAllReduce not found (librccl.so is not loadable)"); return OFX_ERR_STATE; }
+  }
+  int rc = ofx_episode_scores(h, sums);
+  if (rc) return rc;
+  const int kNcclInt64 = 4, kNcclSum = 0;  // rccl.h: ncclDataType_t ncclInt64 = 4, ncclRedOp_t ncclSum = 0
+  const int e = fn(sums, sums, (size_t)h->cfg.n_ships + 1, kNcclInt64, kNcclSum, nccl_comm, h->stream);
+  if (e != 0) { ofx_set_error("ofx_scores_allreduce: ncclAllReduce failed with ncclResult_t %d", e); return OFX_ERR_HIP; }
   return OFX_OK;
 }
 

@@ -33,7 +33,12 @@ struct StepParams {
   int r_death, r_kill, r_aim, r_traj;
   double hit_thresh;
   ofx_state st;
-  const ofx_action *actions;
+  const ofx_action *actions;   // BOTS = false: the caller's actions [N][M]
+  // BOTS = true (ofx_rollout): the scripted bots' action law evaluated in the kernel (agents/agent.py:99-155 on the
+  // counter RNG, the same draws as k_bots) for lock-steps tick0 .. tick0 + n_ticks - 1, all inside ONE launch
+  const int32_t *beh;          // device [M] OFX_BOT_*
+  uint32_t k0, k1, tick0;
+  int n_ticks, arena_base;
 };
 
 // CPython float_rem: fmod, then the result takes the divisor's sign (b > 0 here)
@@ -49,16 +54,54 @@ __device__ inline double py_fmod_pos(double a, double b) {
 
 __device__ inline int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 
+// The scripted bots' law for ship `i` of global arena `ga` at lock-step `tick` - the arithmetic of k_bots
+// (ofx_api.hip), evaluated by the ship's own lane: `alive` / (ptx, pty) are the ship's state when request_actions
+// runs, i.e. before this lock-step's lasers move (battleground.py:146-150).
+__device__ inline ofx_action bot_action(int beh, uint32_t ga, uint32_t i, uint32_t tick, uint32_t k0, uint32_t k1, int W,
+                                        int H, bool alive, int ptx, int pty) {
+  uint32_t r[4];
+  ofx_philox4x32_10(ga, i, tick, OFX_STREAM_BOT, k0, k1, r);
+  bool shoot = false, thrust = false, repoint = false;
+  const double u0 = (double)r[0] * (1.0 / 4294967296.0), u1 = (double)r[1] * (1.0 / 4294967296.0);
+  switch (beh) {
+    case OFX_BOT_RANDOM: {
+      const uint32_t k = (uint32_t)(((uint64_t)r[0] * 3u) >> 32);
+      shoot = k == 0; thrust = k == 1; repoint = k == 2;
+    } break;
+    case OFX_BOT_TURRET: shoot = u0 < 0.8; repoint = u1 < 0.3; break;
+    case OFX_BOT_RUNNER: thrust = u0 < 0.9; repoint = u1 < 0.1; break;
+    case OFX_BOT_THRUST: thrust = true; break;
+    case OFX_BOT_SHOOT: shoot = true; break;
+    default: break;
+  }
+  ofx_action act;
+  act.px = ptx; act.py = pty;
+  act.shoot = 0; act.thrust = 0; act.valid = alive ? 1 : 0; act._pad = 0;
+  if (alive) {
+    act.shoot = shoot; act.thrust = thrust;
+    if (repoint) { act.px = ofx_draw_int(r[2], W); act.py = ofx_draw_int(r[3], H); }
+  }
+  return act;
+}
+
+template <bool BOTS>
 __global__ __launch_bounds__(256) void k_step(StepParams p) {
   const int lane = threadIdx.x & 63;
   const int a = blockIdx.x * OFX_ARENAS_PER_BLOCK + (threadIdx.x >> 6);
   if (a >= p.N) return;  // wave-uniform; the kernel has no block-level barrier
   const int M = p.M, L = p.L;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
-
-  // ---- ships into registers (lane i == ship i) + Agent.step bookkeeping ----
   const bool is_ship = lane < M;
   const size_t si = (size_t)a * M + (is_ship ? lane : 0);
+  const int my_beh = BOTS && is_ship ? p.beh[lane] : 0;
+  const int n_ticks = BOTS ? p.n_ticks : 1;
+#pragma unroll 1
+  for (int tk = 0; tk < n_ticks; tk++) {
+  // An arena belongs to ONE wave for the whole launch, so the lock-steps of a K-tick launch only need this wave's own
+  // stores of lock-step t to be visible to its loads of lock-step t + 1: program order within a wavefront.
+  if (BOTS && tk) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+  // ---- ships into registers (lane i == ship i) + Agent.step bookkeeping ----
   int x = 0, y = 0, ptx = 0, pty = 0, hull = 0, rew = 0, sc = 0, killer = -1;
   bool alive = false;
   if (is_ship) {
@@ -74,6 +117,9 @@ __global__ __launch_bounds__(256) void k_step(StepParams p) {
     sc += rew;                  // agent.py:73-74
     rew = 0;
   }
+  ofx_action bot_act;           // request_actions comes before generate_frame: the state the lasers have not touched yet
+  if (BOTS) bot_act = bot_action(my_beh, (uint32_t)(p.arena_base + a), (uint32_t)lane, p.tick0 + (uint32_t)tk, p.k0, p.k1,
+                                 p.W, p.H, alive, ptx, pty);
   unsigned long long alive_mask = __ballot(alive);
 
   // ---- laser phase ----
@@ -139,7 +185,7 @@ __global__ __launch_bounds__(256) void k_step(StepParams p) {
   int ex = 0, ey = 0;
   double ndx = 0, ndy = 0;
   if (is_ship) {
-    const ofx_action act = p.actions[si];
+    const ofx_action act = BOTS ? bot_act : p.actions[si];
     if (act.valid && alive) {  // ship.py:308
       ptx = act.px;
       pty = act.py;
@@ -261,9 +307,10 @@ __global__ __launch_bounds__(256) void k_step(StepParams p) {
     p.st.n_lasers[a] = out;
     p.st.time[a] += 1;
   }
+  }  // lock-steps of this launch
 }
 
-int ofx_launch_step(ofx_handle *h, const ofx_action *actions) {
+static StepParams step_params(ofx_handle *h) {
   StepParams p;
   const ofx_config &c = h->cfg;
   p.N = c.n_arenas; p.M = c.n_ships; p.L = c.laser_cap; p.W = c.width; p.H = c.height;
@@ -272,9 +319,26 @@ int ofx_launch_step(ofx_handle *h, const ofx_action *actions) {
   p.r_death = c.reward_death; p.r_kill = c.reward_kill; p.r_aim = c.reward_aim; p.r_traj = c.reward_trajectory;
   p.hit_thresh = h->hit_thresh;
   p.st = h->st;
+  p.actions = nullptr; p.beh = nullptr; p.k0 = p.k1 = p.tick0 = 0; p.n_ticks = 1; p.arena_base = c.arena_base;
+  return p;
+}
+
+int ofx_launch_step(ofx_handle *h, const ofx_action *actions) {
+  StepParams p = step_params(h);
   p.actions = actions;
-  const int blocks = (c.n_arenas + OFX_ARENAS_PER_BLOCK - 1) / OFX_ARENAS_PER_BLOCK;
-  hipLaunchKernelGGL(k_step, dim3(blocks), dim3(256), 0, h->stream, p);
+  const int blocks = (h->cfg.n_arenas + OFX_ARENAS_PER_BLOCK - 1) / OFX_ARENAS_PER_BLOCK;
+  hipLaunchKernelGGL(k_step<false>, dim3(blocks), dim3(256), 0, h->stream, p);
+  OFX_HIP(hipGetLastError());
+  return OFX_OK;
+}
+
+// n_ticks lock-steps of bots + step in ONE launch (h->bot_behaviours already holds the behaviours)
+int ofx_launch_step_bots(ofx_handle *h, uint64_t seed, uint32_t tick0, int n_ticks) {
+  StepParams p = step_params(h);
+  p.beh = h->bot_behaviours;
+  p.k0 = (uint32_t)seed; p.k1 = (uint32_t)(seed >> 32); p.tick0 = tick0; p.n_ticks = n_ticks;
+  const int blocks = (h->cfg.n_arenas + OFX_ARENAS_PER_BLOCK - 1) / OFX_ARENAS_PER_BLOCK;
+  hipLaunchKernelGGL(k_step<true>, dim3(blocks), dim3(256), 0, h->stream, p);
   OFX_HIP(hipGetLastError());
   return OFX_OK;
 }

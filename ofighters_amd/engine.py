@@ -175,6 +175,18 @@ class ArenaBatch:
                                             self.tick if tick is None else tick, out_ptr))
         return out_ptr
 
+    def rollout(self, behaviours, seed, tick0, n_ticks, observe=None):
+        """Battleground.run for scripted bots (battleground.py:169-173): n_ticks lock-steps enqueued by ONE host call
+        (ofx_rollout); `observe` = a nat.MAP_* type to rasterise after every lock-step, None = step only (all lock-steps
+        inside one kernel launch).  Bit-identical to n_ticks x (bot_actions, step[, rasterise])."""
+        b = np.array([nat.BEHAVIOURS[x] if not isinstance(x, (int, np.integer)) else int(x) for x in behaviours],
+                     dtype=np.int32)
+        if b.shape != (self.M,):
+            raise Exception("behaviours must have one entry per ship")
+        nat.check(nat.lib().ofx_rollout(self._h, b.ctypes.data_as(C.c_void_p), seed, int(tick0), int(n_ticks),
+                                        -1 if observe is None else int(observe)))
+        self.tick += int(n_ticks)
+
     def actions_host(self):
         self.sync()
         return self._actions.download(ACTION_DTYPE, (self.N, self.M))

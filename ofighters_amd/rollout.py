@@ -35,7 +35,7 @@ class ShardedRollout:
     """
 
     def __init__(self, engine, behaviours, seed, episode_ticks=200, dist=None, observe=True, policy=None,
-                 to_tensor=None, start_tick=0, probe=None):
+                 to_tensor=None, start_tick=0, probe=None, use_rollout=False):
         self.e = engine
         self.behaviours = list(behaviours)
         self.seed = seed
@@ -44,7 +44,8 @@ class ShardedRollout:
         self.observe = observe
         self.policy = policy          # callable(engine) -> None: overwrite the policy ships' actions
         self.to_tensor = to_tensor    # numpy [M+1] int64 -> tensor usable by dist.all_reduce
-        self.probe = probe            # callable(stage, begin) around "step" / "obs" (bench.py: HIP events) or None
+        self.probe = probe            # callable(stage, begin[, n_ticks]) around "step" / "obs" (bench.py) or None
+        self.use_rollout = use_rollout  # without a policy: K lock-steps per host call through engine.rollout
         self.tick = start_tick        # a start inside an episode puts its end where the caller wants it (bench.py)
         self.score_log = []           # all-reduced [M+1] per finished episode
         self.e.spawn_random(seed)
@@ -78,8 +79,29 @@ class ShardedRollout:
         self.tick += 1
 
     def run(self, ticks):
+        if self.policy is None and self.use_rollout and hasattr(self.e, "rollout"):
+            return self._run_headless(ticks)
         for _ in range(ticks):
             self.lockstep()
+        return self.score_log
+
+    def _run_headless(self, ticks):
+        """Scripted bots only: whole runs of lock-steps up to the next episode end go down in ONE host call
+        (ofx_rollout, the batched Battleground.run of battleground.py:169-173); the restart + score all-reduce at the
+        episode ends are the same code as in lockstep()."""
+        from . import _native as nat
+        left = ticks
+        while left > 0:
+            if self.tick > 0 and self.tick % self.episode_ticks == 0:
+                self._episode_end()
+            n = min(left, self.episode_ticks - self.tick % self.episode_ticks)
+            p = self.probe
+            stage = "obs" if self.observe else "step"
+            if p: p(stage, True, n)     # n lock-steps go down in this one call
+            self.e.rollout(self.behaviours, self.seed, self.tick, n, nat.MAP_U8 if self.observe else None)
+            if p: p(stage, False, n)
+            self.tick += n
+            left -= n
         return self.score_log
 
 

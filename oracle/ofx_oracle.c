@@ -545,3 +545,88 @@ uint64_t orc_run_random(const orc_cfg *cfg, int n_arenas, int ticks, uint64_t se
   free(beh); free(act); free(draws); free(m0); free(m1);
   return sum;
 }
+
+/* ---- bench.py's cpu_baseline legs as ONE C call (test infrastructure, like the rest of this file) -----------------
+ * The same per-arena loop as orc_run_random, optionally with n_pol policy forwards per lock-step (no trunk sharing:
+ * one full forward per ship, like the reference's model.predict per QlearnIA, agents/qlearnIA_V2.py:210), spread over
+ * n_threads POSIX threads by arena (arena g goes to thread g % n_threads).  weights may be NULL when n_pol == 0.    */
+#include <pthread.h>
+void orc_policy_forward2(const uint8_t *ship_map, const uint8_t *laser_map, const float *vec8, const float *w,
+                         float *act_values, float *heat, int32_t *iaction, int32_t *ipointer, int legacy);
+
+typedef struct {
+  const orc_cfg *cfg; const float *w;
+  int first, stride, n_arenas, ticks, do_raster, episode_ticks, n_pol;
+  uint64_t seed, sum;
+} orc_bench_job;
+
+static void *orc_bench_thread(void *arg) {
+  orc_bench_job *j = (orc_bench_job *)arg;
+  const orc_cfg *cfg = j->cfg;
+  int M = cfg->n_ships;
+  int32_t *beh = (int32_t *)malloc(sizeof(int32_t) * (size_t)M);
+  int32_t *act = (int32_t *)malloc(sizeof(int32_t) * 5 * (size_t)M);
+  int32_t *draws = (int32_t *)malloc(sizeof(int32_t) * 2 * (size_t)M);
+  double *head = (double *)malloc(sizeof(double) * 8 * (size_t)M);
+  uint8_t *done = (uint8_t *)malloc((size_t)M);
+  size_t cells = (size_t)cfg->width * cfg->height;
+  uint8_t *m0 = (uint8_t *)malloc(cells), *m1 = (uint8_t *)malloc(cells);
+  uint64_t sum = 0;
+  for (int i = 0; i < M; i++) beh[i] = 1;
+  for (int g = j->first; g < j->n_arenas; g += j->stride) {
+    orc_arena *a = orc_create(cfg);
+    orc_reset_draws(cfg, j->seed, (uint32_t)g, 0, draws);
+    orc_spawn(a, draws);
+    uint32_t episode = 0;
+    for (int t = 0; t < j->ticks; t++) {
+      if (j->episode_ticks > 0 && t > 0 && t % j->episode_ticks == 0) {
+        episode++;
+        orc_reset_draws(cfg, j->seed, (uint32_t)g, episode, draws);
+        orc_restart(a, draws);
+      }
+      orc_bot_actions(a, beh, j->seed, (uint32_t)g, (uint32_t)t, act);
+      if (j->n_pol > 0) {  /* the policy ships see the observation of the previous lock-step */
+        orc_rasterise(a, m0, m1);
+        orc_obs_head(a, head, done);
+        for (int i = 0; i < j->n_pol && i < M; i++) {
+          float v8[8], av[2];
+          int32_t ia, ip[2];
+          for (int k = 0; k < 8; k++) v8[k] = (float)head[8 * i + k];
+          orc_policy_forward2(m0, m1, v8, j->w, av, NULL, &ia, ip, 0);
+          act[5 * i + 1] = ia == 0; act[5 * i + 2] = ia == 1; act[5 * i + 3] = ip[0]; act[5 * i + 4] = ip[1];
+        }
+      }
+      orc_step(a, act);
+      if (j->do_raster) {
+        orc_rasterise(a, m0, m1);
+        sum += m0[cells / 2] + m1[cells / 3];
+      }
+      for (int i = 0; i < M; i++) sum += (uint64_t)(a->ships[i].x * 3 + a->ships[i].y + a->ships[i].reward);
+      sum += (uint64_t)a->n_lasers;
+    }
+    orc_destroy(a);
+  }
+  free(beh); free(act); free(draws); free(head); free(done); free(m0); free(m1);
+  j->sum = sum;
+  return NULL;
+}
+
+uint64_t orc_bench_run(const orc_cfg *cfg, const float *weights, int n_arenas, int ticks, uint64_t seed, int do_raster,
+                       int episode_ticks, int n_pol, int n_threads) {
+  if (n_threads < 1) n_threads = 1;
+  orc_bench_job *jobs = (orc_bench_job *)calloc((size_t)n_threads, sizeof(orc_bench_job));
+  pthread_t *th = (pthread_t *)calloc((size_t)n_threads, sizeof(pthread_t));
+  uint64_t sum = 0;
+  for (int k = 0; k < n_threads; k++) {
+    orc_bench_job j = {cfg, weights, k, n_threads, n_arenas, ticks, do_raster, episode_ticks, n_pol, seed, 0};
+    jobs[k] = j;
+  }
+  if (n_threads == 1) orc_bench_thread(&jobs[0]);
+  else {
+    for (int k = 0; k < n_threads; k++) pthread_create(&th[k], NULL, orc_bench_thread, &jobs[k]);
+    for (int k = 0; k < n_threads; k++) pthread_join(th[k], NULL);
+  }
+  for (int k = 0; k < n_threads; k++) sum += jobs[k].sum;
+  free(jobs); free(th);
+  return sum;
+}

@@ -192,6 +192,18 @@ def run_random(cfg, n_arenas, ticks, seed, do_raster, episode_ticks=200):
     return lib().orc_run_random(C.byref(cfg), n_arenas, ticks, C.c_uint64(seed), int(do_raster), episode_ticks)
 
 
+def bench_run(cfg, weights, n_arenas, ticks, seed, do_raster, episode_ticks=200, n_pol=0, n_threads=1):
+    """bench.py's cpu_baseline legs as one C call: the orc_run_random loop, optionally with n_pol policy forwards per
+    arena and lock-step, over n_threads POSIX threads (arena g -> thread g % n_threads)."""
+    L = lib()
+    L.orc_bench_run.argtypes = [C.POINTER(OrcCfg), C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int,
+                                C.c_int]
+    L.orc_bench_run.restype = C.c_uint64
+    w = None if weights is None else np.ascontiguousarray(weights, np.float32)
+    return L.orc_bench_run(C.byref(cfg), None if w is None else _p(w), int(n_arenas), int(ticks), C.c_uint64(seed),
+                           int(do_raster), int(episode_ticks), int(n_pol), int(n_threads))
+
+
 # ------------------------------------------------------------------ policy
 def policy_layout():
     """(offsets, counts, total) of the float32 weight blob (oracle/policy_oracle.c header)."""

@@ -212,6 +212,54 @@ def test_sharding_invariance_and_determinism():
     assert np.array_equal(es_full, es_lo + es_hi)  # what the RCCL all-reduce sums
 
 
+@pytest.mark.parametrize("observe", [False, True])
+def test_rollout_k_ticks_equal_single_ticks(observe):
+    """ofx_rollout (the headless loop, battleground.py:169-173): K lock-steps of bots + step [+ rasterise] enqueued by
+    one host call - without an observer all K inside ONE kernel launch - leave exactly the state bits of K single
+    (ofx_bot_actions, ofx_step[, ofx_rasterise]) calls; also across an episode end and through ShardedRollout."""
+    from ofighters_amd import _native as nat
+    from ofighters_amd.rollout import ShardedRollout
+    beh = ["random", "turret", "runner", "shoot", "thrust", "idle", "random", "turret"]
+    fields = (nat.F_SHIP_X, nat.F_SHIP_Y, nat.F_SHIP_PX, nat.F_SHIP_PY, nat.F_SHIP_ALIVE, nat.F_REWARD, nat.F_SCORE,
+              nat.F_OBS_REWARD, nat.F_KILLER, nat.F_HULL, nat.F_N_LASERS, nat.F_LASER_X, nat.F_LASER_Y, nat.F_LASER_DX,
+              nat.F_LASER_DY, nat.F_LASER_OWNER, nat.F_LASER_DEAD, nat.F_TIME, nat.F_LAST_SCORES)
+    N, seed = 300, 77                         # not a multiple of 4: the last block has idle waves
+    one = _batch(N, 8, arena_base=17, laser_cap=128)
+    many = _batch(N, 8, arena_base=17, laser_cap=128)
+    one.spawn_random(seed)
+    many.spawn_random(seed)
+    mt = nat.MAP_U8 if observe else None
+    t = 0
+    for n in (1, 63, 96):                     # 160 lock-steps, the episode ends at 160
+        for k in range(n):
+            one.bot_actions(beh, seed, tick=t + k)
+            one.step()
+            if observe:
+                one.rasterise()
+        many.rollout(beh, seed, t, n, mt)
+        t += n
+        for f in fields:
+            assert np.array_equal(one.get(f), many.get(f)), (n, f)
+    if observe:
+        for a, c in zip(one.maps_host(nat.MAP_U8), many.maps_host(nat.MAP_U8)):
+            assert np.array_equal(a, c)
+    assert one.overflow_count() == many.overflow_count()
+    one.close(); many.close()
+    # the same through the rollout driver: per-tick calls against the K-tick fast path, two episode ends inside
+    logs = []
+    for fast in (False, True):
+        b = _batch(N, 8, arena_base=17)
+        r = ShardedRollout(b, beh, seed, episode_ticks=50, observe=observe, use_rollout=fast)
+        r.run(30); r.run(95)
+        logs.append(([b.get(f).copy() for f in fields], [s.copy() for s in r.score_log]))
+        b.close()
+    assert len(logs[0][1]) == 2
+    for a, c in zip(logs[0][0], logs[1][0]):
+        assert np.array_equal(a, c)
+    for a, c in zip(logs[0][1], logs[1][1]):
+        assert np.array_equal(a, c)
+
+
 def test_full_size_properties():
     """BASELINE config 2 size (4096 x 8): size-independent properties + a
     random sample of arenas replayed on the oracle."""
