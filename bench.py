@@ -65,7 +65,7 @@ def pmc_traffic(kernel_prefix, live_ms=None):
         kb = {}
         for line in open(pmc):
             f = line.rstrip("\n").split("\t")
-            if len(f) == 2 and f[0].startswith(kernel_prefix) and "=" in f[1]:
+            if len(f) == 2 and kernel_prefix in f[0] and "=" in f[1]:
                 name, val = f[1].split("=")
                 kb[name] = float(val)
         if not ("FETCH_SIZE" in kb and "WRITE_SIZE" in kb):
@@ -73,7 +73,7 @@ def pmc_traffic(kernel_prefix, live_ms=None):
         if live_ms is not None:
             prof_ms = None
             for r in csv.DictReader(open(stats)):
-                if r["Name"].startswith(kernel_prefix):
+                if kernel_prefix in r["Name"]:
                     prof_ms = float(r["AverageNs"]) / 1e6
                     break
             if prof_ms is None or abs(prof_ms - live_ms) > 0.15 * live_ms:
@@ -111,8 +111,8 @@ def cpu_baseline(workload, M, n_pol, w_host, ep_ticks):
     except (OSError, ValueError):
         pass
     if workload == "step+obs+policy":
-        # ~0.27 s per arena-step with 8 forwards on one core: 64 arena-steps on one thread, 4 per thread on all cores
-        n_one, t_one, n_all, t_all, obs, pol = 8, 8, cores, 4, 1, n_pol
+        # ~0.27 s per arena-step with 8 forwards on one core: 64 arena-steps on one thread, 16 per thread on all cores
+        n_one, t_one, n_all, t_all, obs, pol = 8, 8, 2 * cores, 8, 1, n_pol
     elif workload == "step+obs":
         n_one, t_one, n_all, t_all, obs, pol = 2048, 200, 512 * cores, 200, 1, 0
     else:
@@ -242,7 +242,7 @@ class Workload:
                              "in the kernel); avg_kernel_ms / algorithmic bytes are per lock-step = launch time / its "
                              "lock-steps (launches of %s lock-steps)" % sorted(set(self.chunks)))
         if full_config and (self.do_policy or self.do_obs):
-            r["traffic"], src = pmc_traffic("k_head_stream" if self.do_policy else "void k_raster<0>", k_avg_ms)
+            r["traffic"], src = pmc_traffic("k_head_stream" if self.do_policy else "k_raster<0>", k_avg_ms)
             r["traffic_source"] = ("HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE in separate "
                                    "passes of this command: " + src) if r["traffic"] is not None else "none (%s)" % src
         return r
@@ -380,7 +380,7 @@ def main():
         # the stock line-up has ONE QlearnIA ship (lib/ofighters.py:53: bound 1.01 M arena-steps/s), and
         # QlearnIA.play returns None once the ship is destroyed (agents/qlearnIA_V2.py:372-377)
         extra = []
-        for wl_name, np_, alive, wu, st in (("step", 0, False, 200, 1000), ("step+obs", 0, False, 200, 1000),
+        for wl_name, np_, alive, wu, st in (("step", 0, False, 400, 20000), ("step+obs", 0, False, 200, 2000),
                                             ("step+obs+policy", 1, False, 50, 300), ("step+obs+policy", M, True, 50, 200)):
             r = measure(wl_name, np_, alive, wu, st, wl_name != "step+obs+policy")
             if wl_name == "step+obs+policy":

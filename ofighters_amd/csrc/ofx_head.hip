@@ -22,6 +22,12 @@
 #include "ofx_head.h"
 #include <stdlib.h>
 
+#ifndef HS_A_FIRST
+#define HS_A_FIRST 1      // consumers: stage A in front of the stage-C pass (0: behind it, the r02 order)
+#endif
+#ifndef HS_C_PRIO
+#define HS_C_PRIO 0       // s_setprio of the consumer waves (r02: 1; with stage A in front 0 is the faster one)
+#endif
 #ifndef OFX_HEAD_HOOKS
 #define OFX_HEAD_HOOKS 0  // 1: the OFX_HEAD_ABLATE timing switches are compiled into k_head_stream (results are wrong)
 #endif
@@ -527,6 +533,10 @@ __device__ __forceinline__ void hs_u2_store(float *u2r, int ch, int row, int col
 constexpr int HS_NB = 4;                 // producer waves (two M-tiles per sub-step each); 4 consumer waves behind them
 constexpr int HS_THREADS = 64 * (HS_NB + 4);
 
+// EXTRA: the launch wants the heat map and / or a probed value written out (ofx_policy_forward with a heatmap pointer,
+// ofx_policy_forward_obs with a probe: the DQN targets); the rollout's forward does not, and its instantiation carries
+// neither the tests nor the branches of those paths in the consumers' loop
+template <bool EXTRA>
 __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
   __shared__ __align__(16) float u3r[8 * HS_PL3];
   __shared__ __align__(16) float u2r[4 * HS_PL2];
@@ -705,7 +715,7 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
     // ================================================================ consumer waves (stage C + arg-max + stage A)
     // the consumers are the MFMA-dense half of the workgroup and finish last: their instructions go first when a
     // producer wave of the same SIMD competes for the issue slot (A/B on the chip: 17.2 against 17.9 ms)
-    __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_s_setprio(HS_C_PRIO);
     // Every VALU instruction here is paid in matrix throughput (the f32 MFMAs and the VALU share the SIMD's issue
     // slots), so the per-pass bookkeeping is kept to running counters and the arg-max to a snapshot of the best pass.
     // stage-C weights: register r, lane L holds W[k = 16 r + (L >> 2)][phase L & 3]; an MFMA picks its k with ABID
@@ -831,6 +841,18 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
       if (p.ablate & 1) { __syncthreads(); continue; }
 #endif
       HS_STAMP(0);
+#if HS_A_FIRST
+      // The consumers open a sub-step with their matrix-light work (stage A for the NEXT sub-step's M-tiles, the loads
+      // of the one after) while the producer wave that shares their SIMD opens it with its MFMAs; the stage-C pass
+      // follows when the producers are in their own matrix-light tail (tile set-ups for the next sub-step).  Both roles
+      // used to start their MFMA runs right behind the barrier and serialised on the SIMD's matrix pipe
+      // (s_memtime stamps: 4265 cycles per producer tile pair of 1152 matrix cycles, 2143 cycles per sub-step in the
+      // consumers' barrier wait).  Nothing inside a sub-step orders stage A against the pass: uprelu2 rows written in
+      // sub-step st are read by the producers in st + 1 (tools/head_schedule.py).
+      if (apr >= 0) stageA_compute(apr, ahh, av);
+      stageA_pick(min(st + 1, HS_NS - 1));
+      HS_STAMP(3);
+#endif
       if (__builtin_amdgcn_ballot_w64(ok) != 0) {    // wave-uniform
         // zero-padding corrections of frame pixels (global memory: requested up front, zero for the other lanes)
         f32x2 ccol = {0.f, 0.f};
@@ -894,12 +916,12 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
           if (st < 3) { o[0][0] -= crow[0]; o[0][1] -= crow[1]; o[1][0] -= crow[2]; o[1][1] -= crow[3]; }
           else { o[0][2] -= crow[0]; o[0][3] -= crow[1]; o[1][2] -= crow[2]; o[1][3] -= crow[3]; }
         }
-        if (p.heat && ok) {
+        if (EXTRA && p.heat && ok) {
           float *hp = p.heat + (size_t)s * HD_PS * HD_PS + (size_t)(2 * R) * HD_PS + 2 * x0;
           *reinterpret_cast<f32x4 *>(hp) = (f32x4){o[0][0], o[0][1], o[1][0], o[1][1]};
           *reinterpret_cast<f32x4 *>(hp + HD_PS) = (f32x4){o[0][2], o[0][3], o[1][2], o[1][3]};
         }
-        if (p.ptr_probe && ok) {
+        if (EXTRA && p.ptr_probe && ok) {
           const int qx = p.probe[2 * s] - 2 * x0, qy = p.probe[2 * s + 1] - 2 * R;
           if (qx >= 0 && qx < 4 && qy >= 0 && qy < 2) p.ptr_probe[s] = o[qx >> 1][2 * qy + (qx & 1)];
         }
@@ -917,9 +939,11 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
         }
       }
       HS_STAMP(2);
+#if !HS_A_FIRST
       if (apr >= 0) stageA_compute(apr, ahh, av);
       stageA_pick(min(st + 1, HS_NS - 1));
       HS_STAMP(3);
+#endif
       R += 5;
       coff += 10;
 #pragma unroll
@@ -985,7 +1009,8 @@ int ofx_launch_head(ofx_handle *h, const HeadParams2 &p0) {
   const unsigned blocks = (unsigned)(((p.S + 7) / 8) * 16);
   int rc;
   if (p.event_base >= 0 && (rc = ofx_event_record(h, p.event_base))) return rc;
-  hipLaunchKernelGGL(k_head_stream, dim3(blocks), dim3(HS_THREADS), 0, h->stream, p);
+  if (p.heat || p.ptr_probe) hipLaunchKernelGGL(k_head_stream<true>, dim3(blocks), dim3(HS_THREADS), 0, h->stream, p);
+  else hipLaunchKernelGGL(k_head_stream<false>, dim3(blocks), dim3(HS_THREADS), 0, h->stream, p);
   OFX_HIP(hipGetLastError());
   if (p.event_base >= 0 && (rc = ofx_event_record(h, p.event_base + 1))) return rc;
 #if OFX_HEAD_HOOKS

@@ -1,10 +1,11 @@
 #!/bin/bash
 # s_memtime stamps + stage ablations of k_head_stream on the GPU box (diagnostic build -DOFX_HEAD_HOOKS=1; restores the
-# default build).  usage: tools/head_stamps.sh <tag>
+# default build).  usage: tools/head_stamps.sh <tag> ["<extra HEAD_EXTRA flags>"]
 tag=${1:-x}
+extra=$2
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
-make -C ofighters_amd/csrc HEAD_EXTRA="-DOFX_HEAD_HOOKS=1" -B ofx_head.o >/dev/null 2>&1 && make -C ofighters_amd/csrc >/dev/null 2>&1 || { echo "build failed"; exit 1; }
+make -C ofighters_amd/csrc HEAD_EXTRA="-DOFX_HEAD_HOOKS=1 $extra" -B ofx_head.o >/dev/null 2>&1 && make -C ofighters_amd/csrc >/dev/null 2>&1 || { echo "build failed"; exit 1; }
 run() { timeout -k 10 200 python bench.py --steps 30 --warmup 8 --no-cpu-baseline --no-extra 2>>gpurun_out/stamps_$tag.txt | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', 'head ms', round(d['roofline']['avg_kernel_ms'],3), 'tick ms', round(d['ms_per_step'],3))"; }
