@@ -133,6 +133,47 @@ def cpu_baseline(workload, M, n_pol, w_host, ep_ticks):
     }
 
 
+def train_tick(N, M, device, base, w_host, fence):
+    """Secondary line (never `value`): the learning agent as a whole on the reference's own line-up shape (ONE policy
+    ship per arena, lib/ofighters.py:53) - TrainingRollout = forward -> epsilon-greedy -> remember -> step -> rasterise
+    with DeviceTrainer.replay on the reference's schedule (every 50 total steps and on lock-steps where a learning agent
+    first sees its death, agents/qlearnIA_V2.py:376-378,414-415), the fit on `fit_batch` rows of the sampled minibatch.
+    Reports ms per lock-step with the replays amortised in, the replays per lock-step and the ms of one replay."""
+    from ofighters_amd import ArenaBatch
+    from ofighters_amd.lib.epsilon import Epsilon_decay
+    from ofighters_amd.rollout import TrainingRollout
+    from ofighters_amd.trainer import DeviceTrainer
+    b = ArenaBatch(N, M, device=device, arena_base=base)
+    eps = Epsilon_decay()
+    eps.set(0.1)
+    tr = DeviceTrainer(b, w_host, epsilon=eps, batch_size=8, memory_size=64, frames=96, fit_batch=64)
+    roll = TrainingRollout(b, tr, ["random"] * M, SEED, policy_ships=(0,), episode_ticks=b.cfg.episode_ticks)
+    warm, steps = 30, 120
+    roll.run(warm)
+    fence()
+    n0 = len(roll.losses)
+    t0 = time.perf_counter()
+    roll.run(steps)
+    fence()
+    dt = time.perf_counter() - t0
+    n_rep = len(roll.losses) - n0
+    t1 = time.perf_counter()
+    for _ in range(3):
+        tr.replay()
+    fence()
+    rep_ms = (time.perf_counter() - t1) / 3 * 1e3
+    rec = {"workload": "%d arenas x %d ships per GPU, TRAINING tick: one policy ship per arena (forward + epsilon-greedy + "
+                       "transition capture) + step + obs + DeviceTrainer.replay on the reference's schedule "
+                       "(every 50 steps and on lock-steps with a first-seen death), fit_batch 64" % (N, M),
+           "value": N * steps / dt, "unit": "arena-steps/s", "steps": steps, "warmup": warm,
+           "ms_per_step": dt / steps * 1e3, "replays_in_timed_region": n_rep, "ms_per_replay": rep_ms,
+           "last_losses": [float(x) for x in roll.losses[-3:]],
+           "note": "sample + gather + two target forwards + one fit step per replay; the fit kernels are plain VALU "
+                   "kernels (ofx_train.hip), not the hot path"}
+    b.close()
+    return rec
+
+
 class Workload:
     """One timed configuration on an ArenaBatch: ShardedRollout + the policy hook + HIP-event bracketing of the
     dominant kernel."""
@@ -276,6 +317,9 @@ def main():
     ap.add_argument("--policy-alive-only", action="store_true",
                     help="skip the forward of destroyed ships (QlearnIA.play returns None once done, "
                          "agents/qlearnIA_V2.py:372-377); NOT the headline configuration")
+    ap.add_argument("--trunk-form", type=int, default=0, choices=[0, 1, 2],
+                    help="OFX_OPT_TRUNK_FUSE for A/Bs of the trunk kernels (0 = the library's choice; results are "
+                         "bit-identical in every form)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary configurations at N=1")
     args = ap.parse_args()
@@ -330,6 +374,8 @@ def main():
 
     def measure(workload, n_pol_, alive_only, warmup, steps, full_config):
         b = ArenaBatch(N, M, device=local_rank, arena_base=base)
+        if args.trunk_form:
+            b.set_option(nat.OPT_TRUNK_FUSE, args.trunk_form)
         ep = b.cfg.episode_ticks
         # an episode end (restart + score all-reduce) falls into the middle of the timed region whatever --steps is
         start = (ep - warmup - max(1, steps // 2)) % ep
@@ -388,6 +434,7 @@ def main():
                 r["fp32_bound_arena_steps_per_s"] = N * FP32_PEAK_TF * 1e12 / flops
                 r["frac_of_fp32_bound"] = r["value"] / r["fp32_bound_arena_steps_per_s"]
             extra.append(r)
+        extra.append(train_tick(N, M, local_rank, base, w_host, fence))
         out["extra_configs"] = extra
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -60,6 +60,7 @@ struct ofx_handle {
   ofx_replay *replay;              // transition memory (ofx_replay_create), null = none
   void *aux;                       // temporaries of ofx_dqn_targets (grown on demand)
   size_t aux_bytes;
+  int32_t *counter;                // [4] small device counter of the fit's argument checks (allocated on first use)
   float *prep;                     // prepared policy weights (BN folded, phase weights, tables): ofx_policy.hip
   float *prep_tmp;                 // the same for a blob that is not the pinned one (rebuilt per forward)
   const float *prep_pinned;        // the blob `prep` was built from while it is pinned (ofx_policy_pin_weights)

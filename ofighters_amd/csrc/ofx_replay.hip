@@ -28,6 +28,7 @@ struct ofx_replay {
   uint8_t *has_prev, *latched;
   int32_t *prev_iaction, *prev_px, *prev_py, *prev_tick, *prev_slot;
   float *prev_head;        // [N][M][8]
+  int32_t *scan_off;       // [N + 1] prefix sums of ofx_replay_gather_valid (kept: no allocation per replay)
 };
 
 void ofx_replay_free(ofx_handle *h) {
@@ -35,7 +36,7 @@ void ofx_replay_free(ofx_handle *h) {
   if (!r) return;
   void *ptrs[] = {r->frame_bits, r->frame_tick, r->rows, r->head, r->count, r->appended, r->has_prev, r->latched,
                   r->prev_iaction, r->prev_px, r->prev_py, r->prev_tick, r->prev_head, r->frame_head, r->cur_slot,
-                  r->prev_slot};
+                  r->prev_slot, r->scan_off};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   delete r;
   h->replay = nullptr;
@@ -80,6 +81,7 @@ extern "C" int ofx_replay_create(ofx_handle *h, int32_t capacity, int32_t frames
   A(has_prev, N * M, 0) A(latched, N * M, 0)
   A(prev_iaction, N * M, 0) A(prev_px, N * M, 0) A(prev_py, N * M, 0) A(prev_tick, N * M, 0)
   A(prev_head, N * M * 8, 0)
+  A(scan_off, N + 1, 0)
 #undef A
   OFX_HIP(hipDeviceSynchronize());  // null-stream fills vs the handle's non-blocking stream
   return OFX_OK;
@@ -441,8 +443,7 @@ extern "C" int ofx_replay_gather_valid(ofx_handle *h, const int32_t *slot, const
   ofx_replay *r = h->replay;
   OFX_HIP(hipSetDevice(h->cfg.device));
   const int N = h->cfg.n_arenas;
-  int32_t *off = nullptr;
-  OFX_HIP(hipMalloc((void **)&off, sizeof(int32_t) * (N + 1)));
+  int32_t *off = r->scan_off;
   hipLaunchKernelGGL(k_replay_scan, dim3(1), dim3(1024), 0, h->stream, N, n_sampled, off);
   GatherParams p;
   p.N = N; p.C = r->capacity; p.F = r->frames; p.batch = batch; p.words = r->words;
@@ -453,7 +454,6 @@ extern "C" int ofx_replay_gather_valid(ofx_handle *h, const int32_t *slot, const
   int32_t total = 0;
   if (e == hipSuccess) e = hipMemcpyAsync(&total, off + N, sizeof(total), hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-  (void)hipFree(off);
   if (e != hipSuccess) { ofx_set_error("ofx_replay_gather_valid: %s", hipGetErrorString(e)); return OFX_ERR_HIP; }
   *n_rows_host = total - first < 0 ? 0 : (total - first > max_rows ? max_rows : total - first);
   return OFX_OK;

@@ -123,9 +123,10 @@ __global__ void t_conv_bwd_finish(int nw, int nb, int slices, const double *part
   else db[wid - nw] = (float)acc;
 }
 
-// per-channel sums over (n, H, W): out[c] += {sum a, sum a*b} (b may be null -> sum a*a); double accumulation,
-// gridDim.y slices per channel combined with double atomics (out must be zeroed)
-__global__ __launch_bounds__(256) void t_chan_sums(int n, int c_n, size_t per, const float *a, const float *b, double *out) {
+// per-channel sums over (n, H, W): out[c] = {sum a, sum a*b} (b may be null -> sum a*a); double accumulation,
+// gridDim.y slices per channel written to part[c][slice][2] and combined IN SLICE ORDER by t_chan_sums_finish: the same
+// bits every run (the fit is reproducible)
+__global__ __launch_bounds__(256) void t_chan_sums(int n, int c_n, size_t per, const float *a, const float *b, double *part) {
   __shared__ double r0[256], r1[256];
   const int c = blockIdx.x;
   const size_t total = (size_t)n * per;
@@ -142,7 +143,14 @@ __global__ __launch_bounds__(256) void t_chan_sums(int n, int c_n, size_t per, c
     if ((int)threadIdx.x < o) { r0[threadIdx.x] += r0[threadIdx.x + o]; r1[threadIdx.x] += r1[threadIdx.x + o]; }
     __syncthreads();
   }
-  if (threadIdx.x == 0) { atomicAdd(&out[2 * c], r0[0]); atomicAdd(&out[2 * c + 1], r1[0]); }
+  if (threadIdx.x == 0) { part[((size_t)c * gridDim.y + blockIdx.y) * 2] = r0[0]; part[((size_t)c * gridDim.y + blockIdx.y) * 2 + 1] = r1[0]; }
+}
+__global__ void t_chan_sums_finish(int c_n, int slices, const double *part, double *out) {
+  const int c = threadIdx.x;
+  if (c >= c_n) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int k = 0; k < slices; k++) { s0 += part[((size_t)c * slices + k) * 2]; s1 += part[((size_t)c * slices + k) * 2 + 1]; }
+  out[2 * c] = s0; out[2 * c + 1] = s1;
 }
 
 // batch statistics from the sums: mean, biased variance (stat[c] = {mean, var})
@@ -236,21 +244,36 @@ __global__ void t_up_fwd(int nc, int H, int W, const float *x, float *u, int leg
     u[e] = top * (1.f - wy) + bot * wy;
   }
 }
-__global__ void t_up_bwd(int nc, int H, int W, const float *du, float *dx, int legacy) {  // dx must be zero-filled
+// gather form: dx[y][x] = sum over the up-res cells whose two taps per axis include (y, x), in a fixed order (every run
+// gives the same bits; the scatter form needed float atomics).  A source row y is a tap of up-res rows 2y-2 .. 2y+2 only.
+__global__ void t_up_bwd(int nc, int H, int W, const float *du, float *dx, int legacy) {
   const int H2 = 2 * H, W2 = 2 * W;
-  const size_t total = (size_t)nc * H2 * W2;
+  const size_t total = (size_t)nc * H * W;
   for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-    const int ux = e % W2, uy = (e / W2) % H2;
-    const size_t c = e / ((size_t)W2 * H2);
-    int y0, y1, x0, x1; float wy, wx;
-    up_taps(uy, H, y0, y1, wy, legacy); up_taps(ux, W, x0, x1, wx, legacy);
-    float *q = dx + c * H * W;
-    const float g = du[e];
-    if (g == 0.f) continue;
-    atomicAdd(&q[(size_t)y0 * W + x0], g * (1.f - wy) * (1.f - wx));
-    atomicAdd(&q[(size_t)y0 * W + x1], g * (1.f - wy) * wx);
-    atomicAdd(&q[(size_t)y1 * W + x0], g * wy * (1.f - wx));
-    atomicAdd(&q[(size_t)y1 * W + x1], g * wy * wx);
+    const int x = e % W, y = (e / W) % H;
+    const size_t c = e / ((size_t)W * H);
+    const float *q = du + c * H2 * W2;
+    float cy[5], cx[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      const int uy = 2 * y - 2 + k, ux = 2 * x - 2 + k;
+      int a0, a1; float w;
+      cy[k] = 0.f; cx[k] = 0.f;
+      if (uy >= 0 && uy < H2) { up_taps(uy, H, a0, a1, w, legacy); cy[k] = (a0 == y ? 1.f - w : 0.f) + (a1 == y ? w : 0.f); }
+      if (ux >= 0 && ux < W2) { up_taps(ux, W, a0, a1, w, legacy); cx[k] = (a0 == x ? 1.f - w : 0.f) + (a1 == x ? w : 0.f); }
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 5; ky++) {
+      if (cy[ky] == 0.f) continue;
+      const int uy = 2 * y - 2 + ky;
+      float row = 0.f;
+#pragma unroll
+      for (int kx = 0; kx < 5; kx++)
+        if (cx[kx] != 0.f) row += cx[kx] * q[(size_t)uy * W2 + 2 * x - 2 + kx];
+      acc += cy[ky] * row;
+    }
+    dx[e] = acc;
   }
 }
 
@@ -312,19 +335,27 @@ __global__ void t_concat_bwd(int n, const float *df, float *dx4) {
 
 // loss seeds: one non-zero error per head and sample; loss[0] += mse(out1) share, loss[1] += mse(out2) share
 __global__ void t_loss_seed(int n, const ofx_transition *rows, const float *o1, const float *o2, const float *y_act,
-                            const float *y_ptr, float *do1, float *do2, float *loss) {
+                            const float *y_ptr, float *do1, float *do2, float *lpart) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n) return;
   const ofx_transition r = rows[s];
-  if (r.ship < 0) return;  // padding row: no error
+  if (r.ship < 0) { lpart[2 * s] = lpart[2 * s + 1] = 0.f; return; }  // padding row: no error
   const int a = r.iaction ? 1 : 0, px = min(max(r.px, 0), TPS - 1), py = min(max(r.py, 0), TPS - 1);
   const float e1 = o1[2 * s + a] - y_act[s];
   const size_t k = (size_t)s * TPS * TPS + (size_t)py * TPS + px;
   const float e2 = o2[k] - y_ptr[s];
   do1[2 * s + a] = 2.f * e1 / (2.f * n);
   do2[k] = 2.f * e2 / ((float)(TPS * TPS) * n);
-  atomicAdd(&loss[0], e1 * e1 / (2.f * n));
-  atomicAdd(&loss[1], e2 * e2 / ((float)(TPS * TPS) * n));
+  lpart[2 * s] = e1 * e1 / (2.f * n);          // summed in sample order by t_sum_ordered
+  lpart[2 * s + 1] = e2 * e2 / ((float)(TPS * TPS) * n);
+}
+// out[j] = sum_i part[i * stride + j] for j < stride, in index order (one thread per j: tiny)
+__global__ void t_sum_ordered(int count, int stride, const float *part, float *out) {
+  const int j = threadIdx.x;
+  if (j >= stride) return;
+  double acc = 0.0;
+  for (int i = 0; i < count; i++) acc += (double)part[(size_t)i * stride + j];
+  out[j] = (float)acc;
 }
 
 // Trainer.replay as written (ofx_dqn_fit_reference): the targets are whole predictions of `state` with one entry
@@ -348,15 +379,22 @@ __global__ void t_unpack_heads(int n, const ofx_transition *rows, float *vec_pre
     vec_next[(size_t)s * 8 + k] = rows[s].head_next[k];
   }
 }
-__global__ void t_loss_dense(size_t total, float scale, const float *o, const float *t, float *d, float *loss) {
+// dense targets: d = 2 (o - t) scale; block b's share of the loss goes to lpart[b] (summed in block order afterwards)
+__global__ __launch_bounds__(256) void t_loss_dense(size_t total, float scale, const float *o, const float *t, float *d, float *lpart) {
+  __shared__ float red[256];
   float acc = 0.f;
   for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
     const float err = o[e] - t[e];
     d[e] = 2.f * err * scale;
     acc += err * err * scale;
   }
-  for (int o_ = 32; o_ > 0; o_ >>= 1) acc += __shfl_xor(acc, o_);
-  if ((threadIdx.x & 63) == 0 && acc != 0.f) atomicAdd(loss, acc);
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) lpart[blockIdx.x] = red[0];
 }
 
 __global__ void t_adam(size_t cnt, float *w, const float *g, float *m, float *v, float lr_t, float b1, float b2, float eps) {
@@ -411,6 +449,22 @@ __global__ void t_count_pads(int n, const ofx_transition *rows, int32_t *out) {
   if (i < n && rows[i].ship < 0) atomicAdd(out, 1);
 }
 
+// padding rows (ship < 0) would enter the BatchNorm batch statistics and the loss scale: refused before any work is done
+static int refuse_pads(ofx_handle *h, int n, const ofx_transition *rows, const char *who) {
+  hipStream_t st = h->stream;
+  if (!h->counter) OFX_HIP(hipMalloc((void **)&h->counter, 4 * sizeof(int32_t)));
+  int32_t pads = 0;
+  OFX_HIP(hipMemsetAsync(h->counter, 0, sizeof(int32_t), st));
+  hipLaunchKernelGGL(t_count_pads, dim3((n + 255) / 256), dim3(256), 0, st, n, rows, h->counter);
+  OFX_HIP(hipMemcpyAsync(&pads, h->counter, sizeof(pads), hipMemcpyDeviceToHost, st));
+  OFX_HIP(hipStreamSynchronize(st));
+  if (pads) {
+    ofx_set_error("%s: %d of %d rows are padding (ship < 0); gather with ofx_replay_gather_valid", who, pads, n);
+    return OFX_ERR_INVALID;
+  }
+  return OFX_OK;
+}
+
 // One fit step.  Two forms of the targets: the sparse one of ofx_dqn_fit (one error per head and sample: y_act / y_ptr,
 // inputs = `state`) and the dense one of ofx_dqn_fit_reference (t1 [n][2] / t2 [n][400][400] whole target tensors,
 // inputs = bits_in + the rows' next_state head).
@@ -423,20 +477,7 @@ static int dqn_fit_impl(ofx_handle *h, float *weights, float *adam_m, float *ada
   ofx_policy_desc L;
   int rc = ofx_policy_layout(h, &L);
   if (rc) return rc;
-  {  // padding rows (ship < 0) would enter the BatchNorm batch statistics and the loss scale: refuse them up front
-    int32_t *npad = nullptr, pads = 0;
-    OFX_HIP(hipMalloc((void **)&npad, sizeof(int32_t)));
-    OFX_HIP(hipMemsetAsync(npad, 0, sizeof(int32_t), st));
-    hipLaunchKernelGGL(t_count_pads, dim3((n + 255) / 256), dim3(256), 0, st, n, rows, npad);
-    hipError_t e = hipMemcpyAsync(&pads, npad, sizeof(pads), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    (void)hipFree(npad);
-    if (e != hipSuccess) { ofx_set_error("ofx_dqn_fit: %s", hipGetErrorString(e)); return OFX_ERR_HIP; }
-    if (pads) {
-      ofx_set_error("ofx_dqn_fit: %d of %d rows are padding (ship < 0); gather with ofx_replay_gather_valid", pads, n);
-      return OFX_ERR_INVALID;
-    }
-  }
+  if ((rc = refuse_pads(h, n, rows, "ofx_dqn_fit"))) return rc;
   const size_t N = (size_t)n;
   const int legacy = h->opt_bilinear_legacy;
   // activations: trunk sizes 400,200,100,50 (z, a per layer + pooled), head-2 sizes 50,100,200 (+ upsampled inputs)
@@ -450,7 +491,7 @@ static int dqn_fit_impl(ofx_handle *h, float *weights, float *adam_m, float *ada
     sz(N * 8 * 160000); sz(N * 160000);               // up4, o2
     sz(N * 8 * 160000); sz(N * 8 * 160000);           // two gradient scratch planes of the largest size
     sz(N * 5008); sz(N * 100); sz(N * 100); sz(N * 50); sz(N * 2); sz(N * 625); sz(N * 160000);
-    sz(L.n_floats); sz(64); need += 65536 + 16 * 64 * 8 + (size_t)kWSlices * 600 * 8;
+    sz(L.n_floats); sz(64); sz(2 * N + 4096); need += 65536 + 16 * 64 * 8 + 16 * 64 * 2 * 8 + (size_t)kWSlices * 600 * 8;
   }
   void *raw = nullptr;
   OFX_HIP(hipMalloc(&raw, need));
@@ -465,7 +506,9 @@ static int dqn_fit_impl(ofx_handle *h, float *weights, float *adam_m, float *ada
   OFX_HIP(hipMemsetAsync(grad, 0, sizeof(float) * L.n_floats, st));
   float *loss = A.f(64);
   OFX_HIP(hipMemsetAsync(loss, 0, 64 * sizeof(float), st));
+  float *lpart = A.f(2 * N + 4096);                   // per-sample / per-block loss shares, summed in order
   double *sums = A.d(16 * 16);
+  double *spart = A.d(16 * 64 * 2);                  // t_chan_sums partials [channel][slice][2]
   double *wpart = A.d((size_t)kWSlices * 600);
   auto G = [&](int t) { return grad + L.offset[t]; };
 
@@ -478,8 +521,8 @@ static int dqn_fit_impl(ofx_handle *h, float *weights, float *adam_m, float *ada
     const size_t per = (size_t)s * s;
     tz[i] = A.f(N * 8 * per); ta[i] = A.f(N * 8 * per); tp[i] = A.f(N * 8 * per / 4); tstat[i] = A.f(16);
     K(t_conv_fwd, N * 8 * per, n, kTI[i], 8, s, s, tin, T(6 * i), T(6 * i + 1), tz[i]);
-    OFX_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 32, st));
-    hipLaunchKernelGGL(t_chan_sums, dim3(8, 64), dim3(256), 0, st, n, 8, per, tz[i], (const float *)nullptr, sums);
+    hipLaunchKernelGGL(t_chan_sums, dim3(8, 64), dim3(256), 0, st, n, 8, per, tz[i], (const float *)nullptr, spart);
+    hipLaunchKernelGGL(t_chan_sums_finish, dim3(1), dim3(64), 0, st, 8, 64, spart, sums);
     hipLaunchKernelGGL(t_bn_finish_stats, dim3(1), dim3(64), 0, st, 8, (double)N * (double)per, sums, tstat[i]);
     K(t_bn_relu_fwd, N * 8 * per, n, 8, per, tz[i], tstat[i], T(6 * i + 2), T(6 * i + 3), ta[i]);
     K(t_pool_fwd, N * 8 * per / 4, n * 8, s, s, ta[i], tp[i]);
@@ -498,8 +541,8 @@ static int dqn_fit_impl(ofx_handle *h, float *weights, float *adam_m, float *ada
     uu[j] = A.f(N * kUI[j] * per); uz[j] = A.f(N * kUO[j] * per); ua[j] = A.f(N * kUO[j] * per); ustat[j] = A.f(16);
     K(t_up_fwd, N * kUI[j] * per, n * kUI[j], s / 2, s / 2, uin, uu[j], legacy);
     K(t_conv_fwd, N * kUO[j] * per, n, kUI[j], kUO[j], s, s, uu[j], T(32 + 6 * j), T(33 + 6 * j), uz[j]);
-    OFX_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 32, st));
-    hipLaunchKernelGGL(t_chan_sums, dim3(kUO[j], 64), dim3(256), 0, st, n, kUO[j], per, uz[j], (const float *)nullptr, sums);
+    hipLaunchKernelGGL(t_chan_sums, dim3(kUO[j], 64), dim3(256), 0, st, n, kUO[j], per, uz[j], (const float *)nullptr, spart);
+    hipLaunchKernelGGL(t_chan_sums_finish, dim3(1), dim3(64), 0, st, kUO[j], 64, spart, sums);
     hipLaunchKernelGGL(t_bn_finish_stats, dim3(1), dim3(64), 0, st, kUO[j], (double)N * (double)per, sums, ustat[j]);
     K(t_bn_relu_fwd, N * kUO[j] * per, n, kUO[j], per, uz[j], ustat[j], T(34 + 6 * j), T(35 + 6 * j), ua[j]);
     uin = ua[j];
@@ -513,10 +556,17 @@ static int dqn_fit_impl(ofx_handle *h, float *weights, float *adam_m, float *ada
   OFX_HIP(hipMemsetAsync(do1, 0, N * 2 * 4, st));
   OFX_HIP(hipMemsetAsync(do2, 0, N * 160000 * 4, st));
   if (dense) {
-    K(t_loss_dense, N * 2, N * 2, 1.f / (2.f * n), o1, t1, do1, loss);
-    K(t_loss_dense, N * 160000, N * 160000, 1.f / (160000.f * n), o2, t2, do2, loss + 1);
+    {
+      const int nb1 = (int)((N * 2 + 255) / 256), nb2 = (int)(N * 160000 / 256 > 2048 ? 2048 : (N * 160000 + 255) / 256);
+      hipLaunchKernelGGL(t_loss_dense, dim3(nb1), dim3(256), 0, st, N * 2, 1.f / (2.f * n), o1, t1, do1, lpart);
+      hipLaunchKernelGGL(t_sum_ordered, dim3(1), dim3(64), 0, st, nb1, 1, lpart, loss);
+      hipLaunchKernelGGL(t_loss_dense, dim3(nb2), dim3(256), 0, st, N * 160000, 1.f / (160000.f * n), o2, t2, do2, lpart + 2048);
+      hipLaunchKernelGGL(t_sum_ordered, dim3(1), dim3(64), 0, st, nb2, 1, lpart + 2048, loss + 1);
+      OFX_HIP(hipGetLastError());
+    }
   } else {
-    K(t_loss_seed, N, n, rows, o1, o2, y_act, y_ptr, do1, do2, loss);
+    K(t_loss_seed, N, n, rows, o1, o2, y_act, y_ptr, do1, do2, lpart);
+    hipLaunchKernelGGL(t_sum_ordered, dim3(1), dim3(64), 0, st, n, 2, lpart, loss);
   }
 
   // ---- backward: head 2 ----
@@ -524,22 +574,20 @@ static int dqn_fit_impl(ofx_handle *h, float *weights, float *adam_m, float *ada
   conv_bwd_weight(st, n, 8, 1, 400, 400, up4, do2, wpart, G(50), G(51));
   K(t_conv_bwd_data, N * 8 * 160000, n, 8, 1, 400, 400, do2, T(50), gA);   // d up4
   float *dcur = gB;                                                          // d ua[2]
-  OFX_HIP(hipMemsetAsync(dcur, 0, N * 8 * 40000 * 4, st));
-  K(t_up_bwd, N * 8 * 160000, n * 8, 200, 200, gA, dcur, legacy);
+  K(t_up_bwd, N * 8 * 40000, n * 8, 200, 200, gA, dcur, legacy);
   for (int j = 2, s = 200; j >= 0; j--, s /= 2) {
     const size_t per = (size_t)s * s, tot = N * kUO[j] * per;
     float *xh = gA;                                                          // reuse as xhat
     K(t_bn_relu_bwd_pre, tot, n, kUO[j], per, uz[j], ua[j], ustat[j], dcur, xh);
-    OFX_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 32, st));
-    hipLaunchKernelGGL(t_chan_sums, dim3(kUO[j], 64), dim3(256), 0, st, n, kUO[j], per, dcur, xh, sums);
+    hipLaunchKernelGGL(t_chan_sums, dim3(kUO[j], 64), dim3(256), 0, st, n, kUO[j], per, dcur, xh, spart);
+    hipLaunchKernelGGL(t_chan_sums_finish, dim3(1), dim3(64), 0, st, kUO[j], 64, spart, sums);
     float *dz = ua[j];                                                       // the activation is dead now: holds dz
     K(t_bn_bwd, tot, n, kUO[j], per, dcur, xh, ustat[j], T(34 + 6 * j), sums, dz, G(34 + 6 * j), G(35 + 6 * j));
     conv_bwd_weight(st, n, kUI[j], kUO[j], s, s, uu[j], dz, wpart, G(32 + 6 * j), G(33 + 6 * j));
     float *duu = gA;                                                         // d (upsampled input)
     K(t_conv_bwd_data, N * kUI[j] * per, n, kUI[j], kUO[j], s, s, dz, T(32 + 6 * j), duu);
     float *dprev = gB;                                                       // d (previous activation / u0)
-    OFX_HIP(hipMemsetAsync(dprev, 0, N * kUI[j] * per / 4 * 4, st));
-    K(t_up_bwd, N * kUI[j] * per, n * kUI[j], s / 2, s / 2, duu, dprev, legacy);
+    K(t_up_bwd, N * kUI[j] * per / 4, n * kUI[j], s / 2, s / 2, duu, dprev, legacy);
     dcur = dprev;
   }
   // dcur = d u0 [n][625] (pre-mask)
@@ -568,8 +616,8 @@ static int dqn_fit_impl(ofx_handle *h, float *weights, float *adam_m, float *ada
     xh = gB + N * 8 * 40000;                                                 // second half of gB (>= N*8*per for s <= 200)
     if (s == 400) xh = up4;                                                  // the 400^2 layer: up4 (8 x 400^2) is dead by now
     K(t_bn_relu_bwd_pre, tot, n, 8, per, tz[i], ta[i], tstat[i], da, xh);
-    OFX_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 32, st));
-    hipLaunchKernelGGL(t_chan_sums, dim3(8, 64), dim3(256), 0, st, n, 8, per, da, xh, sums);
+    hipLaunchKernelGGL(t_chan_sums, dim3(8, 64), dim3(256), 0, st, n, 8, per, da, xh, spart);
+    hipLaunchKernelGGL(t_chan_sums_finish, dim3(1), dim3(64), 0, st, 8, 64, spart, sums);
     float *dz = ta[i];
     K(t_bn_bwd, tot, n, 8, per, da, xh, tstat[i], T(6 * i + 2), sums, dz, G(6 * i + 2), G(6 * i + 3));
     const float *xin = i == 0 ? x0 : tp[i - 1];
@@ -637,6 +685,8 @@ extern "C" int ofx_dqn_fit_reference(ofx_handle *h, float *weights, float *adam_
   }
   OFX_HIP(hipSetDevice(h->cfg.device));
   hipStream_t st = h->stream;
+  int rc;
+  if ((rc = refuse_pads(h, n, rows, "ofx_dqn_fit_reference"))) return rc;  // before the two predict passes
   const size_t N = (size_t)n;
   float *buf = nullptr;  // vec_prev [n][8], vec_next [n][8], act_next [n][2], max_next [n], t1 [n][2], t2 [n][160000]
   OFX_HIP(hipMalloc((void **)&buf, sizeof(float) * N * (8 + 8 + 2 + 1 + 2 + 160000)));
@@ -647,7 +697,6 @@ extern "C" int ofx_dqn_fit_reference(ofx_handle *h, float *weights, float *adam_
   float *vec_prev = buf, *vec_next = vec_prev + 8 * N, *act_next = vec_next + 8 * N, *max_next = act_next + 2 * N;
   float *t1 = max_next + N, *t2 = t1 + 2 * N;
   K(t_unpack_heads, N, n, rows, vec_prev, vec_next);
-  int rc;
   if ((rc = ofx_policy_predict_obs(h, weights, n, bits_prev, vec_prev, t1, t2, nullptr))) return rc;
   if ((rc = ofx_policy_predict_obs(h, weights, n, bits_next, vec_next, act_next, nullptr, max_next))) return rc;
   K(t_reference_targets, N, n, rows, gamma, act_next, max_next, t1, t2);

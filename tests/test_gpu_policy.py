@@ -138,6 +138,16 @@ def test_trunk_fused_matches_split():
     b.set_option(nat.OPT_TRUNK_FUSE, 0)
     for k in split:
         assert np.array_equal(fused[k], split[k]), k
+    # fewer images than CUs
+    for n_small in (1, 2, 5):
+        bs = _rollout(n_small, M, seed=23 + n_small, ticks=10)
+        bs.set_option(nat.OPT_TRUNK_FUSE, 2)
+        ref = bs.policy_forward_host(w)
+        bs.set_option(nat.OPT_TRUNK_FUSE, 1)
+        got = bs.policy_forward_host(w)
+        for k in ref:
+            assert np.array_equal(got[k], ref[k]), (n_small, k)
+        bs.close()
     # and against the restatement for a few ships (the fused path is the one the full-size workloads run)
     head, _ = b.observe_head()
     sm, lm = b.maps_host(nat.MAP_U8)
@@ -292,6 +302,11 @@ def test_policy_full_size_properties():
     dm = DeviceBuffer(S).upload(mask)
     a3, i3, p3 = run(dm.ptr)
     assert np.array_equal(a3[:, 3], a1[:, 3]) and np.array_equal(p3[:, 3], p1[:, 3])
+    # the streaming trunk (the default at this size) against the split kernels: bit-identical for all 32768 ships
+    b.set_option(nat.OPT_TRUNK_FUSE, 2)
+    a4, i4, p4 = run()
+    b.set_option(nat.OPT_TRUNK_FUSE, 0)
+    assert np.array_equal(a4, a1) and np.array_equal(i4, i1) and np.array_equal(p4, p1)
     head, _ = b.observe_head()
     sm, lm = b.maps_host(nat.MAP_U8)
     rs = np.random.RandomState(2)

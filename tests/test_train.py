@@ -10,15 +10,18 @@ from oracle import pyoracle
 pytestmark = pytest.mark.gpu
 
 
-def _torch_reference(w, shapes, x0, vec8, iaction, px, py, y_act, y_ptr, legacy=False, dense=None):
-    """dense = (t1 [n][2], t2 [n][400][400]): whole target tensors (ofx_dqn_fit_reference) instead of one error per head."""
+def _torch_reference(w, shapes, x0, vec8, iaction, px, py, y_act, y_ptr, legacy=False, dense=None, dtype=None):
+    """dense = (t1 [n][2], t2 [n][400][400]): whole target tensors (ofx_dqn_fit_reference) instead of one error per head.
+    dtype: torch.float64 (the checker) or torch.float32 (how far plain fp32 autograd lands from it)."""
     import torch
     import torch.nn.functional as F
     from tests.policy_ref64 import upsample2
     torch.set_num_threads(8)
+    f64 = torch.float64
+    dt = dtype or f64
     P = {}
     for name, (o, shp) in shapes.items():
-        P[name] = torch.tensor(w[o:o + int(np.prod(shp))].reshape(shp), dtype=torch.float64, requires_grad=True)
+        P[name] = torch.tensor(w[o:o + int(np.prod(shp))].reshape(shp), dtype=dt, requires_grad=True)
     n = x0.shape[0]
     stats = {}
 
@@ -27,14 +30,14 @@ def _torch_reference(w, shapes, x0, vec8, iaction, px, py, y_act, y_ptr, legacy=
             x = upsample2(x, legacy)
         k = P[name + ".kernel"].permute(3, 2, 0, 1)           # HWIO -> OIHW
         z = F.conv2d(x, k, P[name + ".bias"], padding=1)
-        stats[name] = (z.mean(dim=(0, 2, 3)).detach(), z.var(dim=(0, 2, 3), unbiased=False).detach())
+        stats[name] = (z.mean(dim=(0, 2, 3)).detach().cpu(), z.var(dim=(0, 2, 3), unbiased=False).detach().cpu())
         return torch.relu(F.batch_norm(z, None, None, P[name + ".gamma"], P[name + ".beta"], training=True, eps=1e-3))
 
-    x = torch.tensor(x0, dtype=torch.float64)
+    x = torch.tensor(x0, dtype=dt)
     for i in (1, 2, 3, 4):
         x = F.max_pool2d(block(x, "conv%d" % i), 2)
     flat = x.permute(0, 2, 3, 1).reshape(n, 5000)
-    f = torch.cat([torch.tensor(vec8, dtype=torch.float64), flat], dim=1)
+    f = torch.cat([torch.tensor(vec8, dtype=dt), flat], dim=1)
     d1 = torch.relu(f @ P["dense1.kernel"] + P["dense1.bias"])
     d2 = torch.relu(d1 @ P["dense2.kernel"] + P["dense2.bias"])
     o1 = d2 @ P["output1.kernel"] + P["output1.bias"]
@@ -45,24 +48,28 @@ def _torch_reference(w, shapes, x0, vec8, iaction, px, py, y_act, y_ptr, legacy=
     o2 = F.conv2d(u, P["upconv4.kernel"].permute(3, 2, 0, 1), P["upconv4.bias"], padding=1)
     idx = torch.arange(n)
     if dense is not None:
-        e1 = o1 - torch.tensor(dense[0], dtype=torch.float64)
-        e2 = o2[:, 0] - torch.tensor(dense[1], dtype=torch.float64)
+        e1 = o1 - torch.tensor(dense[0], dtype=dt)
+        e2 = o2[:, 0] - torch.tensor(dense[1], dtype=dt)
     else:
-        e1 = o1[idx, torch.tensor(iaction)] - torch.tensor(y_act, dtype=torch.float64)
-        e2 = o2[idx, 0, torch.tensor(py), torch.tensor(px)] - torch.tensor(y_ptr, dtype=torch.float64)
+        e1 = o1[idx, torch.tensor(iaction)] - torch.tensor(y_act, dtype=dt)
+        e2 = o2[idx, 0, torch.tensor(py), torch.tensor(px)] - torch.tensor(y_ptr, dtype=dt)
     l1, l2 = (e1 ** 2).sum() / (2 * n), (e2 ** 2).sum() / (160000 * n)
     (l1 + l2).backward()
     g = np.zeros_like(w, dtype=np.float64)
     for name, (o, shp) in shapes.items():
         if P[name].grad is not None:
-            g[o:o + int(np.prod(shp))] = P[name].grad.numpy().ravel()
+            g[o:o + int(np.prod(shp))] = P[name].grad.detach().cpu().numpy().ravel()
     return float(l1.detach()), float(l2.detach()), g, stats
 
 
 def _compare_gradients(shapes, rg, g, loose=()):
     """gradients tensor by tensor: fp32 kernels vs the float64 checker
     (the bias of a convolution that feeds a BatchNorm has an exactly zero gradient: only rounding noise is left, so
-    the absolute part of the tolerance is tied to the layer's kernel gradient)"""
+    the absolute part of the tolerance is tied to the layer's kernel gradient).
+    `loose` layers: a ReLU whose input is within fp32 rounding of zero is gated one way in fp32 and the other way in
+    float64; the gradient of that ONE activation then differs by its full value, which shows as a localised error (a few
+    cells of u0 and their neighbours through the up-sampling) in the gradients that are short sums.  For those tensors
+    the check is on the structure of the error - rms, share of outliers, a cap on the worst element - instead of max."""
     report = []
     for name, (o, shp) in shapes.items():
         c = int(np.prod(shp))
@@ -73,8 +80,15 @@ def _compare_gradients(shapes, rg, g, loose=()):
         ko, kshp = shapes[layer + ".kernel"]
         kscale = float(np.abs(rg[ko:ko + int(np.prod(kshp))]).max())
         scale, err = float(np.abs(ref).max()), float(np.abs(got - ref).max())
-        rel = 3e-3 if layer in loose else 1e-4
-        report.append((name, scale, err, err <= rel * scale + 5e-5 * kscale))
+        if layer in loose:
+            tol = 1e-4 * scale + 5e-5 * kscale
+            rms = float(np.sqrt(((got - ref) ** 2).mean()))
+            outliers = float((np.abs(got - ref) > tol).mean())
+            ok = rms <= tol and outliers <= 0.03 and err <= 3e-3 * scale
+            report.append((name, scale, err, ok))
+            print("%-18s rms %.2e of scale, %.2f %% of the elements above 1e-4, worst %.2e" % (name, rms / scale, 100 * outliers, err / scale))
+        else:
+            report.append((name, scale, err, err <= 1e-4 * scale + 5e-5 * kscale))
     print("\n".join("%-18s scale %.3e  err %.3e  %s" % r for r in report))
     assert all(r[3] for r in report), [r for r in report if not r[3]]
 
@@ -188,9 +202,10 @@ def test_dqn_fit_reference_quirks():
     rl1, rl2, rg, _ = _torch_reference(w.astype(np.float64), shapes, xn.astype(np.float64), rows["head_next"], None, None,
                                        None, None, None, dense=(t1, t2))
     assert abs(l1 - rl1) <= 2e-4 * max(1.0, abs(rl1)) and abs(l2 - rl2) <= 2e-4 * max(1e-9, abs(rl2)) + 1e-12, (l1, rl1, l2, rl2)
-    # with a dense error field d(u0) is, per element, a sum of ~10^5 mixed-sign terms that BatchNorm's backward makes
-    # cancel (sum dz = 0 per channel): the fp32 kernels' rounding shows at 1.25e-3 of updense1's gradient scale (measured),
-    # every other tensor stays inside the 1e-4 of the textbook step
+    # Every tensor inside 1e-4 of its scale except updense1 (1.25e-3).  tools/fit_precision.py (r03, on the chip)
+    # attributes it: the error sits in 7 of the 625 cells of u0 (one cluster; rms 6e-5 of the scale) - one ReLU gate
+    # that fp32 and float64 decide differently - not in cancellation noise as r02 guessed: torch's own fp32 autograd on
+    # the CPU lands at 1.7e-6 on this minibatch (its rounding leaves that activation on the float64 side).
     _compare_gradients(shapes, rg, g, loose=("updense1",))
     b.close()
 
@@ -242,8 +257,8 @@ def test_short_memories_are_not_padded_into_the_fit():
     """An arena that holds fewer transitions than the batch size gives -1 pads in ofx_replay_gather (their maps are
     zeroed, not left uninitialised); ofx_replay_gather_valid packs only the real rows - the form Trainer.replay works
     on, batch = min(batch_size, len(memory)) (qlearnIA_V2.py:241-243) - and ofx_dqn_fit refuses a padded batch.  Two
-    fits of the packed batch from identical state give the same gradients (to the last bits: the fit's reductions use
-    double-precision atomics, whose order is not fixed)."""
+    fits of the packed batch from identical state give the SAME BITS (gradients, updated weights, losses): every
+    reduction of the fit combines its partial sums in a fixed order, there is no atomic in it."""
     from ofighters_amd import ArenaBatch, DeviceBuffer
     N, M, seed, bs = 3, 4, 11, 6
     b = ArenaBatch(N, M)
@@ -292,12 +307,23 @@ def test_short_memories_are_not_padded_into_the_fit():
         b.dqn_fit(w_d, m_d, v_d, 1, 1e-4, n_all, rows_d.ptr, bp_d.ptr, y.ptr, y.ptr)
     assert np.array_equal(w_d.download(np.float32, w.shape), w)       # nothing was updated
     # ... and is deterministic on the packed batch
-    grads = []
+    grads, news, losses = [], [], []
     for _ in range(2):
         w_d.upload(w); m_d.upload(zeros); v_d.upload(zeros)
         g_d = DeviceBuffer(w.nbytes)
-        b.dqn_fit(w_d, m_d, v_d, 1, 1e-4, total, rows.ptr, bp.ptr, y.ptr, y.ptr, g_d)
+        losses.append(b.dqn_fit(w_d, m_d, v_d, 1, 1e-4, total, rows.ptr, bp.ptr, y.ptr, y.ptr, g_d))
         grads.append(g_d.download(np.float32, w.shape))
-    assert np.isfinite(grads[0]).all()
-    assert np.abs(grads[0] - grads[1]).max() <= 1e-6 * np.abs(grads[0]).max()
+        news.append(w_d.download(np.float32, w.shape))
+    assert np.isfinite(grads[0]).all() and np.abs(grads[0]).max() > 0
+    assert np.array_equal(grads[0], grads[1]) and np.array_equal(news[0], news[1]) and losses[0] == losses[1]
+    # the reference's step as written (dense targets: the other loss / seed kernels), twice: the same bits too
+    outs = []
+    for _ in range(2):
+        w_d.upload(w); m_d.upload(zeros); v_d.upload(zeros)
+        g_d = DeviceBuffer(w.nbytes)
+        l = b.dqn_fit_reference(w_d, m_d, v_d, 1, 1e-4, total, rows.ptr, bp.ptr, bn.ptr, 0.9, g_d)
+        outs.append((l, g_d.download(np.float32, w.shape), w_d.download(np.float32, w.shape)))
+    assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
+    with pytest.raises(Exception, match="padding"):     # refused before its two predict passes
+        b.dqn_fit_reference(w_d, m_d, v_d, 1, 1e-4, n_all, rows_d.ptr, bp_d.ptr, bn_d.ptr, 0.9)
     b.close()
