@@ -60,6 +60,10 @@ struct ofx_handle {
   ofx_replay *replay;              // transition memory (ofx_replay_create), null = none
   void *aux;                       // temporaries of ofx_dqn_targets (grown on demand)
   size_t aux_bytes;
+  void *fitws;                     // workspace of ofx_dqn_fit / ofx_dqn_fit_reference, kept between calls (a fresh 4 GB
+  size_t fitws_bytes;              // hipMalloc per replay cost ~60 ms of mapping: r03), grown on demand
+  void *fitws2;                    // the reference form's dense targets, kept likewise
+  size_t fitws2_bytes;
   int32_t *counter;                // [4] small device counter of the fit's argument checks (allocated on first use)
   float *prep;                     // prepared policy weights (BN folded, phase weights, tables): ofx_policy.hip
   float *prep_tmp;                 // the same for a blob that is not the pinned one (rebuilt per forward)

@@ -449,6 +449,17 @@ __global__ void t_count_pads(int n, const ofx_transition *rows, int32_t *out) {
   if (i < n && rows[i].ship < 0) atomicAdd(out, 1);
 }
 
+// a workspace the handle keeps between calls (grown on demand; freed by ofx_destroy)
+static int keep_workspace(ofx_handle *h, void **buf, size_t *have, size_t need) {
+  if (*have >= need) return OFX_OK;
+  OFX_HIP(hipStreamSynchronize(h->stream));
+  if (*buf) (void)hipFree(*buf);
+  *buf = nullptr; *have = 0;
+  OFX_HIP(hipMalloc(buf, need));
+  *have = need;
+  return OFX_OK;
+}
+
 // padding rows (ship < 0) would enter the BatchNorm batch statistics and the loss scale: refused before any work is done
 static int refuse_pads(ofx_handle *h, int n, const ofx_transition *rows, const char *who) {
   hipStream_t st = h->stream;
@@ -493,12 +504,8 @@ static int dqn_fit_impl(ofx_handle *h, float *weights, float *adam_m, float *ada
     sz(N * 5008); sz(N * 100); sz(N * 100); sz(N * 50); sz(N * 2); sz(N * 625); sz(N * 160000);
     sz(L.n_floats); sz(64); sz(2 * N + 4096); need += 65536 + 16 * 64 * 8 + 16 * 64 * 2 * 8 + (size_t)kWSlices * 600 * 8;
   }
-  void *raw = nullptr;
-  OFX_HIP(hipMalloc(&raw, need));
-  struct Release {  // the error paths below return early: the block must not leak (and must not be freed under running kernels)
-    void *p; hipStream_t st;
-    ~Release() { if (p) { (void)hipStreamSynchronize(st); (void)hipFree(p); } }
-  } release{raw, st};
+  if ((rc = keep_workspace(h, &h->fitws, &h->fitws_bytes, need))) return rc;
+  void *raw = h->fitws;
   Arena A{(char *)raw, 0, need};
   const float *W_ = weights;
   auto T = [&](int t) { return weights + L.offset[t]; };
@@ -652,7 +659,7 @@ static int dqn_fit_impl(ofx_handle *h, float *weights, float *adam_m, float *ada
   if (loss_host) { loss_host[0] = lh[0]; loss_host[1] = lh[1]; }
   (void)W_;
   if ((rc = ofx_policy_weights_updated(h, weights))) return rc;  // a pinned blob is prepared again
-  return OFX_OK;  // `release` frees the block (the stream is idle: synchronised above)
+  return OFX_OK;
 }
 
 extern "C" int ofx_dqn_fit(ofx_handle *h, float *weights, float *adam_m, float *adam_v, int32_t step, float lr, int32_t n,
@@ -688,12 +695,9 @@ extern "C" int ofx_dqn_fit_reference(ofx_handle *h, float *weights, float *adam_
   int rc;
   if ((rc = refuse_pads(h, n, rows, "ofx_dqn_fit_reference"))) return rc;  // before the two predict passes
   const size_t N = (size_t)n;
-  float *buf = nullptr;  // vec_prev [n][8], vec_next [n][8], act_next [n][2], max_next [n], t1 [n][2], t2 [n][160000]
-  OFX_HIP(hipMalloc((void **)&buf, sizeof(float) * N * (8 + 8 + 2 + 1 + 2 + 160000)));
-  struct Release {
-    void *p; hipStream_t st;
-    ~Release() { (void)hipStreamSynchronize(st); (void)hipFree(p); }
-  } release{buf, st};
+  // vec_prev [n][8], vec_next [n][8], act_next [n][2], max_next [n], t1 [n][2], t2 [n][160000]
+  if ((rc = keep_workspace(h, &h->fitws2, &h->fitws2_bytes, sizeof(float) * N * (8 + 8 + 2 + 1 + 2 + 160000)))) return rc;
+  float *buf = (float *)h->fitws2;
   float *vec_prev = buf, *vec_next = vec_prev + 8 * N, *act_next = vec_next + 8 * N, *max_next = act_next + 2 * N;
   float *t1 = max_next + N, *t2 = t1 + 2 * N;
   K(t_unpack_heads, N, n, rows, vec_prev, vec_next);
