@@ -1244,8 +1244,9 @@ static int launch_conv(ofx_handle *h, ConvParams p, int images, int H) {
   return OFX_OK;
 }
 
-static int launch_gemm(ofx_handle *h, const float *A, int lda, const float *B, int ldb, const float *bias, float *C,
-                       int ldc, int M, int N, int K, int relu) {
+// (also the dense layers of the fit's forward, ofx_train.hip)
+int ofx_launch_gemm(ofx_handle *h, const float *A, int lda, const float *B, int ldb, const float *bias, float *C, int ldc,
+                    int M, int N, int K, int relu) {
   const int tiles = ((M + 31) / 32) * ((N + 31) / 32);
   hipLaunchKernelGGL(k_gemm_f32, dim3((tiles + 3) / 4), dim3(256), 0, h->stream, A, lda, B, ldb, bias, C, ldc, M, N, K,
                      relu);
@@ -1403,7 +1404,7 @@ static int policy_forward_impl(ofx_handle *h, const float *weights, int N, int M
   OFX_HIP(hipGetLastError());
 
   // 3. head-2: updense1 on MFMA, upconv1 (1 -> 2 @ 50x50), then upconv2-4 + arg-max in the streaming kernel (ofx_head.hip)
-  if ((rc = launch_gemm(h, ws.d1, 100, weights + off[t_ud], 625, weights + off[t_ud + 1], ws.u0, 625, S, 625, 100, 1)))
+  if ((rc = ofx_launch_gemm(h, ws.d1, 100, weights + off[t_ud], 625, weights + off[t_ud + 1], ws.u0, 625, S, 625, 100, 1)))
     return rc;
   ConvParams up;
   memset(&up, 0, sizeof(up));

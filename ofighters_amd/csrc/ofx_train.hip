@@ -1,9 +1,10 @@
 // ofx_train.hip - one DQN fit step of the bi-head pointer_model: the model.fit call of
 // Trainer.replay (agents/qlearnIA_V2.py:284; model.compile(loss='mse', optimizer=Adam(lr)) :190).
 //
-// Straightforward reference-quality kernels (one thread per output element, plain loops, fp32): this path runs once
-// per 50 environment steps on a minibatch, it is not the hot path and is NOT tuned - correctness first (checked
-// against torch autograd, tests/test_train.py).  Keras semantics assumed (parity unpinned: no keras in the image):
+// Plain fp32 VALU kernels with fixed-order reductions (no atomics: a fit is reproducible to the bit); the convolutions
+// keep all channels of a pixel in registers, the dense forwards run on the f32 MFMA GEMM of the forward.  This path runs
+// on the reference's replay schedule on a minibatch; it is not the hot path - correctness first (every gradient tensor
+// checked against torch autograd in float64, tests/test_train.py).  Keras semantics assumed (parity unpinned: no keras in the image):
 //   * fit runs the graph in training mode: BatchNorm normalises with the batch mean / biased variance (eps 1e-3) and
 //     moves the stored statistics: moving = 0.99 moving + 0.01 batch;
 //   * loss = mse(output1) + mse(output2), each the mean over the batch and the output elements;
@@ -26,91 +27,130 @@ __global__ void t_bits_to_f32(int n, const uint32_t *bits, float *x) {  // bits 
   }
 }
 
-// z[n][co][H][W] = conv3x3(x[n][ci][H][W], w HWIO [3][3][ci][co]) + b[co], zero padding
-__global__ void t_conv_fwd(int n, int ci_n, int co_n, int H, int W, const float *x, const float *w, const float *b, float *z) {
-  const size_t total = (size_t)n * co_n * H * W;
+// z[n][co][H][W] = conv3x3(x[n][ci][H][W], w HWIO [3][3][ci][co]) + b[co], zero padding.  One thread per PIXEL with all
+// CO outputs in registers: an input value is loaded once for the CO channels (the weights are wave-uniform reads); per
+// output the terms are added in the order (ci, ky, kx), one rounding per operation (-ffp-contract=off).
+template <int CO>
+__global__ void t_conv_fwd(int n, int ci_n, int H, int W, const float *x, const float *w, const float *b, float *z) {
+  const size_t per = (size_t)H * W, total = (size_t)n * per;
   for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-    const int xx = e % W, yy = (e / W) % H, co = (e / ((size_t)W * H)) % co_n, s = e / ((size_t)W * H * co_n);
-    float acc = b[co];
+    const int xx = e % W, yy = (e / W) % H;
+    const size_t s = e / per;
+    float acc[CO];
+#pragma unroll
+    for (int co = 0; co < CO; co++) acc[co] = b[co];
     for (int ci = 0; ci < ci_n; ci++) {
-      const float *xp = x + ((size_t)s * ci_n + ci) * H * W;
+      const float *xp = x + (s * ci_n + ci) * per;
+#pragma unroll
       for (int ky = 0; ky < 3; ky++) {
         const int y = yy + ky - 1;
         if (y < 0 || y >= H) continue;
+#pragma unroll
         for (int kx = 0; kx < 3; kx++) {
           const int xq = xx + kx - 1;
           if (xq < 0 || xq >= W) continue;
-          acc += xp[(size_t)y * W + xq] * w[((ky * 3 + kx) * ci_n + ci) * co_n + co];
+          const float v = xp[(size_t)y * W + xq];
+          const float *wp = w + ((ky * 3 + kx) * ci_n + ci) * CO;
+#pragma unroll
+          for (int co = 0; co < CO; co++) acc[co] += v * wp[co];
         }
       }
     }
-    z[e] = acc;
+#pragma unroll
+    for (int co = 0; co < CO; co++) z[(s * CO + co) * per + (size_t)yy * W + xx] = acc[co];
   }
 }
 
-// dx[n][ci][H][W] = sum_co conv3x3_transposed(dz[n][co], w)
-__global__ void t_conv_bwd_data(int n, int ci_n, int co_n, int H, int W, const float *dz, const float *w, float *dx) {
-  const size_t total = (size_t)n * ci_n * H * W;
+// dx[n][ci][H][W] = sum_co conv3x3_transposed(dz[n][co], w): one thread per pixel with all CI inputs in registers
+template <int CI>
+__global__ void t_conv_bwd_data(int n, int co_n, int H, int W, const float *dz, const float *w, float *dx) {
+  const size_t per = (size_t)H * W, total = (size_t)n * per;
   for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-    const int xx = e % W, yy = (e / W) % H, ci = (e / ((size_t)W * H)) % ci_n, s = e / ((size_t)W * H * ci_n);
-    float acc = 0.f;
+    const int xx = e % W, yy = (e / W) % H;
+    const size_t s = e / per;
+    float acc[CI];
+#pragma unroll
+    for (int ci = 0; ci < CI; ci++) acc[ci] = 0.f;
     for (int co = 0; co < co_n; co++) {
-      const float *dp = dz + ((size_t)s * co_n + co) * H * W;
+      const float *dp = dz + (s * co_n + co) * per;
+#pragma unroll
       for (int ky = 0; ky < 3; ky++) {
         const int y = yy - (ky - 1);  // output pixel that read this input through tap ky
         if (y < 0 || y >= H) continue;
+#pragma unroll
         for (int kx = 0; kx < 3; kx++) {
           const int xq = xx - (kx - 1);
           if (xq < 0 || xq >= W) continue;
-          acc += dp[(size_t)y * W + xq] * w[((ky * 3 + kx) * ci_n + ci) * co_n + co];
+          const float v = dp[(size_t)y * W + xq];
+          const float *wp = w + (size_t)(ky * 3 + kx) * CI * co_n + co;
+#pragma unroll
+          for (int ci = 0; ci < CI; ci++) acc[ci] += v * wp[ci * co_n];
         }
       }
     }
-    dx[e] = acc;
+#pragma unroll
+    for (int ci = 0; ci < CI; ci++) dx[(s * CI + ci) * per + (size_t)yy * W + xx] = acc[ci];
   }
 }
 
-// dw[(ky,kx,ci,co)] = sum_{n,y,x} x[n][ci][y+ky-1][x+kx-1] dz[n][co][y][x] ; one workgroup per weight, tree reduction
-// (double accumulators: up to 10^7 terms); workgroups 9*ci*co .. +co-1 reduce db[co] = sum dz
+// dw[(ky,kx,ci,co)] = sum_{n,y,x} x[n][ci][y+ky-1][x+kx-1] dz[n][co][y][x] (double accumulators: up to 10^7 terms).
+// block = a block of CIB input channels x a block of COB output channels x one of gridDim.y slices of the (n, H, W) sum:
+// a pixel's input taps and output gradients are loaded once for the CIB x COB weight columns; db[co] = sum dz comes from
+// the blocks of input-channel block 0.  part[slice][wid], combined in slice order by t_conv_bwd_finish.
+template <int CIB, int COB>
 __global__ __launch_bounds__(256) void t_conv_bwd_weight(int n, int ci_n, int co_n, int H, int W, const float *x,
                                                          const float *dz, double *part) {
-  // block = one (ci, co) pair x one of gridDim.y slices of the (n, H, W) sum: dz is read once for the nine taps (and the
-  // bias, by the ci == 0 blocks); part[slice][wid], combined in fixed order by t_conv_bwd_finish
-  __shared__ double red[4][10];
-  const int co = blockIdx.x % co_n, ci = blockIdx.x / co_n, nw = 9 * ci_n * co_n;
+  constexpr int NV = CIB * COB * 9 + COB;
+  __shared__ double red[4][NV];
+  const int cob = co_n / COB;                                      // co_n is a multiple of COB, ci_n of CIB
+  const int co0 = (blockIdx.x % cob) * COB, ci0 = (blockIdx.x / cob) * CIB, nw = 9 * ci_n * co_n;
   const size_t per = (size_t)H * W, total = (size_t)n * per, stride = (size_t)gridDim.y * 256;
-  double acc[10];
+  double acc[NV];
 #pragma unroll
-  for (int k = 0; k < 10; k++) acc[k] = 0.0;
+  for (int k = 0; k < NV; k++) acc[k] = 0.0;
   for (size_t e = (size_t)blockIdx.y * 256 + threadIdx.x; e < total; e += stride) {
     const int s = e / per, yy = (e - (size_t)s * per) / W, xx = e % W;
-    const double g = dz[((size_t)s * co_n + co) * per + (size_t)yy * W + xx];
-    const float *xs = x + ((size_t)s * ci_n + ci) * per;
-    acc[9] += g;
+    double g[COB];
 #pragma unroll
-    for (int ky = 0; ky < 3; ky++) {
-      const int y = yy + ky - 1;
-      if (y < 0 || y >= H) continue;
+    for (int c = 0; c < COB; c++) {
+      g[c] = dz[((size_t)s * co_n + co0 + c) * per + (size_t)yy * W + xx];
+      acc[CIB * COB * 9 + c] += g[c];
+    }
 #pragma unroll
-      for (int kx = 0; kx < 3; kx++) {
-        const int xq = xx + kx - 1;
-        if (xq >= 0 && xq < W) acc[ky * 3 + kx] += (double)xs[(size_t)y * W + xq] * g;
+    for (int i = 0; i < CIB; i++) {
+      const float *xs = x + ((size_t)s * ci_n + ci0 + i) * per;
+#pragma unroll
+      for (int ky = 0; ky < 3; ky++) {
+        const int y = yy + ky - 1;
+        if (y < 0 || y >= H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) {
+          const int xq = xx + kx - 1;
+          if (xq < 0 || xq >= W) continue;
+          const double v = (double)xs[(size_t)y * W + xq];
+#pragma unroll
+          for (int c = 0; c < COB; c++) acc[(i * COB + c) * 9 + ky * 3 + kx] += v * g[c];
+        }
       }
     }
   }
 #pragma unroll
-  for (int k = 0; k < 10; k++) {
+  for (int k = 0; k < NV; k++) {
     double v = acc[k];
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
   }
   __syncthreads();
-  if (threadIdx.x < 10) {
+  if (threadIdx.x < NV) {
     const int k = threadIdx.x;
     const double v = red[0][k] + red[1][k] + red[2][k] + red[3][k];
     double *row = part + (size_t)blockIdx.y * (nw + co_n);
-    if (k < 9) row[(k * ci_n + ci) * co_n + co] = v;
-    else if (ci == 0) row[nw + co] = v;
+    if (k < CIB * COB * 9) {
+      const int t = k % 9, ic = k / 9, i = ic / COB, c = ic % COB;
+      row[(t * ci_n + ci0 + i) * co_n + co0 + c] = v;
+    } else if (ci0 == 0) {
+      row[nw + co0 + (k - CIB * COB * 9)] = v;
+    }
   }
 }
 
@@ -129,13 +169,14 @@ __global__ void t_conv_bwd_finish(int nw, int nb, int slices, const double *part
 __global__ __launch_bounds__(256) void t_chan_sums(int n, int c_n, size_t per, const float *a, const float *b, double *part) {
   __shared__ double r0[256], r1[256];
   const int c = blockIdx.x;
-  const size_t total = (size_t)n * per;
   double s0 = 0.0, s1 = 0.0;
-  for (size_t e = (size_t)blockIdx.y * 256 + threadIdx.x; e < total; e += (size_t)gridDim.y * 256) {
-    const size_t s = e / per, idx = (s * c_n + c) * per + (e - s * per);
-    const double va = a[idx], vb = b ? b[idx] : va;
-    s0 += va;
-    s1 += va * vb;
+  for (int s = 0; s < n; s++) {                                    // the channel's plane of every sample, slice by slice
+    const float *pa = a + ((size_t)s * c_n + c) * per, *pb = b ? b + ((size_t)s * c_n + c) * per : pa;
+    for (size_t i = (size_t)blockIdx.y * 256 + threadIdx.x; i < per; i += (size_t)gridDim.y * 256) {
+      const double va = pa[i], vb = pb[i];
+      s0 += va;
+      s1 += va * vb;
+    }
   }
   r0[threadIdx.x] = s0; r1[threadIdx.x] = s1;
   __syncthreads();
@@ -162,38 +203,43 @@ __global__ void t_bn_finish_stats(int c_n, double count, const double *sums, flo
   stat[2 * c + 1] = (float)(v > 0.0 ? v : 0.0);
 }
 
+// The three BatchNorm element-wise kernels: blockIdx.y = plane (sample s, channel c) of `per` elements - the channel is
+// block-uniform, no division per element.
 // a = relu(gamma * (z - mean) / sqrt(var + eps) + beta)
-__global__ void t_bn_relu_fwd(int n, int c_n, size_t per, const float *z, const float *stat, const float *gamma,
-                              const float *beta, float *a) {
-  const size_t total = (size_t)n * c_n * per;
-  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-    const int c = (e / per) % c_n;
-    const float xh = (z[e] - stat[2 * c]) * rsqrtf(stat[2 * c + 1] + 1e-3f);
-    a[e] = fmaxf(gamma[c] * xh + beta[c], 0.f);
+__global__ void t_bn_relu_fwd(int c_n, size_t per, const float *z, const float *stat, const float *gamma, const float *beta,
+                              float *a) {
+  const int c = blockIdx.y % c_n;
+  const size_t base = (size_t)blockIdx.y * per;
+  const float mean = stat[2 * c], rs = rsqrtf(stat[2 * c + 1] + 1e-3f), g = gamma[c], bt = beta[c];
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < per; i += (size_t)gridDim.x * blockDim.x) {
+    const float xh = (z[base + i] - mean) * rs;
+    a[base + i] = fmaxf(g * xh + bt, 0.f);
   }
 }
 
 // dy (w.r.t. the BN output, ReLU mask applied) and xhat, in place over da / into xh
-__global__ void t_bn_relu_bwd_pre(int n, int c_n, size_t per, const float *z, const float *a, const float *stat, float *da,
-                                  float *xh) {
-  const size_t total = (size_t)n * c_n * per;
-  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-    const int c = (e / per) % c_n;
-    xh[e] = (z[e] - stat[2 * c]) * rsqrtf(stat[2 * c + 1] + 1e-3f);
-    if (!(a[e] > 0.f)) da[e] = 0.f;
+__global__ void t_bn_relu_bwd_pre(int c_n, size_t per, const float *z, const float *a, const float *stat, float *da, float *xh) {
+  const int c = blockIdx.y % c_n;
+  const size_t base = (size_t)blockIdx.y * per;
+  const float mean = stat[2 * c], rs = rsqrtf(stat[2 * c + 1] + 1e-3f);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < per; i += (size_t)gridDim.x * blockDim.x) {
+    xh[base + i] = (z[base + i] - mean) * rs;
+    if (!(a[base + i] > 0.f)) da[base + i] = 0.f;
   }
 }
 
 // dz = gamma / sqrt(var+eps) * (dy - mean(dy) - xhat * mean(dy * xhat)) ; sums[c] = {sum dy, sum dy*xhat}
-__global__ void t_bn_bwd(int n, int c_n, size_t per, const float *dy, const float *xh, const float *stat, const float *gamma,
-                         const double *sums, float *dz, float *dgamma, float *dbeta) {
-  const size_t total = (size_t)n * c_n * per;
-  const double count = (double)n * (double)per;
-  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-    const int c = (e / per) % c_n;
-    const float m0 = (float)(sums[2 * c] / count), m1 = (float)(sums[2 * c + 1] / count);
-    dz[e] = gamma[c] * rsqrtf(stat[2 * c + 1] + 1e-3f) * (dy[e] - m0 - xh[e] * m1);
-    if (e < (size_t)c_n) { dbeta[e] = (float)sums[2 * e]; dgamma[e] = (float)sums[2 * e + 1]; }
+__global__ void t_bn_bwd(int c_n, size_t per, double count, const float *dy, const float *xh, const float *stat,
+                         const float *gamma, const double *sums, float *dz, float *dgamma, float *dbeta) {
+  const int c = blockIdx.y % c_n;
+  const size_t base = (size_t)blockIdx.y * per;
+  const float m0 = (float)(sums[2 * c] / count), m1 = (float)(sums[2 * c + 1] / count);
+  const float k = gamma[c] * rsqrtf(stat[2 * c + 1] + 1e-3f);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < per; i += (size_t)gridDim.x * blockDim.x)
+    dz[base + i] = k * (dy[base + i] - m0 - xh[base + i] * m1);
+  if (blockIdx.x == 0 && blockIdx.y < (unsigned)c_n && threadIdx.x == 0) {
+    dbeta[blockIdx.y] = (float)sums[2 * blockIdx.y];
+    dgamma[blockIdx.y] = (float)sums[2 * blockIdx.y + 1];
   }
 }
 
@@ -277,16 +323,6 @@ __global__ void t_up_bwd(int nc, int H, int W, const float *du, float *dx, int l
   }
 }
 
-// y[n][out] = act(x[n][in] W[in][out] + b)
-__global__ void t_dense_fwd(int n, int in_n, int out_n, const float *x, const float *w, const float *b, float *y, int relu) {
-  const size_t total = (size_t)n * out_n;
-  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-    const int o = e % out_n, s = e / out_n;
-    float acc = b[o];
-    for (int k = 0; k < in_n; k++) acc += x[(size_t)s * in_n + k] * w[(size_t)k * out_n + o];
-    y[e] = relu ? fmaxf(acc, 0.f) : acc;
-  }
-}
 // dy masked by the ReLU of y (in place) when relu
 __global__ void t_relu_mask(size_t total, const float *y, float *dy) {
   for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x)
@@ -431,7 +467,7 @@ struct Arena {  // bump allocator over one hipMalloc
 
 static const int kTI[4] = {2, 8, 8, 8}, kUI[4] = {1, 2, 4, 8}, kUO[4] = {2, 4, 8, 1};
 
-static const int kWSlices = 64;
+static const int kWSlices = 128;
 
 static void conv_bwd_weight(hipStream_t st, int n, int ci, int co, int H, int W, const float *x, const float *dz,
                             double *part, float *dw, float *db) {
@@ -440,8 +476,42 @@ static void conv_bwd_weight(hipStream_t st, int n, int ci, int co, int H, int W,
   const size_t total = (size_t)n * H * W;
   int slices = (int)((total + 16383) / 16384);
   slices = slices < 1 ? 1 : slices > kWSlices ? kWSlices : slices;
-  hipLaunchKernelGGL(t_conv_bwd_weight, dim3(ci * co, slices), dim3(256), 0, st, n, ci, co, H, W, x, dz, part);
+#define BWW(CIB, COB) hipLaunchKernelGGL((t_conv_bwd_weight<CIB, COB>), dim3((ci / CIB) * (co / COB), slices), dim3(256), 0, st, n, ci, co, H, W, x, dz, part)
+  if (co % 4 == 0) BWW(1, 4);
+  else if (co % 2 == 0 && ci % 2 == 0) BWW(2, 2);
+  else if (co % 2 == 0) BWW(1, 2);
+  else if (ci % 4 == 0) BWW(4, 1);
+  else BWW(1, 1);
+#undef BWW
   hipLaunchKernelGGL(t_conv_bwd_finish, dim3((nw + co + 255) / 256), dim3(256), 0, st, nw, co, slices, part, dw, db);
+}
+
+// one blockIdx.y per (sample, channel) plane of `per` elements, up to 64 blocks of 256 threads along it
+#define PLANES(per, planes) dim3((unsigned)(((per) + 255) / 256 > 64 ? 64 : ((per) + 255) / 256), (unsigned)(planes)), dim3(256)
+#define GRIDP(total) dim3((unsigned)(((total) + 255) / 256 > 65535 * 16 ? 65535 * 16 : ((total) + 255) / 256)), dim3(256)
+static int conv_fwd(hipStream_t st, int n, int ci, int co, int H, int W, const float *x, const float *w, const float *b, float *z) {
+  const size_t px = (size_t)n * H * W;
+  switch (co) {
+    case 8: hipLaunchKernelGGL(t_conv_fwd<8>, GRIDP(px), 0, st, n, ci, H, W, x, w, b, z); break;
+    case 4: hipLaunchKernelGGL(t_conv_fwd<4>, GRIDP(px), 0, st, n, ci, H, W, x, w, b, z); break;
+    case 2: hipLaunchKernelGGL(t_conv_fwd<2>, GRIDP(px), 0, st, n, ci, H, W, x, w, b, z); break;
+    case 1: hipLaunchKernelGGL(t_conv_fwd<1>, GRIDP(px), 0, st, n, ci, H, W, x, w, b, z); break;
+    default: ofx_set_error("ofx_dqn_fit: no conv kernel for %d output channels", co); return OFX_ERR_STATE;
+  }
+  OFX_HIP(hipGetLastError());
+  return OFX_OK;
+}
+static int conv_bwd_data(hipStream_t st, int n, int ci, int co, int H, int W, const float *dz, const float *w, float *dx) {
+  const size_t px = (size_t)n * H * W;
+  switch (ci) {
+    case 8: hipLaunchKernelGGL(t_conv_bwd_data<8>, GRIDP(px), 0, st, n, co, H, W, dz, w, dx); break;
+    case 4: hipLaunchKernelGGL(t_conv_bwd_data<4>, GRIDP(px), 0, st, n, co, H, W, dz, w, dx); break;
+    case 2: hipLaunchKernelGGL(t_conv_bwd_data<2>, GRIDP(px), 0, st, n, co, H, W, dz, w, dx); break;
+    case 1: hipLaunchKernelGGL(t_conv_bwd_data<1>, GRIDP(px), 0, st, n, co, H, W, dz, w, dx); break;
+    default: ofx_set_error("ofx_dqn_fit: no conv kernel for %d input channels", ci); return OFX_ERR_STATE;
+  }
+  OFX_HIP(hipGetLastError());
+  return OFX_OK;
 }
 
 __global__ void t_count_pads(int n, const ofx_transition *rows, int32_t *out) {
@@ -527,36 +597,37 @@ static int dqn_fit_impl(ofx_handle *h, float *weights, float *adam_m, float *ada
   for (int i = 0, s = 400; i < 4; i++, s /= 2) {
     const size_t per = (size_t)s * s;
     tz[i] = A.f(N * 8 * per); ta[i] = A.f(N * 8 * per); tp[i] = A.f(N * 8 * per / 4); tstat[i] = A.f(16);
-    K(t_conv_fwd, N * 8 * per, n, kTI[i], 8, s, s, tin, T(6 * i), T(6 * i + 1), tz[i]);
+    if ((rc = conv_fwd(st, n, kTI[i], 8, s, s, tin, T(6 * i), T(6 * i + 1), tz[i]))) return rc;
     hipLaunchKernelGGL(t_chan_sums, dim3(8, 64), dim3(256), 0, st, n, 8, per, tz[i], (const float *)nullptr, spart);
     hipLaunchKernelGGL(t_chan_sums_finish, dim3(1), dim3(64), 0, st, 8, 64, spart, sums);
     hipLaunchKernelGGL(t_bn_finish_stats, dim3(1), dim3(64), 0, st, 8, (double)N * (double)per, sums, tstat[i]);
-    K(t_bn_relu_fwd, N * 8 * per, n, 8, per, tz[i], tstat[i], T(6 * i + 2), T(6 * i + 3), ta[i]);
+    hipLaunchKernelGGL(t_bn_relu_fwd, PLANES(per, n * 8), 0, st, 8, per, tz[i], tstat[i], T(6 * i + 2), T(6 * i + 3), ta[i]);
     K(t_pool_fwd, N * 8 * per / 4, n * 8, s, s, ta[i], tp[i]);
     tin = tp[i];
   }
   float *f = A.f(N * 5008), *d1 = A.f(N * 100), *d2 = A.f(N * 50), *o1 = A.f(N * 2), *u0 = A.f(N * 625);
   K(t_concat_fwd, N * 5008, n, rows, tp[3], f, dense ? 1 : 0);
-  K(t_dense_fwd, N * 100, n, 5008, 100, f, T(24), T(25), d1, 1);
-  K(t_dense_fwd, N * 50, n, 100, 50, d1, T(26), T(27), d2, 1);
-  K(t_dense_fwd, N * 2, n, 50, 2, d2, T(28), T(29), o1, 0);
-  K(t_dense_fwd, N * 625, n, 100, 625, d1, T(30), T(31), u0, 1);
+  // the four dense layers on the f32 MFMA (k_gemm_f32: exact fp32 products, fp32 accumulation in MFMA order)
+  if ((rc = ofx_launch_gemm(h, f, 5008, T(24), 100, T(25), d1, 100, n, 100, 5008, 1))) return rc;
+  if ((rc = ofx_launch_gemm(h, d1, 100, T(26), 50, T(27), d2, 50, n, 50, 100, 1))) return rc;
+  if ((rc = ofx_launch_gemm(h, d2, 50, T(28), 2, T(29), o1, 2, n, 2, 50, 0))) return rc;
+  if ((rc = ofx_launch_gemm(h, d1, 100, T(30), 625, T(31), u0, 625, n, 625, 100, 1))) return rc;
   float *uu[3], *uz[3], *ua[3], *ustat[3];
   const float *uin = u0;
   for (int j = 0, s = 50; j < 3; j++, s *= 2) {
     const size_t per = (size_t)s * s;
     uu[j] = A.f(N * kUI[j] * per); uz[j] = A.f(N * kUO[j] * per); ua[j] = A.f(N * kUO[j] * per); ustat[j] = A.f(16);
     K(t_up_fwd, N * kUI[j] * per, n * kUI[j], s / 2, s / 2, uin, uu[j], legacy);
-    K(t_conv_fwd, N * kUO[j] * per, n, kUI[j], kUO[j], s, s, uu[j], T(32 + 6 * j), T(33 + 6 * j), uz[j]);
+    if ((rc = conv_fwd(st, n, kUI[j], kUO[j], s, s, uu[j], T(32 + 6 * j), T(33 + 6 * j), uz[j]))) return rc;
     hipLaunchKernelGGL(t_chan_sums, dim3(kUO[j], 64), dim3(256), 0, st, n, kUO[j], per, uz[j], (const float *)nullptr, spart);
     hipLaunchKernelGGL(t_chan_sums_finish, dim3(1), dim3(64), 0, st, kUO[j], 64, spart, sums);
     hipLaunchKernelGGL(t_bn_finish_stats, dim3(1), dim3(64), 0, st, kUO[j], (double)N * (double)per, sums, ustat[j]);
-    K(t_bn_relu_fwd, N * kUO[j] * per, n, kUO[j], per, uz[j], ustat[j], T(34 + 6 * j), T(35 + 6 * j), ua[j]);
+    hipLaunchKernelGGL(t_bn_relu_fwd, PLANES(per, n * kUO[j]), 0, st, kUO[j], per, uz[j], ustat[j], T(34 + 6 * j), T(35 + 6 * j), ua[j]);
     uin = ua[j];
   }
   float *up4 = A.f(N * 8 * 160000), *o2 = A.f(N * 160000);
   K(t_up_fwd, N * 8 * 160000, n * 8, 200, 200, ua[2], up4, legacy);
-  K(t_conv_fwd, N * 160000, n, 8, 1, 400, 400, up4, T(50), T(51), o2);
+  if ((rc = conv_fwd(st, n, 8, 1, 400, 400, up4, T(50), T(51), o2))) return rc;
 
   // ---- loss seeds ----
   float *do1 = A.f(N * 2), *do2 = A.f(N * 160000);
@@ -579,20 +650,20 @@ static int dqn_fit_impl(ofx_handle *h, float *weights, float *adam_m, float *ada
   // ---- backward: head 2 ----
   float *gA = A.f(N * 8 * 160000), *gB = A.f(N * 8 * 160000);  // gradient scratch (largest tensors)
   conv_bwd_weight(st, n, 8, 1, 400, 400, up4, do2, wpart, G(50), G(51));
-  K(t_conv_bwd_data, N * 8 * 160000, n, 8, 1, 400, 400, do2, T(50), gA);   // d up4
+  if ((rc = conv_bwd_data(st, n, 8, 1, 400, 400, do2, T(50), gA))) return rc;   // d up4
   float *dcur = gB;                                                          // d ua[2]
   K(t_up_bwd, N * 8 * 40000, n * 8, 200, 200, gA, dcur, legacy);
   for (int j = 2, s = 200; j >= 0; j--, s /= 2) {
-    const size_t per = (size_t)s * s, tot = N * kUO[j] * per;
+    const size_t per = (size_t)s * s;
     float *xh = gA;                                                          // reuse as xhat
-    K(t_bn_relu_bwd_pre, tot, n, kUO[j], per, uz[j], ua[j], ustat[j], dcur, xh);
+    hipLaunchKernelGGL(t_bn_relu_bwd_pre, PLANES(per, n * kUO[j]), 0, st, kUO[j], per, uz[j], ua[j], ustat[j], dcur, xh);
     hipLaunchKernelGGL(t_chan_sums, dim3(kUO[j], 64), dim3(256), 0, st, n, kUO[j], per, dcur, xh, spart);
     hipLaunchKernelGGL(t_chan_sums_finish, dim3(1), dim3(64), 0, st, kUO[j], 64, spart, sums);
     float *dz = ua[j];                                                       // the activation is dead now: holds dz
-    K(t_bn_bwd, tot, n, kUO[j], per, dcur, xh, ustat[j], T(34 + 6 * j), sums, dz, G(34 + 6 * j), G(35 + 6 * j));
+    hipLaunchKernelGGL(t_bn_bwd, PLANES(per, n * kUO[j]), 0, st, kUO[j], per, (double)N * (double)per, dcur, xh, ustat[j], T(34 + 6 * j), sums, dz, G(34 + 6 * j), G(35 + 6 * j));
     conv_bwd_weight(st, n, kUI[j], kUO[j], s, s, uu[j], dz, wpart, G(32 + 6 * j), G(33 + 6 * j));
     float *duu = gA;                                                         // d (upsampled input)
-    K(t_conv_bwd_data, N * kUI[j] * per, n, kUI[j], kUO[j], s, s, dz, T(32 + 6 * j), duu);
+    if ((rc = conv_bwd_data(st, n, kUI[j], kUO[j], s, s, dz, T(32 + 6 * j), duu))) return rc;
     float *dprev = gB;                                                       // d (previous activation / u0)
     K(t_up_bwd, N * kUI[j] * per / 4, n * kUI[j], s / 2, s / 2, duu, dprev, legacy);
     dcur = dprev;
@@ -622,16 +693,16 @@ static int dqn_fit_impl(ofx_handle *h, float *weights, float *adam_m, float *ada
     float *xh = tp[i];                                                       // pooled output is dead: reuse? too small -> use gB tail
     xh = gB + N * 8 * 40000;                                                 // second half of gB (>= N*8*per for s <= 200)
     if (s == 400) xh = up4;                                                  // the 400^2 layer: up4 (8 x 400^2) is dead by now
-    K(t_bn_relu_bwd_pre, tot, n, 8, per, tz[i], ta[i], tstat[i], da, xh);
+    hipLaunchKernelGGL(t_bn_relu_bwd_pre, PLANES(per, n * 8), 0, st, 8, per, tz[i], ta[i], tstat[i], da, xh);
     hipLaunchKernelGGL(t_chan_sums, dim3(8, 64), dim3(256), 0, st, n, 8, per, da, xh, spart);
     hipLaunchKernelGGL(t_chan_sums_finish, dim3(1), dim3(64), 0, st, 8, 64, spart, sums);
     float *dz = ta[i];
-    K(t_bn_bwd, tot, n, 8, per, da, xh, tstat[i], T(6 * i + 2), sums, dz, G(6 * i + 2), G(6 * i + 3));
+    hipLaunchKernelGGL(t_bn_bwd, PLANES(per, n * 8), 0, st, 8, per, (double)N * (double)per, da, xh, tstat[i], T(6 * i + 2), sums, dz, G(6 * i + 2), G(6 * i + 3));
     const float *xin = i == 0 ? x0 : tp[i - 1];
     conv_bwd_weight(st, n, kTI[i], 8, s, s, xin, dz, wpart, G(6 * i), G(6 * i + 1));
     if (i > 0) {
       dp = gB;                                                               // d tp[i-1] [n][8][s][s]
-      K(t_conv_bwd_data, N * 8 * per, n, 8, 8, s, s, dz, T(6 * i), dp);
+      if ((rc = conv_bwd_data(st, n, 8, 8, s, s, dz, T(6 * i), dp))) return rc;
     }
   }
   if (A.over) {  // sizing bug guard: nothing has touched the weights yet
