@@ -514,6 +514,23 @@ static_assert(HS_PL2 % 32 == 16, "uprelu2 plane stride");
 // 2, 3, 5, 6, 7, 8, 10, ...
 __device__ __forceinline__ int hs_pairs_done(int s) { return min(50, s + 2 + ((s + 2) >> 2)); }
 
+// Stage-A tile of consumer wave cw in sub-step st (uprelu2 rows for the M-tiles of st + 1): tile id 2 pair + half belongs
+// to wave id & 3, so the half is cw & 1 and the table holds the row pair (-1 = none).  A compile-time table in constant
+// memory: one scalar load + one bit-field extract instead of ~35 scalar instructions per sub-step.
+struct alignas(16) HsPick { signed char v[HS_NS][4]; };
+constexpr int hs_pairs_done_c(int s) { return s + 2 + ((s + 2) >> 2) < 50 ? s + 2 + ((s + 2) >> 2) : 50; }
+constexpr HsPick hs_make_pick() {
+  HsPick t{};
+  for (int st = 0; st < HS_NS; st++)
+    for (int cw = 0; cw < 4; cw++) {
+      const int lo = 2 * hs_pairs_done_c(st), hi = 2 * hs_pairs_done_c(st + 1);
+      const int at = lo + ((cw - lo) & 3);
+      t.v[st][cw] = (signed char)(at < hi ? at >> 1 : -1);
+    }
+  return t;
+}
+__constant__ HsPick kHsPick = hs_make_pick();
+
 __device__ __forceinline__ int hs_tiles_done(int s) {  // tiles finished by the end of sub-step s
   return s < 0 ? 0 : min(HS_NTILES, 8 * (s + 1) + ((s + 1) >> 3));
 }
@@ -746,7 +763,9 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
         av[j] = up1s[((kq & 1) * 50 + yy) * 50 + xx];
       }
       // the exact frame-column cell lanes 0-7 write behind the tile (2 rows x 4 channels), requested with the rest: a
-      // load in front of its use would expose the HBM latency in every second stage-A tile
+      // load in front of its use would expose the HBM latency in every second stage-A tile.
+      // (r03: lane-constant column offsets + a wave-uniform row base take these six loads' ~18 address instructions
+      // away and the kernel got SLOWER, 15.5 against 15.3 ms in one call - tools/ab_so.sh; left as the compiler has it)
       av[5] = fr2[((side ? 3 : 2) * 100 + 2 * pr + ((lane >> 2) & 1)) * 4 + (lane & 3)];
     };
     auto stageA_compute = [&](int pr, int hh, const float *av) {
@@ -826,10 +845,9 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
     float av[6];
     int apr, ahh;
     auto stageA_pick = [&](int st) {
-      const int lo = 2 * hs_pairs_done(st), hi = 2 * hs_pairs_done(st + 1);
-      const int at = lo + ((cw - lo) & 3);
-      apr = at < hi ? at >> 1 : -1;
-      ahh = at & 1;
+      const int row = reinterpret_cast<const int *>(&kHsPick.v[0][0])[st];   // wave-uniform: a scalar load
+      apr = (int)(signed char)(row >> (8 * cw));
+      ahh = cw & 1;
       stageA_load(max(apr, 0), ahh, av);
     };
     stageA_pick(0);

@@ -474,8 +474,11 @@ static void conv_bwd_weight(hipStream_t st, int n, int ci, int co, int H, int W,
   const int nw = 9 * ci * co;
   // few weights over many pixels (out2, upconv3) need the slices to fill the chip; small maps do not
   const size_t total = (size_t)n * H * W;
-  int slices = (int)((total + 16383) / 16384);
-  slices = slices < 1 ? 1 : slices > kWSlices ? kWSlices : slices;
+  // the partial-sum buffer holds kWSlices * 600 doubles: a layer with few weights can afford more, shorter slices
+  const int cap = (int)((size_t)kWSlices * 600 / (size_t)(nw + co));
+  int slices = (int)((total + 8191) / 8192);
+  slices = slices < 1 ? 1 : slices > cap ? cap : slices;
+  if (slices > 1024) slices = 1024;
 #define BWW(CIB, COB) hipLaunchKernelGGL((t_conv_bwd_weight<CIB, COB>), dim3((ci / CIB) * (co / COB), slices), dim3(256), 0, st, n, ci, co, H, W, x, dz, part)
   if (co % 4 == 0) BWW(1, 4);
   else if (co % 2 == 0 && ci % 2 == 0) BWW(2, 2);
