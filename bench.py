@@ -133,6 +133,40 @@ def cpu_baseline(workload, M, n_pol, w_host, ep_ticks):
     }
 
 
+def bf16_accuracy(w_host, n_arenas=16, m=8, ticks=12):
+    """Error of the bf16-operand forward against a float64 evaluation of the declared graph (torch CPU ops,
+    tests/policy_ref64.py - a checker, not a reference implementation) on n_arenas x m ships of a short rollout with the
+    bench weights: max |heat - heat64| / max |heat64| and how often the pointer is the float64 map's arg-max; the fp32
+    path's numbers on the same ships beside them."""
+    import numpy as np
+    import torch
+    from ofighters_amd import ArenaBatch, _native as nat
+    from tests import policy_ref64 as R
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    b = ArenaBatch(n_arenas, m)
+    b.spawn_random(SEED)
+    b.rollout(["random"] * m, SEED, 0, ticks)
+    out = {}
+    for tag, flag in (("fp32", 0), ("bf16", 1)):
+        b.set_option(nat.OPT_POLICY_BF16, flag)
+        out[tag] = b.policy_forward_host(w_host, want_heat=True)
+    head, _ = b.observe_head()
+    sm, lm = b.maps_host(nat.MAP_U8)
+    rec = {t: {"heat_max_err_over_max": 0.0, "argmax_equal_float64": 0} for t in out}
+    for g in range(n_arenas):
+        _, h64 = R.forward(sm[g], lm[g], head[g].astype(np.float32), w_host)
+        for i in range(m):
+            k = int(np.argmax(h64[i]))
+            for t in out:
+                e = float(np.abs(out[t]["heat"][g, i] - h64[i]).max() / np.abs(h64[i]).max())
+                rec[t]["heat_max_err_over_max"] = max(rec[t]["heat_max_err_over_max"], e)
+                rec[t]["argmax_equal_float64"] += int(tuple(out[t]["ipointer"][g, i]) == (k % 400, k // 400))
+    rec["ships"] = n_arenas * m
+    rec["argmax_bf16_equal_fp32"] = int((out["bf16"]["ipointer"] == out["fp32"]["ipointer"]).all(axis=2).sum())
+    b.close()
+    return rec
+
+
 def train_tick(N, M, device, base, w_host, fence):
     """Secondary line (never `value`): the learning agent as a whole on the reference's own line-up shape (ONE policy
     ship per arena, lib/ofighters.py:53) - TrainingRollout = forward -> epsilon-greedy -> remember -> step -> rasterise
@@ -320,6 +354,8 @@ def main():
     ap.add_argument("--trunk-form", type=int, default=0, choices=[0, 1, 2],
                     help="OFX_OPT_TRUNK_FUSE for A/Bs of the trunk kernels (0 = the library's choice; results are "
                          "bit-identical in every form)")
+    ap.add_argument("--no-bf16-accuracy", dest="bf16_accuracy", action="store_false",
+                    help="skip the float64 evaluation behind the bf16 lines' accuracy numbers (~20 s of CPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary configurations at N=1")
     args = ap.parse_args()
@@ -372,10 +408,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(workload, n_pol_, alive_only, warmup, steps, full_config):
+    def measure(workload, n_pol_, alive_only, warmup, steps, full_config, bf16=False):
         b = ArenaBatch(N, M, device=local_rank, arena_base=base)
         if args.trunk_form:
             b.set_option(nat.OPT_TRUNK_FUSE, args.trunk_form)
+        if bf16:
+            b.set_option(nat.OPT_POLICY_BF16, 1)
         ep = b.cfg.episode_ticks
         # an episode end (restart + score all-reduce) falls into the middle of the timed region whatever --steps is
         start = (ep - warmup - max(1, steps // 2)) % ep
@@ -433,6 +471,19 @@ def main():
                 flops = r["roofline"]["algorithmic_flops_per_launch"] / 23.76e6 * 24.37e6 + N * 2.0 * 53.28e6
                 r["fp32_bound_arena_steps_per_s"] = N * FP32_PEAK_TF * 1e12 / flops
                 r["frac_of_fp32_bound"] = r["value"] / r["fp32_bound_arena_steps_per_s"]
+            extra.append(r)
+        # OPT-IN reduced precision (OFX_OPT_POLICY_BF16): never `value`, no parity and no roofline claim - the speed of the
+        # bf16-operand head for 8 and 1 policy ships next to its measured error against the float64 graph
+        acc = bf16_accuracy(w_host) if args.bf16_accuracy else None
+        for np_ in (M, 1):
+            r = measure("step+obs+policy", np_, False, 30, 150, False, bf16=True)
+            r["dtype"] = "bf16 operands / fp32 accumulation in upconv3 + upconv4 (97 % of the per-ship work); everything else fp32"
+            r["north_star_target_arena_steps_per_s"] = 1.0e6
+            r["frac_of_north_star_target"] = r["value"] / 1.0e6
+            r["roofline"] = None
+            r["note"] = "opt-in, not the headline: earns no parity or roofline credit"
+            if acc is not None:
+                r["accuracy_vs_float64"] = acc
             extra.append(r)
         extra.append(train_tick(N, M, local_rank, base, w_host, fence))
         out["extra_configs"] = extra

@@ -1316,6 +1316,7 @@ extern "C" int ofx_set_option(ofx_handle *h, int32_t option, int32_t value) {
       if (value < 0 || value > 2) { ofx_set_error("ofx_set_option: OFX_OPT_TRUNK_FUSE takes 0 (auto), 1 (always), 2 (never)"); return OFX_ERR_INVALID; }
       h->opt_trunk_fuse = value; return OFX_OK;
     case OFX_OPT_FRAMES_REF: h->opt_frames_ref = value != 0; return OFX_OK;
+    case OFX_OPT_POLICY_BF16: h->opt_policy_bf16 = value != 0; return OFX_OK;
     case OFX_OPT_BILINEAR_LEGACY:  // a different function, not a variant: the prepared phase weights depend on it
       if (h->opt_bilinear_legacy == (value != 0)) return OFX_OK;
       h->opt_bilinear_legacy = value != 0;
@@ -1422,6 +1423,7 @@ static int policy_forward_impl(ofx_handle *h, const float *weights, int N, int M
   hp2.w2fr = prep + L.w2fr; hp2.w3fr = prep + L.w3fr; hp2.efr = prep + L.efr;
   hp2.u2fr = ws.u2fr; hp2.u3fr = ws.u3fr; hp2.c4 = ws.c4;
   hp2.frames_ref = h->opt_frames_ref; hp2.legacy = h->opt_bilinear_legacy;
+  hp2.bf16 = h->opt_policy_bf16 && vec8 == nullptr;  // the rollout's forward only: targets and fit stay fp32
   hp2.mask = ship_mask; hp2.live = ws.live; hp2.best = ws.best; hp2.heat = heatmap; hp2.probe = probe; hp2.ptr_probe = probe ? ptr_probe : nullptr;
   const int pb = h->prof_base;  // ofx_policy_profile: events around the dominant kernel, until the ring is full
   hp2.event_base = pb;
