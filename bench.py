@@ -144,6 +144,7 @@ def bf16_accuracy(w_host, n_arenas=16, m=8, ticks=12):
     from tests import policy_ref64 as R
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     b = ArenaBatch(n_arenas, m)
+    b.set_option(nat.OPT_TRUNK_FUSE, 1)      # the streaming trunk the 4096-arena workload runs (its conv2 / conv3 take the switch)
     b.spawn_random(SEED)
     b.rollout(["random"] * m, SEED, 0, ticks)
     out = {}
@@ -152,12 +153,16 @@ def bf16_accuracy(w_host, n_arenas=16, m=8, ticks=12):
         out[tag] = b.policy_forward_host(w_host, want_heat=True)
     head, _ = b.observe_head()
     sm, lm = b.maps_host(nat.MAP_U8)
-    rec = {t: {"heat_max_err_over_max": 0.0, "argmax_equal_float64": 0} for t in out}
+    rec = {t: {"heat_max_err_over_max": 0.0, "act_max_err_over_max": 0.0, "argmax_equal_float64": 0,
+               "iaction_equal_float64": 0} for t in out}
     for g in range(n_arenas):
-        _, h64 = R.forward(sm[g], lm[g], head[g].astype(np.float32), w_host)
+        a64, h64 = R.forward(sm[g], lm[g], head[g].astype(np.float32), w_host)
         for i in range(m):
             k = int(np.argmax(h64[i]))
             for t in out:
+                ea = float(np.abs(out[t]["act"][g, i] - a64[i]).max() / max(1e-30, np.abs(a64[i]).max()))
+                rec[t]["act_max_err_over_max"] = max(rec[t]["act_max_err_over_max"], ea)
+                rec[t]["iaction_equal_float64"] += int(int(out[t]["iaction"][g, i]) == int(np.argmax(a64[i])))
                 e = float(np.abs(out[t]["heat"][g, i] - h64[i]).max() / np.abs(h64[i]).max())
                 rec[t]["heat_max_err_over_max"] = max(rec[t]["heat_max_err_over_max"], e)
                 rec[t]["argmax_equal_float64"] += int(tuple(out[t]["ipointer"][g, i]) == (k % 400, k // 400))
@@ -354,6 +359,8 @@ def main():
     ap.add_argument("--trunk-form", type=int, default=0, choices=[0, 1, 2],
                     help="OFX_OPT_TRUNK_FUSE for A/Bs of the trunk kernels (0 = the library's choice; results are "
                          "bit-identical in every form)")
+    ap.add_argument("--policy-bf16", action="store_true",
+                    help="OFX_OPT_POLICY_BF16 for the main line (opt-in reduced precision: NOT the headline configuration)")
     ap.add_argument("--no-bf16-accuracy", dest="bf16_accuracy", action="store_false",
                     help="skip the float64 evaluation behind the bf16 lines' accuracy numbers (~20 s of CPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -429,9 +436,9 @@ def main():
         b.close()
         return rec
 
-    headline_full = N == 4096 and M == 8 and n_pol == M and not args.policy_alive_only
+    headline_full = N == 4096 and M == 8 and n_pol == M and not args.policy_alive_only and not args.policy_bf16
     head = measure(args.workload, n_pol, args.policy_alive_only, args.warmup, args.steps,
-                   headline_full or args.workload != "step+obs+policy")
+                   headline_full or args.workload != "step+obs+policy", bf16=args.policy_bf16)
     do_policy = args.workload == "step+obs+policy"
     out = {
         "metric": METRIC,
@@ -444,7 +451,7 @@ def main():
         "higher_is_better": True,
         "scaling": args.scaling,
         "vs_baseline": None,
-        "dtype": "f32" if do_policy else "f64",
+        "dtype": ("bf16 operands, f32 accumulation (opt-in OFX_OPT_POLICY_BF16)" if args.policy_bf16 else "f32") if do_policy else "f64",
         "data": "synthetic",
         "config": {
             "workload": head["workload"],
@@ -477,7 +484,7 @@ def main():
         acc = bf16_accuracy(w_host) if args.bf16_accuracy else None
         for np_ in (M, 1):
             r = measure("step+obs+policy", np_, False, 30, 150, False, bf16=True)
-            r["dtype"] = "bf16 operands / fp32 accumulation in upconv3 + upconv4 (97 % of the per-ship work); everything else fp32"
+            r["dtype"] = "bf16 operands / fp32 accumulation in conv2, conv3 (streaming trunk) and upconv3, upconv4 (97 % of the per-ship work); conv1 (exact table), conv4, dense layers, upconv1-2, frame lines fp32"
             r["north_star_target_arena_steps_per_s"] = 1.0e6
             r["frac_of_north_star_target"] = r["value"] / 1.0e6
             r["roofline"] = None

@@ -21,6 +21,7 @@ struct HeadParams2 {
   int32_t *live;                // with a mask: scratch [1 + S], filled here with the count and the ordered list of the
                                 // selected ships - workgroup i works on live[1 + i], so the live workgroups are the
                                 // FIRST ones of the grid whatever the mask's pattern (spread over XCDs and CUs)
+  int live_ready;               // the caller has filled `live` already (ofx_head_compact)
   unsigned long long *best;     // [S] packed (ordered value << 32) | ~index, zeroed by the caller
   float *heat;                  // [S][400][400] or null
   const int32_t *probe;         // [S][2] (x, y) or null
@@ -35,5 +36,7 @@ struct HeadParams2 {
 
 // bytes of the three frame buffers for S samples
 size_t ofx_head_frame_bytes(size_t S, size_t *u2fr, size_t *u3fr, size_t *c4);
+// mask [S] -> live[0] = count, live[1 + i] = i-th selected ship (one workgroup, a scan)
+int ofx_head_compact(ofx_handle *h, int S, const uint8_t *mask, int32_t *live);
 // k_head_frames + k_head_stream on the handle's stream
 int ofx_launch_head(ofx_handle *h, const HeadParams2 &p);

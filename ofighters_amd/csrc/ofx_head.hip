@@ -1075,6 +1075,12 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
   }
 }
 
+int ofx_head_compact(ofx_handle *h, int S, const uint8_t *mask, int32_t *live) {
+  hipLaunchKernelGGL(k_head_compact, dim3(1), dim3(1024), 0, h->stream, S, mask, live);
+  OFX_HIP(hipGetLastError());
+  return OFX_OK;
+}
+
 size_t ofx_head_frame_bytes(size_t S, size_t *u2fr, size_t *u3fr, size_t *c4) {
   *u2fr = 4 * S * 1600;
   *u3fr = 4 * S * 6400;
@@ -1097,7 +1103,7 @@ int ofx_launch_head(ofx_handle *h, const HeadParams2 &p0) {
 #endif
   if (p.mask) {
     if (!p.live) { ofx_set_error("ofx_launch_head: a mask needs the live-list scratch"); return OFX_ERR_STATE; }
-    hipLaunchKernelGGL(k_head_compact, dim3(1), dim3(1024), 0, h->stream, p.S, p.mask, p.live);
+    if (!p.live_ready) hipLaunchKernelGGL(k_head_compact, dim3(1), dim3(1024), 0, h->stream, p.S, p.mask, p.live);
   } else {
     p.live = nullptr;
   }

@@ -276,6 +276,7 @@ struct ConvParams {
   int tiles_x, tiles;              // tiles per row / per image
   int legacy;                      // k_upconv1: TF1 legacy source mapping (src = dst / 2) instead of half-pixel centres
   int images;                      // k_convm: number of images (the grid is padded to a multiple of 8 of them)
+  const int32_t *live;             // k_upconv1 with a mask: ordered list of the selected images (live[0] = count), else null
 };
 
 // MODE: 0 planar f32 input, 1 two 1-bit maps
@@ -396,13 +397,31 @@ __device__ __forceinline__ float max_raw(float x, float floor) {
 // A[x][k] is gathered from an LDS copy of the input tile (one ds_read_b32 per lane per MFMA, immediate offsets);
 // the row pair of a column group shares one accumulator quad: lane (n = (co, r), kq) holds pixels 4 kq .. 4 kq + 3,
 // so the x-pool is in-lane and the y-pool is one DPP quad swap.
+// bf16 operand helpers of the opt-in OFX_OPT_POLICY_BF16 forms (k_convm, ts_gemm_phase_bf16)
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 pl_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x4 pl_pk4(float a, float b, float c, float d) {
+  const pl_bf16x2 lo = __builtin_convertvector((f32x2){a, b}, pl_bf16x2), hi = __builtin_convertvector((f32x2){c, d}, pl_bf16x2);
+  const uint2 u = {__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+  return __builtin_bit_cast(s16x4, u);
+}
+// the lane's six B operands from wbm [24][64] (value for MFMA j of the fp32 form, lane l: k = l >> 4 -> ci = (l >> 4) + 4 (j & 1), tap j >> 1)
+__device__ __forceinline__ void ts_bw_bf16(const float *wbm, int n16, int kq, s16x4 (&bwb)[6]) {
+#pragma unroll
+  for (int J = 0; J < 6; J++) {
+    const int j = 2 * (2 * J + (kq >> 1)) + (kq & 1);
+    const float *q = wbm + j * 64 + n16;
+    bwb[J] = pl_pk4(q[0], q[16], q[32], q[48]);
+  }
+}
 // MODE 0: planar f32 input [img][CIN][H][W] (the only mode left; conv1 reads the bit maps through k_conv1_lut).  Output: planar [img][8][H/2][W/2] or
 // (OUT_HWC) [img][H/2][W/2][8].  TH rows x 16 NG columns per workgroup, TH even, H % TH == 0; W is masked.
 // A workgroup walks TPW consecutive tiles of one image: the weights are fetched once, the global loads of tile i+1 are
 // in flight (in registers) while tile i computes, and the grid stays small (the dispatcher needs ~5 ns per workgroup:
 // one workgroup per tile cost 1.6 ms of launch floor for conv2 alone).
-template <int CIN, int TH, int NG, int MODE, bool OUT_HWC, int TPW>
+template <int CIN, int TH, int NG, int MODE, bool OUT_HWC, int TPW, bool BF16 = false>
 __global__ __launch_bounds__(256) void k_convm(ConvParams p) {
+  static_assert(!BF16 || CIN == 8, "the bf16 form packs the four channels of a k-quarter");
   constexpr int TW = 16 * NG, LS = TW + 8;  // LDS row: image column tx0 + c sits at index c + 4 (16-byte aligned interior),
                                             // the left / right halo columns at 3 and TW + 4
   constexpr int PLS = ((TH + 2) * LS + 63) / 64 * 64 + 16;  // plane stride = 16 mod 64: the 4 k-quarters hit different banks
@@ -436,6 +455,17 @@ __global__ __launch_bounds__(256) void k_convm(ConvParams p) {
   }
   const float bias = p.b[co];
   const f32x4 binit = {bias, bias, bias, bias};
+  // OFX_OPT_POLICY_BF16: see ts_gemm_phase_bf16 - MFMA J, element i: tap 2 J + (kq >> 1), channel 4 (kq & 1) + i
+  s16x4 bwb[6];
+  int toff[6];
+  if constexpr (BF16) {
+    ts_bw_bf16(p.wbm, n16, kq, bwb);
+#pragma unroll
+    for (int J = 0; J < 6; J++) {
+      const int tap = 2 * J + (kq >> 1);
+      toff[J] = (4 * (kq & 1) - kq) * PLS + (tap / 3) * LS + tap % 3;
+    }
+  }
   const int H2 = H >> 1, W2 = W >> 1;
 
   // ---- staging, split into fetch (global -> registers) and commit (registers -> LDS) ----
@@ -554,7 +584,16 @@ __global__ __launch_bounds__(256) void k_convm(ConvParams p) {
         const int g1 = job1 % NG, t1 = job1 / NG;
         const float *a1 = abase + (2 * t1) * LS + 16 * g1;
         f32x4 d0 = binit, d1 = binit;
-        {
+        if constexpr (BF16) {
+#pragma unroll
+          for (int J = 0; J < 6; J++) {
+            const float *q0 = a0 + toff[J], *q1 = a1 + toff[J];
+            const s16x4 A0 = pl_pk4(q0[0], q0[PLS], q0[2 * PLS], q0[3 * PLS]);
+            const s16x4 A1 = pl_pk4(q1[0], q1[PLS], q1[2 * PLS], q1[3 * PLS]);
+            d0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(A0, bwb[J], d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(A1, bwb[J], d1, 0, 0, 0);
+          }
+        } else {
 #pragma unroll
           for (int j = 0; j < NK; j++) {
             d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(lda(a0, j), bw[j], d0, 0, 0, 0);
@@ -565,8 +604,16 @@ __global__ __launch_bounds__(256) void k_convm(ConvParams p) {
         finish(d1, g1, t1);
       } else {
         f32x4 d0 = binit;
+        if constexpr (BF16) {
 #pragma unroll
-        for (int j = 0; j < NK; j++) d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(lda(a0, j), bw[j], d0, 0, 0, 0);
+          for (int J = 0; J < 6; J++) {
+            const float *q0 = a0 + toff[J];
+            d0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pl_pk4(q0[0], q0[PLS], q0[2 * PLS], q0[3 * PLS]), bwb[J], d0, 0, 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < NK; j++) d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(lda(a0, j), bw[j], d0, 0, 0, 0);
+        }
         finish(d0, g0, t0);
       }
     }
@@ -574,7 +621,7 @@ __global__ __launch_bounds__(256) void k_convm(ConvParams p) {
   }
 }
 
-template <int CIN, int TH, int NG, int MODE, bool OUT_HWC, int TPW>
+template <int CIN, int TH, int NG, int MODE, bool OUT_HWC, int TPW, bool BF16 = false>
 static int launch_convm(ofx_handle *h, ConvParams p, int images, int H) {
   p.H = H; p.W = H;
   p.tiles_x = (H + 16 * NG - 1) / (16 * NG);
@@ -582,7 +629,7 @@ static int launch_convm(ofx_handle *h, ConvParams p, int images, int H) {
   if (p.tiles % TPW) { ofx_set_error("launch_convm: %d tiles per image not divisible by %d", p.tiles, TPW); return OFX_ERR_INVALID; }
   if (OUT_HWC && (H % 2 || H > 16 * NG)) { ofx_set_error("launch_convm: the 8-byte staging takes even rows of one tile width"); return OFX_ERR_INVALID; }
   p.images = images;
-  hipLaunchKernelGGL((k_convm<CIN, TH, NG, MODE, OUT_HWC, TPW>), dim3((unsigned)((images + 7) / 8 * 8 * (p.tiles / TPW))), dim3(256), 0,
+  hipLaunchKernelGGL((k_convm<CIN, TH, NG, MODE, OUT_HWC, TPW, BF16>), dim3((unsigned)((images + 7) / 8 * 8 * (p.tiles / TPW))), dim3(256), 0,
                      h->stream, p);
   OFX_HIP(hipGetLastError());
   return OFX_OK;
@@ -680,8 +727,14 @@ __global__ __launch_bounds__(256) void k_conv1_lut(ConvParams p, const float *lu
 __global__ __launch_bounds__(256) void k_upconv1(ConvParams p) {
   __shared__ float u0s[625];
   __shared__ float up[52][53];   // up-sampled plane with its zero frame; pitch 53: the 5 segments of a row start on different banks
-  const int img = blockIdx.x, tid = threadIdx.x;
-  if (p.mask && !p.mask[img]) return;  // block-uniform
+  const int tid = threadIdx.x;
+  // work item it = the it-th ship (of the ordered list `live` with a mask): a bounded grid walks the items, so a
+  // masked launch pays for its selected ships only (32768 workgroups that exit at once cost 0.13 ms)
+  const int n_items = p.live ? p.live[0] : p.images;
+#pragma unroll 1
+  for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
+  const int img = p.live ? p.live[1 + it] : it;
+  __syncthreads();  // the previous item's readers of u0s / up are done
   for (int e = tid; e < 625; e += 256) u0s[e] = p.in[(size_t)img * 625 + e];
   __syncthreads();
   for (int e = tid; e < 52 * 52; e += 256) {
@@ -701,7 +754,7 @@ __global__ __launch_bounds__(256) void k_upconv1(ConvParams p) {
     up[r][c] = v;
   }
   __syncthreads();
-  if (tid >= 250) return;
+  if (tid < 250) {
   const int row = tid / 5, x0 = 10 * (tid - 5 * row);
   float acc[2][10];
 #pragma unroll
@@ -730,6 +783,8 @@ __global__ __launch_bounds__(256) void k_upconv1(ConvParams p) {
     for (int i = 0; i < 10; i += 2)
       *reinterpret_cast<float2 *>(o + i) = make_float2(fmaxf(acc[co][i] + bias, 0.f), fmaxf(acc[co][i + 1] + bias, 0.f));
   }
+  }  // tid < 250
+  }  // work items
 }
 
 // ---- streaming trunk kernel (k_trunk12): the GEMM phase ---------------------------------------------
@@ -795,6 +850,56 @@ __device__ __forceinline__ void ts_gemm_phase(const float *abase, const float (&
   }
 }
 
+// OFX_OPT_POLICY_BF16 (opt-in): the same banded GEMM on v_mfma_f32_16x16x16_bf16 - K = 96 as 6 MFMAs of K = 16 instead
+// of 24 of K = 4.  MFMA J, lane (pixel n16, k-quarter kq), element i: k <-> (tap = 2 J + (kq >> 1), ci = 4 (kq & 1) + i):
+// the A operand is the four channel planes 4 (kq & 1) .. + 3 at the tap's (row, dx) of the fp32 LDS tile, rounded to
+// bf16 on the way in (one address per J: lane-constant tap offset, planes by immediate); the B operand is packed once
+// from the same PrepLayout::wbm the fp32 kernel uses.  fp32 accumulation, same epilogue.
+template <int WD, int RP, int LS, int PLS>
+__device__ __forceinline__ void ts_gemm_phase_bf16(const float *abase, const s16x4 (&bwb)[6], const f32x4 binit, int wv, int n16,
+                                                   int kq, int r, float *orow) {
+  constexpr int NPX = RP * WD, NT = (NPX + 15) / 16;
+  static_assert(WD % 4 == 0 && NT <= 64, "four M-tiles per wave at most");
+  int toff[6];  // abase carries the fp32 form's + kq * PLS: taken out again
+#pragma unroll
+  for (int J = 0; J < 6; J++) {
+    const int tap = 2 * J + (kq >> 1);
+    toff[J] = (4 * (kq & 1) - kq) * PLS + (tap / 3) * LS + tap % 3;
+  }
+  auto finish = [&](const f32x4 d, int T) {
+    float q0, q1;
+    q0 = max_raw(max_raw(d[0], 0.f), d[1]);
+    q1 = max_raw(max_raw(d[2], 0.f), d[3]);
+    q0 = max_raw(q0, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, q0), 0xB1, 0xF, 0xF, true)));
+    q1 = max_raw(q1, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, q1), 0xB1, 0xF, 0xF, true)));
+    const int P = 16 * T + 4 * kq;
+    const int rp = P / WD, x = P - rp * WD;
+    if (r == 0 && P < NPX) *reinterpret_cast<float2 *>(orow + rp * (WD / 2) + (x >> 1)) = make_float2(q0, q1);
+  };
+  auto a_of_tile = [&](int T) -> const float * {
+    const int P = min(16 * T + n16, NPX - 1);
+    const int rp = P / WD, x = P - rp * WD;
+    return abase + 2 * rp * LS + x;
+  };
+#pragma unroll 1
+  for (int T = wv; T < NT; T += 32) {  // two M-tiles at a time: two accumulator chains
+    const int T1 = T + 16;
+    const bool two = T1 < NT;          // wave-uniform
+    const float *a0 = a_of_tile(T), *a1 = a_of_tile(two ? T1 : T);
+    f32x4 d0 = binit, d1 = binit;
+#pragma unroll
+    for (int J = 0; J < 6; J++) {
+      const float *q0 = a0 + toff[J], *q1 = a1 + toff[J];
+      const s16x4 A0 = pl_pk4(q0[0], q0[PLS], q0[2 * PLS], q0[3 * PLS]);
+      const s16x4 A1 = pl_pk4(q1[0], q1[PLS], q1[2 * PLS], q1[3 * PLS]);
+      d0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(A0, bwb[J], d0, 0, 0, 0);
+      d1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(A1, bwb[J], d1, 0, 0, 0);
+    }
+    finish(d0, T);
+    if (two) finish(d1, T1);
+  }
+}
+
 // ---- conv1 -> conv2 fused: the 5.2 GB pooled conv1 activation never exists -----------------------------------------
 // One 1024-thread workgroup walks ONE image top to bottom in 20 steps of F12_TH = 10 conv2 rows.  Per step:
 //   phase A (all threads, VALU + LDS): the table form of conv1 (see k_conv1_lut) for the 10 NEW rows of p1 = pool(relu(
@@ -818,6 +923,7 @@ static_assert(F12_PLS % 64 == 16 && F12_PLS % 4 == 0 && F12_LS % 4 == 0, "tile l
 static_assert(2 * F12_BR * F12_WR <= F12_THREADS, "one staged word per thread");
 static_assert((F12_TH + 1) * 100 <= 2 * F12_THREADS && F12_TH * 100 <= F12_THREADS, "pixel pairs per step");
 
+template <bool BF16>
 __global__ __launch_bounds__(F12_THREADS) void k_trunk12(ConvParams p, const float *lut) {
   constexpr int W = PS, H = PS, H1 = PS / 2, H2 = PS / 4, LS = F12_LS, PLS = F12_PLS, NK = 24;
   __shared__ __align__(16) float slut[2 * 512 * 8];
@@ -864,9 +970,13 @@ __global__ __launch_bounds__(F12_THREADS) void k_trunk12(ConvParams p, const flo
     reinterpret_cast<f32x4 *>(slut)[e] = reinterpret_cast<const f32x4 *>(lut)[e];
   for (int e = tid; e < 8 * PLS / 4; e += F12_THREADS) reinterpret_cast<f32x4 *>(tile)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int e = tid; e < 2 * 8 * 2 * LS / 4; e += F12_THREADS) reinterpret_cast<f32x4 *>(&halo[0][0][0][0])[e] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float bw[NK];
+  float bw[BF16 ? 1 : NK];
+  s16x4 bwb[6];
+  if constexpr (BF16) ts_bw_bf16(p.wbm, n16, kq, bwb);
+  else {
 #pragma unroll
-  for (int j = 0; j < NK; j++) bw[j] = p.wbm[j * 64 + lane];     // per-lane B operand of k_convm (PrepLayout::wbm)
+    for (int j = 0; j < NK; j++) bw[j] = p.wbm[j * 64 + lane];   // per-lane B operand of k_convm (PrepLayout::wbm)
+  }
   const float bias = p.b[co];
   const f32x4 binit = {bias, bias, bias, bias};
   bits_commit(0, 0, F12_TH + 1, bits_fetch((int)blockIdx.x, 0, F12_TH + 1));
@@ -948,8 +1058,12 @@ __global__ __launch_bounds__(F12_THREADS) void k_trunk12(ConvParams p, const flo
     unsigned nextw = 0u;
     if (more) nextw = bits_fetch(nimg, na, nb);
 
-    ts_gemm_phase<200, F12_TH / 2, F12_LS, F12_PLS>(abase, bw, binit, wv, n16, kq, r,
-                                                     p.out + (((size_t)img * 8 + co) * H2 + (R0 >> 1)) * H2);
+    if constexpr (BF16)
+      ts_gemm_phase_bf16<200, F12_TH / 2, F12_LS, F12_PLS>(abase, bwb, binit, wv, n16, kq, r,
+                                                            p.out + (((size_t)img * 8 + co) * H2 + (R0 >> 1)) * H2);
+    else
+      ts_gemm_phase<200, F12_TH / 2, F12_LS, F12_PLS>(abase, bw, binit, wv, n16, kq, r,
+                                                       p.out + (((size_t)img * 8 + co) * H2 + (R0 >> 1)) * H2);
     if (more) bits_commit(buf ^ 1, na, nb, nextw);  // the other buffer: phase A of this step is behind every wave
     __syncthreads();
   }
@@ -969,6 +1083,7 @@ constexpr int C3_PF4 = C3_ROWS * C3_F4, C3_NI = (C3_PF4 + 63) / 64;  // float4 o
 static_assert(C3_PLS % 64 == 16 && C3_W % C3_TH == 0 && C3_W / 4 + 2 == C3_F4 && 64 * C3_NI * 4 <= C3_PLS + 64 * 4, "tile layout");
 static_assert(2 * 8 * C3_PLS * 4 <= 160 * 1024, "two tiles in LDS");
 
+template <bool BF16>
 __global__ __launch_bounds__(F12_THREADS) void k_conv3_stream(ConvParams p, const float *zero16) {
   constexpr int W = C3_W, H = C3_W, H2 = C3_W / 2, PLS = C3_PLS, NK = 24, STEPS = H / C3_TH;
   __shared__ __align__(16) float tiles[2][8 * C3_PLS];
@@ -992,9 +1107,13 @@ __global__ __launch_bounds__(F12_THREADS) void k_conv3_stream(ConvParams p, cons
     }
   };
 
-  float bw[NK];
+  float bw[BF16 ? 1 : NK];
+  s16x4 bwb[6];
+  if constexpr (BF16) ts_bw_bf16(p.wbm, n16, kq, bwb);
+  else {
 #pragma unroll
-  for (int j = 0; j < NK; j++) bw[j] = p.wbm[j * 64 + lane];
+    for (int j = 0; j < NK; j++) bw[j] = p.wbm[j * 64 + lane];
+  }
   const float bias = p.b[co];
   const f32x4 binit = {bias, bias, bias, bias};
   if ((int)blockIdx.x < p.images) stage(0, (int)blockIdx.x, 0);
@@ -1011,8 +1130,12 @@ __global__ __launch_bounds__(F12_THREADS) void k_conv3_stream(ConvParams p, cons
     const bool last = step + 1 == STEPS;
     const int nimg = last ? img + (int)gridDim.x : img;
     if (nimg < p.images) stage(buf ^ 1, nimg, last ? 0 : R0 + C3_TH);
-    ts_gemm_phase<W, C3_TH / 2, C3_LS, C3_PLS>(&tiles[buf][kq * PLS + 3], bw, binit, wv, n16, kq, r,
-                                               p.out + (((size_t)img * 8 + co) * H2 + (R0 >> 1)) * H2);
+    if constexpr (BF16)
+      ts_gemm_phase_bf16<W, C3_TH / 2, C3_LS, C3_PLS>(&tiles[buf][kq * PLS + 3], bwb, binit, wv, n16, kq, r,
+                                                      p.out + (((size_t)img * 8 + co) * H2 + (R0 >> 1)) * H2);
+    else
+      ts_gemm_phase<W, C3_TH / 2, C3_LS, C3_PLS>(&tiles[buf][kq * PLS + 3], bw, binit, wv, n16, kq, r,
+                                                 p.out + (((size_t)img * 8 + co) * H2 + (R0 >> 1)) * H2);
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the next tile's LDS-direct loads have landed (see above)
     __syncthreads();
     buf ^= 1;
@@ -1024,15 +1147,19 @@ __global__ __launch_bounds__(F12_THREADS) void k_conv3_stream(ConvParams p, cons
 // v_mfma_f32_32x32x2_f32: lane l holds A[row l&31][k l>>5], B[k l>>5][col l&31];
 // C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
 
+// `live` (may be null): ordered list of the rows to compute, live[0] = count, live[1 + i] = row (a masked forward:
+// the i-th selected ship) - the M-tiles run over the list, A is read and C written at the listed rows
 __global__ __launch_bounds__(256) void k_gemm_f32(const float *A, int lda, const float *B, int ldb, const float *bias,
-                                                  float *C, int ldc, int M, int N, int K, int relu) {
+                                                  float *C, int ldc, int M, int N, int K, int relu, const int32_t *live) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int tiles_n = (N + 31) / 32;
   const int tile = blockIdx.x * 4 + wv;
+  if (live) M = live[0];
   if (tile >= ((M + 31) / 32) * tiles_n) return;
   const int m0 = (tile / tiles_n) * 32, n0 = (tile % tiles_n) * 32;
-  const int r = m0 + (lane & 31), c = n0 + (lane & 31), kh = lane >> 5;
-  const bool rv = r < M, cv = c < N;
+  const int r0 = m0 + (lane & 31), c = n0 + (lane & 31), kh = lane >> 5;
+  const bool rv = r0 < M, cv = c < N;
+  const int r = live ? live[1 + (rv ? r0 : 0)] : r0;
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; i++) acc[i] = 0.f;
@@ -1052,7 +1179,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const float *A, int lda, const
       if (row < M) {
         float v = acc[i] + bv;
         if (relu) v = fmaxf(v, 0.f);
-        C[(size_t)row * ldc + c] = v;
+        C[(size_t)(live ? live[1 + row] : row) * ldc + c] = v;
       }
     }
   }
@@ -1104,6 +1231,7 @@ struct HeadParams {
   const float *g1;            // [g1_chunks][N][100]  trunk part of dense1 (no bias), split-K partial sums
   int g1_chunks;
   const float *k1, *b1, *k2, *b2, *k3, *b3;
+  const int32_t *live;   // ordered list of the selected ships (with a mask) or null
   const uint8_t *mask;
   const float *vec8;          // [S][8] explicit observation heads (ofx_policy_forward_obs) or null = the live state
   float *d1;                  // [S][100]
@@ -1115,9 +1243,13 @@ __global__ __launch_bounds__(256) void k_head_dense(HeadParams p) {
   __shared__ float sd1[4][100];
   __shared__ float sd2[4][50];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int s = blockIdx.x * 4 + wv;
-  const bool on = s < p.N * p.M && (!p.mask || p.mask[s]);
-  const int a = on ? s / p.M : 0;
+  // with a mask: work item i = the i-th selected ship (p.live: count, then the ordered list); the blocks behind the
+  // count leave at once
+  const int item = blockIdx.x * 4 + wv, n_items = p.live ? p.live[0] : p.N * p.M;
+  if ((int)blockIdx.x * 4 >= n_items) return;  // block-uniform
+  const bool on = item < n_items;
+  const int s = on ? (p.live ? p.live[1 + item] : item) : 0;
+  const int a = s / p.M;
   float vec[8];
   if (on) {  // obs.vector[:8] (observation.py:119-123): reward, can_shoot, pointing, dim, pos
     if (p.vec8) {
@@ -1246,10 +1378,10 @@ static int launch_conv(ofx_handle *h, ConvParams p, int images, int H) {
 
 // (also the dense layers of the fit's forward, ofx_train.hip)
 int ofx_launch_gemm(ofx_handle *h, const float *A, int lda, const float *B, int ldb, const float *bias, float *C, int ldc,
-                    int M, int N, int K, int relu) {
+                    int M, int N, int K, int relu, const int32_t *live) {
   const int tiles = ((M + 31) / 32) * ((N + 31) / 32);
   hipLaunchKernelGGL(k_gemm_f32, dim3((tiles + 3) / 4), dim3(256), 0, h->stream, A, lda, B, ldb, bias, C, ldc, M, N, K,
-                     relu);
+                     relu, live);
   OFX_HIP(hipGetLastError());
   return OFX_OK;
 }
@@ -1353,13 +1485,16 @@ static int policy_forward_impl(ofx_handle *h, const float *weights, int N, int M
   cp.bits[1] = bits1;
   cp.bits_stride = bits_stride;
   cp.w = prep + L.tw[0]; cp.b = prep + L.tb[0]; cp.out = ws.p1;
+  const bool bf16 = h->opt_policy_bf16 && vec8 == nullptr;  // opt-in, the rollout's forward only (streaming trunk: conv2, conv3)
   const bool plain = h->opt_trunk_plain;  // OFX_OPT_TRUNK_PLAIN: every trunk layer through the plain VALU kernel
   const bool fused12 = trunk_fused(h, (size_t)N);
   if (plain) rc = launch_conv<2, 8, 10, 100, 1, true, false>(h, cp, N, 400);
   else if (fused12) {
     cp.out = ws.p2; cp.b = prep + L.tb[1]; cp.wbm = prep + L.wbm[0]; cp.images = N;
-    hipLaunchKernelGGL(k_trunk12, dim3((unsigned)(N < h->n_cus ? N : h->n_cus)), dim3(F12_THREADS), 0, h->stream, cp,
-                       (const float *)(prep + L.lut1));
+    if (bf16) hipLaunchKernelGGL(k_trunk12<true>, dim3((unsigned)(N < h->n_cus ? N : h->n_cus)), dim3(F12_THREADS), 0, h->stream, cp,
+                                 (const float *)(prep + L.lut1));
+    else hipLaunchKernelGGL(k_trunk12<false>, dim3((unsigned)(N < h->n_cus ? N : h->n_cus)), dim3(F12_THREADS), 0, h->stream, cp,
+                            (const float *)(prep + L.lut1));
     OFX_HIP(hipGetLastError());
   } else {
     cp.H = 400; cp.W = 400;
@@ -1377,13 +1512,16 @@ static int policy_forward_impl(ofx_handle *h, const float *weights, int N, int M
   if (plain) rc = launch_conv<8, 8, 10, 100, 0, true, false>(h, cp, N, 100);
   else if (fused12) {  // large batches: the streaming form, like conv1 -> conv2
     cp.images = N;
-    hipLaunchKernelGGL(k_conv3_stream, dim3((unsigned)(N < h->n_cus ? N : h->n_cus)), dim3(F12_THREADS), 0, h->stream, cp,
-                       (const float *)(prep + L.zero16));
+    if (bf16) hipLaunchKernelGGL(k_conv3_stream<true>, dim3((unsigned)(N < h->n_cus ? N : h->n_cus)), dim3(F12_THREADS), 0, h->stream, cp,
+                                 (const float *)(prep + L.zero16));
+    else hipLaunchKernelGGL(k_conv3_stream<false>, dim3((unsigned)(N < h->n_cus ? N : h->n_cus)), dim3(F12_THREADS), 0, h->stream, cp,
+                            (const float *)(prep + L.zero16));
     OFX_HIP(hipGetLastError());
   } else rc = launch_convm<8, 4, 7, 0, false, 1>(h, cp, N, 100);
   if (rc) return rc;
   cp.in = ws.p3; cp.w = prep + L.tw[3]; cp.b = prep + L.tb[3]; cp.out = ws.p4; cp.wbm = prep + L.wbm[2];
   if (plain) rc = launch_conv<8, 8, 10, 50, 0, true, true>(h, cp, N, 50);  // (h,w,c) = Flatten order
+  else if (bf16 && fused12) rc = launch_convm<8, 10, 4, 0, true, 1, true>(h, cp, N, 50);
   else rc = launch_convm<8, 10, 4, 0, true, 1>(h, cp, N, 50);
   if (rc) return rc;
 
@@ -1400,18 +1538,24 @@ static int policy_forward_impl(ofx_handle *h, const float *weights, int N, int M
   hp.k1 = k1; hp.b1 = weights + off[t_d1 + 1];
   hp.k2 = weights + off[t_d2]; hp.b2 = weights + off[t_d2 + 1];
   hp.k3 = weights + off[t_o1]; hp.b3 = weights + off[t_o1 + 1];
-  hp.mask = ship_mask; hp.d1 = ws.d1; hp.act = act_values; hp.iaction = iaction ? iaction : ws.iaction;
+  // a masked forward works on the ordered list of the selected ships from here on (one scan of the mask)
+  const int32_t *live = nullptr;
+  if (ship_mask) {
+    if ((rc = ofx_head_compact(h, S, ship_mask, ws.live))) return rc;
+    live = ws.live;
+  }
+  hp.mask = ship_mask; hp.live = live; hp.d1 = ws.d1; hp.act = act_values; hp.iaction = iaction ? iaction : ws.iaction;
   hipLaunchKernelGGL(k_head_dense, dim3((S + 3) / 4), dim3(256), 0, h->stream, hp);
   OFX_HIP(hipGetLastError());
 
   // 3. head-2: updense1 on MFMA, upconv1 (1 -> 2 @ 50x50), then upconv2-4 + arg-max in the streaming kernel (ofx_head.hip)
-  if ((rc = ofx_launch_gemm(h, ws.d1, 100, weights + off[t_ud], 625, weights + off[t_ud + 1], ws.u0, 625, S, 625, 100, 1)))
+  if ((rc = ofx_launch_gemm(h, ws.d1, 100, weights + off[t_ud], 625, weights + off[t_ud + 1], ws.u0, 625, S, 625, 100, 1, live)))
     return rc;
   ConvParams up;
   memset(&up, 0, sizeof(up));
-  up.mask = ship_mask; up.legacy = h->opt_bilinear_legacy;
+  up.live = live; up.images = S; up.legacy = h->opt_bilinear_legacy;
   up.in = ws.u0; up.w = prep + L.uw[0]; up.b = prep + L.ub[0]; up.out = ws.up1;
-  hipLaunchKernelGGL(k_upconv1, dim3((unsigned)S), dim3(256), 0, h->stream, up);
+  hipLaunchKernelGGL(k_upconv1, dim3((unsigned)(S < 4096 ? S : 4096)), dim3(256), 0, h->stream, up);
   OFX_HIP(hipGetLastError());
   OFX_HIP(hipMemsetAsync(ws.best, 0, sizeof(unsigned long long) * S, h->stream));
   HeadParams2 hp2;
@@ -1423,8 +1567,8 @@ static int policy_forward_impl(ofx_handle *h, const float *weights, int N, int M
   hp2.w2fr = prep + L.w2fr; hp2.w3fr = prep + L.w3fr; hp2.efr = prep + L.efr;
   hp2.u2fr = ws.u2fr; hp2.u3fr = ws.u3fr; hp2.c4 = ws.c4;
   hp2.frames_ref = h->opt_frames_ref; hp2.legacy = h->opt_bilinear_legacy;
-  hp2.bf16 = h->opt_policy_bf16 && vec8 == nullptr;  // the rollout's forward only: targets and fit stay fp32
-  hp2.mask = ship_mask; hp2.live = ws.live; hp2.best = ws.best; hp2.heat = heatmap; hp2.probe = probe; hp2.ptr_probe = probe ? ptr_probe : nullptr;
+  hp2.bf16 = bf16;  // the rollout's forward only: targets and fit stay fp32
+  hp2.mask = ship_mask; hp2.live = ws.live; hp2.live_ready = ship_mask != nullptr; hp2.best = ws.best; hp2.heat = heatmap; hp2.probe = probe; hp2.ptr_probe = probe ? ptr_probe : nullptr;
   const int pb = h->prof_base;  // ofx_policy_profile: events around the dominant kernel, until the ring is full
   hp2.event_base = pb;
   if ((rc = ofx_launch_head(h, hp2))) return rc;

@@ -2,16 +2,16 @@
 default, never the headline number).  Measured against the float64 graph like the fp32 path (tests/policy_ref64.py):
 the error of the heat map and how often its arg-max is the float64 map's are REPORTED (gpurun_out/policy_fp64_report.json,
 bench.py repeats the measurement in its bf16 lines); asserted is only that the switch gives a reduced-precision version
-of the same function - act_values (fp32 dense layers) bit-identical to the fp32 path, the heat map within 2e-2 of its
-scale, the fused arg-max equal to the arg-max of the map the kernel wrote, every pointer a near-maximum of the float64
-map - and that the fp32 path is untouched by the switch having been used."""
+of the same function - act_values within 2e-2 of their scale (conv2 / conv3 of the streaming trunk run on bf16 operands
+too), the heat map within 3e-2 of its scale, the fused arg-max equal to the arg-max of the map the kernel wrote, every
+pointer a near-maximum of the float64 map - and that the fp32 path is untouched by the switch having been used."""
 import numpy as np
 import pytest
 
 from tests.test_gpu_policy_fp64 import _report, _rollout
 
 pytestmark = pytest.mark.gpu
-TOL_BF16 = 2e-2      # max |heat - heat64| / max |heat64|; measured ~2-4e-3 (bf16 has 8 significant bits)
+TOL_BF16 = 3e-2      # max |heat - heat64| / max |heat64|; measured ~1e-2 (bf16 has 8 significant bits)
 
 
 def test_bf16_forward_against_fp64_and_fp32():
@@ -23,6 +23,7 @@ def test_bf16_forward_against_fp64_and_fp32():
     N, M = 4, 4
     b = _rollout(N, M, seed=31, ticks=40)
     w, _ = pyoracle.policy_init(5, trained_like=True)
+    b.set_option(nat.OPT_TRUNK_FUSE, 1)      # the streaming trunk (what large batches run): its conv2 / conv3 take the switch too
     fp32 = b.policy_forward_host(w, want_heat=True)
     b.set_option(nat.OPT_POLICY_BF16, 1)
     bf = b.policy_forward_host(w, want_heat=True)
@@ -33,7 +34,9 @@ def test_bf16_forward_against_fp64_and_fp32():
     again = b.policy_forward_host(w, want_heat=True)
     for k in fp32:
         assert np.array_equal(fp32[k], again[k]), k                  # the fp32 path is what it was
-    assert np.array_equal(bf["act"], fp32["act"]) and np.array_equal(bf["iaction"], fp32["iaction"])
+    act_scale = float(np.abs(fp32["act"]).max())
+    act_err = float(np.abs(bf["act"] - fp32["act"]).max()) / act_scale
+    assert 0 < act_err <= 2e-2, act_err
     assert np.array_equal(bf_masked["ipointer"][:, 1], bf["ipointer"][:, 1])
     assert not np.array_equal(bf["heat"], fp32["heat"])
     head, _ = b.observe_head()
@@ -53,7 +56,7 @@ def test_bf16_forward_against_fp64_and_fp32():
             kk = int(np.argmax(bf["heat"][g, i]))
             assert (gx, gy) == (kk % 400, kk // 400)                  # first maximum of the map the kernel wrote
             assert h64[i][gy, gx] >= h64[i].max() - 2 * TOL_BF16 * scale
-    _report("small_trained_bf16", dict(heat_err=worst, heat_vs_fp32=rel32, argmax_same_as_fp64=int(same),
+    _report("small_trained_bf16", dict(heat_err=worst, heat_vs_fp32=rel32, act_vs_fp32=act_err, argmax_same_as_fp64=int(same),
                                        argmax_same_as_fp32=int(same32), ships=N * M))
     assert 1e-5 < worst <= TOL_BF16, worst
     b.close()
