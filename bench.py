@@ -133,7 +133,7 @@ def cpu_baseline(workload, M, n_pol, w_host, ep_ticks):
     }
 
 
-def bf16_accuracy(w_host, n_arenas=16, m=8, ticks=12):
+def bf16_accuracy(w_host, n_arenas=8, m=8, ticks=12):
     """Error of the bf16-operand forward against a float64 evaluation of the declared graph (torch CPU ops,
     tests/policy_ref64.py - a checker, not a reference implementation) on n_arenas x m ships of a short rollout with the
     bench weights: max |heat - heat64| / max |heat64| and how often the pointer is the float64 map's arg-max; the fp32
