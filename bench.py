@@ -481,7 +481,12 @@ def main():
             extra.append(r)
         # OPT-IN reduced precision (OFX_OPT_POLICY_BF16): never `value`, no parity and no roofline claim - the speed of the
         # bf16-operand head for 8 and 1 policy ships next to its measured error against the float64 graph
-        acc = bf16_accuracy(w_host) if args.bf16_accuracy else None
+        acc = None
+        if args.bf16_accuracy:
+            try:
+                acc = bf16_accuracy(w_host)
+            except Exception as e:      # a secondary measurement must never take the headline line down with it
+                acc = {"error": repr(e)}
         for np_ in (M, 1):
             r = measure("step+obs+policy", np_, False, 30, 150, False, bf16=True)
             r["dtype"] = "bf16 operands / fp32 accumulation in conv2, conv3 (streaming trunk) and upconv3, upconv4 (97 % of the per-ship work); conv1 (exact table), conv4, dense layers, upconv1-2, frame lines fp32"
@@ -492,7 +497,10 @@ def main():
             if acc is not None:
                 r["accuracy_vs_float64"] = acc
             extra.append(r)
-        extra.append(train_tick(N, M, local_rank, base, w_host, fence))
+        try:
+            extra.append(train_tick(N, M, local_rank, base, w_host, fence))
+        except Exception as e:
+            extra.append({"workload": "TRAINING tick", "error": repr(e)})
         out["extra_configs"] = extra
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

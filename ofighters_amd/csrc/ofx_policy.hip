@@ -1555,7 +1555,8 @@ static int policy_forward_impl(ofx_handle *h, const float *weights, int N, int M
   memset(&up, 0, sizeof(up));
   up.live = live; up.images = S; up.legacy = h->opt_bilinear_legacy;
   up.in = ws.u0; up.w = prep + L.uw[0]; up.b = prep + L.ub[0]; up.out = ws.up1;
-  hipLaunchKernelGGL(k_upconv1, dim3((unsigned)(S < 4096 ? S : 4096)), dim3(256), 0, h->stream, up);
+  // every ship: one workgroup each (0.22 ms; a bounded grid that loops is 0.02 ms slower); with a mask: a bounded grid over the list
+  hipLaunchKernelGGL(k_upconv1, dim3((unsigned)(live && S > 4096 ? 4096 : S)), dim3(256), 0, h->stream, up);
   OFX_HIP(hipGetLastError());
   OFX_HIP(hipMemsetAsync(ws.best, 0, sizeof(unsigned long long) * S, h->stream));
   HeadParams2 hp2;
