@@ -148,7 +148,7 @@ def bf16_accuracy(w_host, n_arenas=8, m=8, ticks=12):
     b.spawn_random(SEED)
     b.rollout(["random"] * m, SEED, 0, ticks)
     out = {}
-    for tag, flag in (("fp32", 0), ("bf16", 1)):
+    for tag, flag in (("fp32", 0), ("bf16", 1), ("fp16", 2)):
         b.set_option(nat.OPT_POLICY_BF16, flag)
         out[tag] = b.policy_forward_host(w_host, want_heat=True)
     head, _ = b.observe_head()
@@ -167,7 +167,8 @@ def bf16_accuracy(w_host, n_arenas=8, m=8, ticks=12):
                 rec[t]["heat_max_err_over_max"] = max(rec[t]["heat_max_err_over_max"], e)
                 rec[t]["argmax_equal_float64"] += int(tuple(out[t]["ipointer"][g, i]) == (k % 400, k // 400))
     rec["ships"] = n_arenas * m
-    rec["argmax_bf16_equal_fp32"] = int((out["bf16"]["ipointer"] == out["fp32"]["ipointer"]).all(axis=2).sum())
+    for t in ("bf16", "fp16"):
+        rec["argmax_%s_equal_fp32" % t] = int((out[t]["ipointer"] == out["fp32"]["ipointer"]).all(axis=2).sum())
     b.close()
     return rec
 
@@ -359,8 +360,9 @@ def main():
     ap.add_argument("--trunk-form", type=int, default=0, choices=[0, 1, 2],
                     help="OFX_OPT_TRUNK_FUSE for A/Bs of the trunk kernels (0 = the library's choice; results are "
                          "bit-identical in every form)")
-    ap.add_argument("--policy-bf16", action="store_true",
-                    help="OFX_OPT_POLICY_BF16 for the main line (opt-in reduced precision: NOT the headline configuration)")
+    ap.add_argument("--policy-bf16", type=int, nargs="?", const=1, default=0, choices=[0, 1, 2],
+                    help="OFX_OPT_POLICY_BF16 for the main line: 1 bf16, 2 fp16 operands (opt-in reduced precision: NOT the "
+                         "headline configuration)")
     ap.add_argument("--no-bf16-accuracy", dest="bf16_accuracy", action="store_false",
                     help="skip the float64 evaluation behind the bf16 lines' accuracy numbers (~20 s of CPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -420,7 +422,7 @@ def main():
         if args.trunk_form:
             b.set_option(nat.OPT_TRUNK_FUSE, args.trunk_form)
         if bf16:
-            b.set_option(nat.OPT_POLICY_BF16, 1)
+            b.set_option(nat.OPT_POLICY_BF16, int(bf16))
         ep = b.cfg.episode_ticks
         # an episode end (restart + score all-reduce) falls into the middle of the timed region whatever --steps is
         start = (ep - warmup - max(1, steps // 2)) % ep
@@ -451,7 +453,7 @@ def main():
         "higher_is_better": True,
         "scaling": args.scaling,
         "vs_baseline": None,
-        "dtype": ("bf16 operands, f32 accumulation (opt-in OFX_OPT_POLICY_BF16)" if args.policy_bf16 else "f32") if do_policy else "f64",
+        "dtype": (("bf16" if args.policy_bf16 == 1 else "fp16") + " operands, f32 accumulation (opt-in OFX_OPT_POLICY_BF16)" if args.policy_bf16 else "f32") if do_policy else "f64",
         "data": "synthetic",
         "config": {
             "workload": head["workload"],
@@ -487,16 +489,19 @@ def main():
                 acc = bf16_accuracy(w_host)
             except Exception as e:      # a secondary measurement must never take the headline line down with it
                 acc = {"error": repr(e)}
-        for np_ in (M, 1):
-            r = measure("step+obs+policy", np_, False, 30, 150, False, bf16=True)
-            r["dtype"] = "bf16 operands / fp32 accumulation in conv2, conv3 (streaming trunk) and upconv3, upconv4 (97 % of the per-ship work); conv1 (exact table), conv4, dense layers, upconv1-2, frame lines fp32"
-            r["north_star_target_arena_steps_per_s"] = 1.0e6
-            r["frac_of_north_star_target"] = r["value"] / 1.0e6
-            r["roofline"] = None
-            r["note"] = "opt-in, not the headline: earns no parity or roofline credit"
-            if acc is not None:
-                r["accuracy_vs_float64"] = acc
-            extra.append(r)
+        for lowp, tag in ((1, "bf16"), (2, "fp16")):
+            for np_ in (M, 1):
+                r = measure("step+obs+policy", np_, False, 30, 150, False, bf16=lowp)
+                r["dtype"] = ("%s operands / fp32 accumulation in conv2-4 (streaming trunk) and upconv3-4 (97 %% of the per-ship "
+                              "work); conv1 (exact table), dense layers, upconv1-2, frame lines fp32" % tag)
+                r["north_star_target_arena_steps_per_s"] = 1.0e6
+                r["frac_of_north_star_target"] = r["value"] / 1.0e6
+                r["roofline"] = None
+                r["note"] = "opt-in (OFX_OPT_POLICY_BF16 = %d), not the headline: earns no parity or roofline credit" % lowp
+                if acc is not None:
+                    r["accuracy_vs_float64"] = ({k: acc[k] for k in ("fp32", tag, "ships", "argmax_%s_equal_fp32" % tag)}
+                                                if "error" not in acc else acc)
+                extra.append(r)
         try:
             extra.append(train_tick(N, M, local_rank, base, w_host, fence))
         except Exception as e:

@@ -285,11 +285,13 @@ int ofx_policy_pin_weights(ofx_handle *h, const float *weights);
  * heat map under the other.  Applies to the forward, the DQN targets and ofx_dqn_fit; a pinned blob is re-prepared. */
 #define OFX_OPT_BILINEAR_LEGACY 3
 /* OPT-IN reduced precision, never the default and never the headline number: ofx_policy_forward (the rollout's forward
- * on the live state; ofx_policy_forward_obs, the DQN targets and the fit stay fp32) feeds upconv3 and upconv4 - 97 % of the
- * per-ship work - to the bf16 matrix instructions: operands rounded to bf16 (8 significant bits), sums in fp32.  The
+ * on the live state; ofx_policy_forward_obs, the DQN targets and the fit stay fp32) feeds conv2-4 (streaming trunk) and
+ * upconv3-4 - 97 % of the per-ship work - to the 16-bit matrix instructions: operands rounded to nearest even, sums in
+ * fp32.  value 1: bf16 operands (8 significant bits); value 2: fp16 operands (11 significant bits; operands beyond
+ * 65504 would overflow - activations behind BatchNorm + ReLU and folded weights are far below); value 0: fp32.  The
  * reference's Keras model is fp32 (agents/qlearnIA_V2.py:123-190): with this switch the heat map differs from the fp32
- * path at the 1e-3 level and near-ties of its arg-max can resolve differently; bench.py reports the measured error
- * against the float64 graph and the arg-max agreement next to the speed.                                            */
+ * path at the 3e-3 (bf16) / 4e-4 (fp16) level and near-ties of its arg-max can resolve differently; bench.py reports the
+ * measured error against the float64 graph and the arg-max agreement next to the speed.                              */
 #define OFX_OPT_POLICY_BF16 5
 int ofx_set_option(ofx_handle *h, int32_t option, int32_t value);
 /* Exploration of the bi-head action space (Trainer.get_best_action epsilon branch, agents/qlearnIA_V2.py:199-204,

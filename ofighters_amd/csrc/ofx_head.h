@@ -28,7 +28,7 @@ struct HeadParams2 {
   float *ptr_probe;             // [S] heat-map value at the probe
   int frames_ref;               // frame lines through the from-the-definition kernel (OFX_OPT_FRAMES_REF)
   int legacy;                   // TF1 legacy bilinear instead of half-pixel centres (OFX_OPT_BILINEAR_LEGACY)
-  int bf16;                     // OFX_OPT_POLICY_BF16: bf16 operands in upconv3 / upconv4 (opt-in, not the default)
+  int bf16;                     // OFX_OPT_POLICY_BF16: 1 bf16 / 2 fp16 operands in upconv3 / upconv4 (opt-in, not the default)
   int event_base;               // >= 0: ofx_event_record(event_base / event_base + 1) around k_head_stream
   int ablate;                   // diagnostics (OFX_HEAD_HOOKS builds only)
   unsigned long long *dbg;      // diagnostics: [blocks][8 waves][6] s_memtime sums

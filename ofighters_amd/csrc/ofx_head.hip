@@ -20,6 +20,7 @@
 // uprelu2 / uprelu3, correction lines of the heat map) in a small pre-pass; k_head_stream overwrites the frame cells
 // of its rings with the exact values and starts the heat-map accumulators of frame pixels at bias - correction.
 #include "ofx_head.h"
+#include "ofx_lowp.h"
 #include <stdlib.h>
 
 #ifndef HS_A_FIRST
@@ -34,15 +35,6 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-// OFX_OPT_POLICY_BF16 (opt-in, never the default): bf16 operands, fp32 accumulation
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 hd_bf16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ s16x4 hd_pk4(float a, float b, float c, float d) {  // 2 x v_cvt_pk_bf16_f32 (round to nearest even)
-  const hd_bf16x2 lo = __builtin_convertvector((f32x2){a, b}, hd_bf16x2), hi = __builtin_convertvector((f32x2){c, d}, hd_bf16x2);
-  const uint2 u = {__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
-  return __builtin_bit_cast(s16x4, u);
-}
-
 #define HD_PS 400
 
 // max without the canonicalising v_max(x, x) of fmaxf(); compiler-visible (never feed an MFMA result to inline asm:
@@ -559,13 +551,14 @@ constexpr int HS_THREADS = 64 * (HS_NB + 4);
 // EXTRA: the launch wants the heat map and / or a probed value written out (ofx_policy_forward with a heatmap pointer,
 // ofx_policy_forward_obs with a probe: the DQN targets); the rollout's forward does not, and its instantiation carries
 // neither the tests nor the branches of those paths in the consumers' loop
-// BF16 (OFX_OPT_POLICY_BF16, opt-in): stage B on v_mfma_f32_16x16x16_bf16 (K = 36 -> 3 MFMAs of K = 16 per channel half
+// LP != 0 (OFX_OPT_POLICY_BF16, opt-in; 1 = bf16, 2 = fp16 operands): stage B on v_mfma_f32_16x16x16_bf16 / _f16 (K = 36 -> 3 MFMAs of K = 16 per channel half
 // instead of 9 of K = 4) and stage C on v_mfma_f32_4x4x4_16B_bf16 (one MFMA per (channel, row) takes the four columns a
 // lane has read for its pixel pair, the fourth with a zero weight: 48 instead of 144 per pass); the operands - uprelu2 /
 // uprelu3 values read from the fp32 rings and the phase weights - are rounded to bf16 on the way into the matrix
 // instruction, the sums stay fp32.  Rings, schedule, frame lines (exact fp32) and stage A are the fp32 kernel's.
-template <bool EXTRA, bool BF16>
+template <bool EXTRA, int LP>
 __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
+  constexpr bool BF16 = LP != 0;  // reduced-precision operands (1 = bf16, 2 = fp16), fp32 sums
   __shared__ __align__(16) float u3r[8 * HS_PL3];
   __shared__ __align__(16) float u2r[4 * HS_PL2];
   // group (flat over quad rows) -> float offset of its first quad in the uprelu2 ring (row slot of quad row - 1) and
@@ -615,7 +608,7 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
     // BF16: B operand of MFMA J of half hf = W[k = 16 J + 4 kq + i][n16], i = 0..3 (k >= 36: zero); the A operand is the
     // four channels of tap 4 J + kq at the lane's quad: one address per J (lane-constant tap offset), channel planes
     // by immediate
-    s16x4 bwb[2][3];
+    lp_x4 bwb[2][3];
     int toff[3];
     if constexpr (BF16) {
 #pragma unroll
@@ -628,7 +621,7 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
             const int k = 16 * J + 4 * kq + i;
             w[i] = k < 36 ? p.w3mf[(hf * 36 + k) * 16 + n16] : 0.f;
           }
-          bwb[hf][J] = hd_pk4(w[0], w[1], w[2], w[3]);
+          bwb[hf][J] = lp_pk4<LP ? LP : 1>(w[0], w[1], w[2], w[3]);
         }
         const int tap = min(4 * J + kq, 8);
         toff[J] = (tap / 3) * HS_P2 + tap % 3 - kq * HS_PL2;   // t.a carries the f32 kernel's + kq * HS_PL2: taken out
@@ -689,17 +682,17 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
       }
     };
     auto tile_bf16 = [&](const TileB &t) {
-      s16x4 A[3];
+      lp_x4 A[3];
 #pragma unroll
       for (int J = 0; J < 3; J++) {
         const float *q = t.a + toff[J];
-        A[J] = hd_pk4(q[0], q[HS_PL2], q[2 * HS_PL2], q[3 * HS_PL2]);
+        A[J] = lp_pk4<LP ? LP : 1>(q[0], q[HS_PL2], q[2 * HS_PL2], q[3 * HS_PL2]);
       }
       f32x4 d0 = binit3[0], d1 = binit3[1];
 #pragma unroll
       for (int J = 0; J < 3; J++) {
-        d0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(A[J], bwb[0][J], d0, 0, 0, 0);
-        d1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(A[J], bwb[1][J], d1, 0, 0, 0);
+        d0 = lp_mfma16<LP ? LP : 1>(A[J], bwb[0][J], d0);
+        d1 = lp_mfma16<LP ? LP : 1>(A[J], bwb[1][J], d1);
       }
       tile_epilogue(t, d0, d1);
       if (t.hasf) tile_frames(t);
@@ -796,14 +789,14 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
     // BF16: group g = ((channel * 3 + row) * 2 + pixel of the pair): register pair g >> 4, block g & 15 holds, for phase
     // L & 3, the weights of the four columns x0 - 1 .. x0 + 2 the lane has read: (w0, w1, w2, 0) for the pair's first
     // pixel, (0, w0, w1, w2) for its second
-    s16x4 wbf[3];
+    lp_x4 wbf[3];
     if constexpr (BF16) {
 #pragma unroll
       for (int r = 0; r < 3; r++) {
         const int g = 16 * r + (lane >> 2), ch = g / 6, dy = (g >> 1) % 3, px = g & 1;
         const float *wq = p.w4eff_c + (ch * 4 + (lane & 3)) * 9 + dy * 3;
         const float w0 = wq[0], w1 = wq[1], w2 = wq[2];
-        wbf[r] = px ? hd_pk4(0.f, w0, w1, w2) : hd_pk4(w0, w1, w2, 0.f);
+        wbf[r] = px ? lp_pk4<LP ? LP : 1>(0.f, w0, w1, w2) : lp_pk4<LP ? LP : 1>(w0, w1, w2, 0.f);
       }
     }
     const int n16 = lane & 15, kq = lane >> 4;
@@ -971,12 +964,12 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
           if constexpr (BF16) {
 #pragma unroll
             for (int hf = 0; hf < 2; hf++) {
-              const s16x4 b4 = hd_pk4(V[t % 3][hf][0][0], V[t % 3][hf][0][1], V[t % 3][hf][1][0], V[t % 3][hf][1][1]);
+              const lp_x4 b4 = lp_pk4<LP ? LP : 1>(V[t % 3][hf][0][0], V[t % 3][hf][0][1], V[t % 3][hf][1][0], V[t % 3][hf][1][1]);
 #pragma unroll
               for (int px = 0; px < 2; px++) {
                 const int g = ((c + 4 * hf) * 3 + dy) * 2 + px;
                 switch (g & 15) {
-#define HS_CASEB(B) case B: acc[px][hf] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wbf[g >> 4], b4, acc[px][hf], 4, B, 0); break;
+#define HS_CASEB(B) case B: acc[px][hf] = lp_mfma4_bcast<LP ? LP : 1, B>(wbf[g >> 4], b4, acc[px][hf]); break;
                   HS_CASEB(0) HS_CASEB(1) HS_CASEB(2) HS_CASEB(3) HS_CASEB(4) HS_CASEB(5) HS_CASEB(6) HS_CASEB(7)
                   HS_CASEB(8) HS_CASEB(9) HS_CASEB(10) HS_CASEB(11) HS_CASEB(12) HS_CASEB(13) HS_CASEB(14) HS_CASEB(15)
 #undef HS_CASEB
@@ -1113,11 +1106,12 @@ int ofx_launch_head(ofx_handle *h, const HeadParams2 &p0) {
   const unsigned blocks = (unsigned)(((p.S + 7) / 8) * 16);
   int rc;
   if (p.event_base >= 0 && (rc = ofx_event_record(h, p.event_base))) return rc;
-  if (p.bf16) {
-    if (p.heat || p.ptr_probe) hipLaunchKernelGGL((k_head_stream<true, true>), dim3(blocks), dim3(HS_THREADS), 0, h->stream, p);
-    else hipLaunchKernelGGL((k_head_stream<false, true>), dim3(blocks), dim3(HS_THREADS), 0, h->stream, p);
-  } else if (p.heat || p.ptr_probe) hipLaunchKernelGGL((k_head_stream<true, false>), dim3(blocks), dim3(HS_THREADS), 0, h->stream, p);
-  else hipLaunchKernelGGL((k_head_stream<false, false>), dim3(blocks), dim3(HS_THREADS), 0, h->stream, p);
+  const bool extra = p.heat || p.ptr_probe;
+#define HS_LAUNCH(E, L) hipLaunchKernelGGL((k_head_stream<E, L>), dim3(blocks), dim3(HS_THREADS), 0, h->stream, p)
+  if (p.bf16 == 1) { if (extra) HS_LAUNCH(true, 1); else HS_LAUNCH(false, 1); }
+  else if (p.bf16 == 2) { if (extra) HS_LAUNCH(true, 2); else HS_LAUNCH(false, 2); }
+  else { if (extra) HS_LAUNCH(true, 0); else HS_LAUNCH(false, 0); }
+#undef HS_LAUNCH
   OFX_HIP(hipGetLastError());
   if (p.event_base >= 0 && (rc = ofx_event_record(h, p.event_base + 1))) return rc;
 #if OFX_HEAD_HOOKS

@@ -70,7 +70,8 @@ struct ofx_handle {
   const float *prep_pinned;        // the blob `prep` was built from while it is pinned (ofx_policy_pin_weights)
   int opt_trunk_fuse;              // OFX_OPT_TRUNK_FUSE: 0 auto, 1 always, 2 never
   int n_cus;                       // compute units of the device (grid of the persistent trunk kernel)
-  bool opt_trunk_plain, opt_frames_ref, opt_bilinear_legacy, opt_policy_bf16;  // ofx_set_option
+  bool opt_trunk_plain, opt_frames_ref, opt_bilinear_legacy;  // ofx_set_option
+  int opt_policy_lowp;             // OFX_OPT_POLICY_BF16: 0 fp32, 1 bf16 operands, 2 fp16 operands (opt-in)
 };
 #define OFX_RING_MAX 65536         /* numbered events of ofx_event_record */
 

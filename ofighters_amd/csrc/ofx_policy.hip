@@ -26,6 +26,7 @@
 
 #include "ofx_internal.h"
 #include "ofx_head.h"
+#include "ofx_lowp.h"
 
 #define PS 400 /* the model's fixed input side: Input((DEFAULT_WIDTH, DEFAULT_HEIGHT, 2)) */
 
@@ -398,20 +399,14 @@ __device__ __forceinline__ float max_raw(float x, float floor) {
 // the row pair of a column group shares one accumulator quad: lane (n = (co, r), kq) holds pixels 4 kq .. 4 kq + 3,
 // so the x-pool is in-lane and the y-pool is one DPP quad swap.
 // bf16 operand helpers of the opt-in OFX_OPT_POLICY_BF16 forms (k_convm, ts_gemm_phase_bf16)
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 pl_bf16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ s16x4 pl_pk4(float a, float b, float c, float d) {
-  const pl_bf16x2 lo = __builtin_convertvector((f32x2){a, b}, pl_bf16x2), hi = __builtin_convertvector((f32x2){c, d}, pl_bf16x2);
-  const uint2 u = {__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
-  return __builtin_bit_cast(s16x4, u);
-}
 // the lane's six B operands from wbm [24][64] (value for MFMA j of the fp32 form, lane l: k = l >> 4 -> ci = (l >> 4) + 4 (j & 1), tap j >> 1)
-__device__ __forceinline__ void ts_bw_bf16(const float *wbm, int n16, int kq, s16x4 (&bwb)[6]) {
+template <int LP>
+__device__ __forceinline__ void ts_bw_lp(const float *wbm, int n16, int kq, lp_x4 (&bwb)[6]) {
 #pragma unroll
   for (int J = 0; J < 6; J++) {
     const int j = 2 * (2 * J + (kq >> 1)) + (kq & 1);
     const float *q = wbm + j * 64 + n16;
-    bwb[J] = pl_pk4(q[0], q[16], q[32], q[48]);
+    bwb[J] = lp_pk4<LP>(q[0], q[16], q[32], q[48]);
   }
 }
 // MODE 0: planar f32 input [img][CIN][H][W] (the only mode left; conv1 reads the bit maps through k_conv1_lut).  Output: planar [img][8][H/2][W/2] or
@@ -419,8 +414,9 @@ __device__ __forceinline__ void ts_bw_bf16(const float *wbm, int n16, int kq, s1
 // A workgroup walks TPW consecutive tiles of one image: the weights are fetched once, the global loads of tile i+1 are
 // in flight (in registers) while tile i computes, and the grid stays small (the dispatcher needs ~5 ns per workgroup:
 // one workgroup per tile cost 1.6 ms of launch floor for conv2 alone).
-template <int CIN, int TH, int NG, int MODE, bool OUT_HWC, int TPW, bool BF16 = false>
+template <int CIN, int TH, int NG, int MODE, bool OUT_HWC, int TPW, int LP = 0>
 __global__ __launch_bounds__(256) void k_convm(ConvParams p) {
+  constexpr bool BF16 = LP != 0;
   static_assert(!BF16 || CIN == 8, "the bf16 form packs the four channels of a k-quarter");
   constexpr int TW = 16 * NG, LS = TW + 8;  // LDS row: image column tx0 + c sits at index c + 4 (16-byte aligned interior),
                                             // the left / right halo columns at 3 and TW + 4
@@ -456,10 +452,10 @@ __global__ __launch_bounds__(256) void k_convm(ConvParams p) {
   const float bias = p.b[co];
   const f32x4 binit = {bias, bias, bias, bias};
   // OFX_OPT_POLICY_BF16: see ts_gemm_phase_bf16 - MFMA J, element i: tap 2 J + (kq >> 1), channel 4 (kq & 1) + i
-  s16x4 bwb[6];
+  lp_x4 bwb[6];
   int toff[6];
   if constexpr (BF16) {
-    ts_bw_bf16(p.wbm, n16, kq, bwb);
+    ts_bw_lp<LP ? LP : 1>(p.wbm, n16, kq, bwb);
 #pragma unroll
     for (int J = 0; J < 6; J++) {
       const int tap = 2 * J + (kq >> 1);
@@ -588,10 +584,10 @@ __global__ __launch_bounds__(256) void k_convm(ConvParams p) {
 #pragma unroll
           for (int J = 0; J < 6; J++) {
             const float *q0 = a0 + toff[J], *q1 = a1 + toff[J];
-            const s16x4 A0 = pl_pk4(q0[0], q0[PLS], q0[2 * PLS], q0[3 * PLS]);
-            const s16x4 A1 = pl_pk4(q1[0], q1[PLS], q1[2 * PLS], q1[3 * PLS]);
-            d0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(A0, bwb[J], d0, 0, 0, 0);
-            d1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(A1, bwb[J], d1, 0, 0, 0);
+            const lp_x4 A0 = lp_pk4<LP ? LP : 1>(q0[0], q0[PLS], q0[2 * PLS], q0[3 * PLS]);
+            const lp_x4 A1 = lp_pk4<LP ? LP : 1>(q1[0], q1[PLS], q1[2 * PLS], q1[3 * PLS]);
+            d0 = lp_mfma16<LP ? LP : 1>(A0, bwb[J], d0);
+            d1 = lp_mfma16<LP ? LP : 1>(A1, bwb[J], d1);
           }
         } else {
 #pragma unroll
@@ -608,7 +604,7 @@ __global__ __launch_bounds__(256) void k_convm(ConvParams p) {
 #pragma unroll
           for (int J = 0; J < 6; J++) {
             const float *q0 = a0 + toff[J];
-            d0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pl_pk4(q0[0], q0[PLS], q0[2 * PLS], q0[3 * PLS]), bwb[J], d0, 0, 0, 0);
+            d0 = lp_mfma16<LP ? LP : 1>(lp_pk4<LP ? LP : 1>(q0[0], q0[PLS], q0[2 * PLS], q0[3 * PLS]), bwb[J], d0);
           }
         } else {
 #pragma unroll
@@ -621,7 +617,7 @@ __global__ __launch_bounds__(256) void k_convm(ConvParams p) {
   }
 }
 
-template <int CIN, int TH, int NG, int MODE, bool OUT_HWC, int TPW, bool BF16 = false>
+template <int CIN, int TH, int NG, int MODE, bool OUT_HWC, int TPW, int LP = 0>
 static int launch_convm(ofx_handle *h, ConvParams p, int images, int H) {
   p.H = H; p.W = H;
   p.tiles_x = (H + 16 * NG - 1) / (16 * NG);
@@ -629,7 +625,7 @@ static int launch_convm(ofx_handle *h, ConvParams p, int images, int H) {
   if (p.tiles % TPW) { ofx_set_error("launch_convm: %d tiles per image not divisible by %d", p.tiles, TPW); return OFX_ERR_INVALID; }
   if (OUT_HWC && (H % 2 || H > 16 * NG)) { ofx_set_error("launch_convm: the 8-byte staging takes even rows of one tile width"); return OFX_ERR_INVALID; }
   p.images = images;
-  hipLaunchKernelGGL((k_convm<CIN, TH, NG, MODE, OUT_HWC, TPW, BF16>), dim3((unsigned)((images + 7) / 8 * 8 * (p.tiles / TPW))), dim3(256), 0,
+  hipLaunchKernelGGL((k_convm<CIN, TH, NG, MODE, OUT_HWC, TPW, LP>), dim3((unsigned)((images + 7) / 8 * 8 * (p.tiles / TPW))), dim3(256), 0,
                      h->stream, p);
   OFX_HIP(hipGetLastError());
   return OFX_OK;
@@ -855,8 +851,8 @@ __device__ __forceinline__ void ts_gemm_phase(const float *abase, const float (&
 // the A operand is the four channel planes 4 (kq & 1) .. + 3 at the tap's (row, dx) of the fp32 LDS tile, rounded to
 // bf16 on the way in (one address per J: lane-constant tap offset, planes by immediate); the B operand is packed once
 // from the same PrepLayout::wbm the fp32 kernel uses.  fp32 accumulation, same epilogue.
-template <int WD, int RP, int LS, int PLS>
-__device__ __forceinline__ void ts_gemm_phase_bf16(const float *abase, const s16x4 (&bwb)[6], const f32x4 binit, int wv, int n16,
+template <int WD, int RP, int LS, int PLS, int LP>
+__device__ __forceinline__ void ts_gemm_phase_bf16(const float *abase, const lp_x4 (&bwb)[6], const f32x4 binit, int wv, int n16,
                                                    int kq, int r, float *orow) {
   constexpr int NPX = RP * WD, NT = (NPX + 15) / 16;
   static_assert(WD % 4 == 0 && NT <= 64, "four M-tiles per wave at most");
@@ -890,10 +886,10 @@ __device__ __forceinline__ void ts_gemm_phase_bf16(const float *abase, const s16
 #pragma unroll
     for (int J = 0; J < 6; J++) {
       const float *q0 = a0 + toff[J], *q1 = a1 + toff[J];
-      const s16x4 A0 = pl_pk4(q0[0], q0[PLS], q0[2 * PLS], q0[3 * PLS]);
-      const s16x4 A1 = pl_pk4(q1[0], q1[PLS], q1[2 * PLS], q1[3 * PLS]);
-      d0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(A0, bwb[J], d0, 0, 0, 0);
-      d1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(A1, bwb[J], d1, 0, 0, 0);
+      const lp_x4 A0 = lp_pk4<LP>(q0[0], q0[PLS], q0[2 * PLS], q0[3 * PLS]);
+      const lp_x4 A1 = lp_pk4<LP>(q1[0], q1[PLS], q1[2 * PLS], q1[3 * PLS]);
+      d0 = lp_mfma16<LP>(A0, bwb[J], d0);
+      d1 = lp_mfma16<LP>(A1, bwb[J], d1);
     }
     finish(d0, T);
     if (two) finish(d1, T1);
@@ -923,8 +919,9 @@ static_assert(F12_PLS % 64 == 16 && F12_PLS % 4 == 0 && F12_LS % 4 == 0, "tile l
 static_assert(2 * F12_BR * F12_WR <= F12_THREADS, "one staged word per thread");
 static_assert((F12_TH + 1) * 100 <= 2 * F12_THREADS && F12_TH * 100 <= F12_THREADS, "pixel pairs per step");
 
-template <bool BF16>
+template <int LP>
 __global__ __launch_bounds__(F12_THREADS) void k_trunk12(ConvParams p, const float *lut) {
+  constexpr bool BF16 = LP != 0;
   constexpr int W = PS, H = PS, H1 = PS / 2, H2 = PS / 4, LS = F12_LS, PLS = F12_PLS, NK = 24;
   __shared__ __align__(16) float slut[2 * 512 * 8];
   __shared__ __align__(16) float tile[8 * F12_PLS];
@@ -971,8 +968,8 @@ __global__ __launch_bounds__(F12_THREADS) void k_trunk12(ConvParams p, const flo
   for (int e = tid; e < 8 * PLS / 4; e += F12_THREADS) reinterpret_cast<f32x4 *>(tile)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int e = tid; e < 2 * 8 * 2 * LS / 4; e += F12_THREADS) reinterpret_cast<f32x4 *>(&halo[0][0][0][0])[e] = f32x4{0.f, 0.f, 0.f, 0.f};
   float bw[BF16 ? 1 : NK];
-  s16x4 bwb[6];
-  if constexpr (BF16) ts_bw_bf16(p.wbm, n16, kq, bwb);
+  lp_x4 bwb[6];
+  if constexpr (BF16) ts_bw_lp<LP ? LP : 1>(p.wbm, n16, kq, bwb);
   else {
 #pragma unroll
     for (int j = 0; j < NK; j++) bw[j] = p.wbm[j * 64 + lane];   // per-lane B operand of k_convm (PrepLayout::wbm)
@@ -1059,7 +1056,7 @@ __global__ __launch_bounds__(F12_THREADS) void k_trunk12(ConvParams p, const flo
     if (more) nextw = bits_fetch(nimg, na, nb);
 
     if constexpr (BF16)
-      ts_gemm_phase_bf16<200, F12_TH / 2, F12_LS, F12_PLS>(abase, bwb, binit, wv, n16, kq, r,
+      ts_gemm_phase_bf16<200, F12_TH / 2, F12_LS, F12_PLS, LP ? LP : 1>(abase, bwb, binit, wv, n16, kq, r,
                                                             p.out + (((size_t)img * 8 + co) * H2 + (R0 >> 1)) * H2);
     else
       ts_gemm_phase<200, F12_TH / 2, F12_LS, F12_PLS>(abase, bw, binit, wv, n16, kq, r,
@@ -1083,8 +1080,9 @@ constexpr int C3_PF4 = C3_ROWS * C3_F4, C3_NI = (C3_PF4 + 63) / 64;  // float4 o
 static_assert(C3_PLS % 64 == 16 && C3_W % C3_TH == 0 && C3_W / 4 + 2 == C3_F4 && 64 * C3_NI * 4 <= C3_PLS + 64 * 4, "tile layout");
 static_assert(2 * 8 * C3_PLS * 4 <= 160 * 1024, "two tiles in LDS");
 
-template <bool BF16>
+template <int LP>
 __global__ __launch_bounds__(F12_THREADS) void k_conv3_stream(ConvParams p, const float *zero16) {
+  constexpr bool BF16 = LP != 0;
   constexpr int W = C3_W, H = C3_W, H2 = C3_W / 2, PLS = C3_PLS, NK = 24, STEPS = H / C3_TH;
   __shared__ __align__(16) float tiles[2][8 * C3_PLS];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1108,8 +1106,8 @@ __global__ __launch_bounds__(F12_THREADS) void k_conv3_stream(ConvParams p, cons
   };
 
   float bw[BF16 ? 1 : NK];
-  s16x4 bwb[6];
-  if constexpr (BF16) ts_bw_bf16(p.wbm, n16, kq, bwb);
+  lp_x4 bwb[6];
+  if constexpr (BF16) ts_bw_lp<LP ? LP : 1>(p.wbm, n16, kq, bwb);
   else {
 #pragma unroll
     for (int j = 0; j < NK; j++) bw[j] = p.wbm[j * 64 + lane];
@@ -1131,7 +1129,7 @@ __global__ __launch_bounds__(F12_THREADS) void k_conv3_stream(ConvParams p, cons
     const int nimg = last ? img + (int)gridDim.x : img;
     if (nimg < p.images) stage(buf ^ 1, nimg, last ? 0 : R0 + C3_TH);
     if constexpr (BF16)
-      ts_gemm_phase_bf16<W, C3_TH / 2, C3_LS, C3_PLS>(&tiles[buf][kq * PLS + 3], bwb, binit, wv, n16, kq, r,
+      ts_gemm_phase_bf16<W, C3_TH / 2, C3_LS, C3_PLS, LP ? LP : 1>(&tiles[buf][kq * PLS + 3], bwb, binit, wv, n16, kq, r,
                                                       p.out + (((size_t)img * 8 + co) * H2 + (R0 >> 1)) * H2);
     else
       ts_gemm_phase<W, C3_TH / 2, C3_LS, C3_PLS>(&tiles[buf][kq * PLS + 3], bw, binit, wv, n16, kq, r,
@@ -1448,7 +1446,9 @@ extern "C" int ofx_set_option(ofx_handle *h, int32_t option, int32_t value) {
       if (value < 0 || value > 2) { ofx_set_error("ofx_set_option: OFX_OPT_TRUNK_FUSE takes 0 (auto), 1 (always), 2 (never)"); return OFX_ERR_INVALID; }
       h->opt_trunk_fuse = value; return OFX_OK;
     case OFX_OPT_FRAMES_REF: h->opt_frames_ref = value != 0; return OFX_OK;
-    case OFX_OPT_POLICY_BF16: h->opt_policy_bf16 = value != 0; return OFX_OK;
+    case OFX_OPT_POLICY_BF16:
+      if (value < 0 || value > 2) { ofx_set_error("ofx_set_option: OFX_OPT_POLICY_BF16 takes 0 (fp32), 1 (bf16 operands), 2 (fp16 operands)"); return OFX_ERR_INVALID; }
+      h->opt_policy_lowp = value; return OFX_OK;
     case OFX_OPT_BILINEAR_LEGACY:  // a different function, not a variant: the prepared phase weights depend on it
       if (h->opt_bilinear_legacy == (value != 0)) return OFX_OK;
       h->opt_bilinear_legacy = value != 0;
@@ -1485,16 +1485,16 @@ static int policy_forward_impl(ofx_handle *h, const float *weights, int N, int M
   cp.bits[1] = bits1;
   cp.bits_stride = bits_stride;
   cp.w = prep + L.tw[0]; cp.b = prep + L.tb[0]; cp.out = ws.p1;
-  const bool bf16 = h->opt_policy_bf16 && vec8 == nullptr;  // opt-in, the rollout's forward only (streaming trunk: conv2, conv3)
+  const int lowp = vec8 == nullptr ? h->opt_policy_lowp : 0;  // opt-in (1 bf16, 2 fp16 operands), the rollout's forward only
   const bool plain = h->opt_trunk_plain;  // OFX_OPT_TRUNK_PLAIN: every trunk layer through the plain VALU kernel
   const bool fused12 = trunk_fused(h, (size_t)N);
   if (plain) rc = launch_conv<2, 8, 10, 100, 1, true, false>(h, cp, N, 400);
   else if (fused12) {
     cp.out = ws.p2; cp.b = prep + L.tb[1]; cp.wbm = prep + L.wbm[0]; cp.images = N;
-    if (bf16) hipLaunchKernelGGL(k_trunk12<true>, dim3((unsigned)(N < h->n_cus ? N : h->n_cus)), dim3(F12_THREADS), 0, h->stream, cp,
-                                 (const float *)(prep + L.lut1));
-    else hipLaunchKernelGGL(k_trunk12<false>, dim3((unsigned)(N < h->n_cus ? N : h->n_cus)), dim3(F12_THREADS), 0, h->stream, cp,
-                            (const float *)(prep + L.lut1));
+    const dim3 g12((unsigned)(N < h->n_cus ? N : h->n_cus));
+    if (lowp == 1) hipLaunchKernelGGL(k_trunk12<1>, g12, dim3(F12_THREADS), 0, h->stream, cp, (const float *)(prep + L.lut1));
+    else if (lowp == 2) hipLaunchKernelGGL(k_trunk12<2>, g12, dim3(F12_THREADS), 0, h->stream, cp, (const float *)(prep + L.lut1));
+    else hipLaunchKernelGGL(k_trunk12<0>, g12, dim3(F12_THREADS), 0, h->stream, cp, (const float *)(prep + L.lut1));
     OFX_HIP(hipGetLastError());
   } else {
     cp.H = 400; cp.W = 400;
@@ -1512,16 +1512,17 @@ static int policy_forward_impl(ofx_handle *h, const float *weights, int N, int M
   if (plain) rc = launch_conv<8, 8, 10, 100, 0, true, false>(h, cp, N, 100);
   else if (fused12) {  // large batches: the streaming form, like conv1 -> conv2
     cp.images = N;
-    if (bf16) hipLaunchKernelGGL(k_conv3_stream<true>, dim3((unsigned)(N < h->n_cus ? N : h->n_cus)), dim3(F12_THREADS), 0, h->stream, cp,
-                                 (const float *)(prep + L.zero16));
-    else hipLaunchKernelGGL(k_conv3_stream<false>, dim3((unsigned)(N < h->n_cus ? N : h->n_cus)), dim3(F12_THREADS), 0, h->stream, cp,
-                            (const float *)(prep + L.zero16));
+    const dim3 g3((unsigned)(N < h->n_cus ? N : h->n_cus));
+    if (lowp == 1) hipLaunchKernelGGL(k_conv3_stream<1>, g3, dim3(F12_THREADS), 0, h->stream, cp, (const float *)(prep + L.zero16));
+    else if (lowp == 2) hipLaunchKernelGGL(k_conv3_stream<2>, g3, dim3(F12_THREADS), 0, h->stream, cp, (const float *)(prep + L.zero16));
+    else hipLaunchKernelGGL(k_conv3_stream<0>, g3, dim3(F12_THREADS), 0, h->stream, cp, (const float *)(prep + L.zero16));
     OFX_HIP(hipGetLastError());
   } else rc = launch_convm<8, 4, 7, 0, false, 1>(h, cp, N, 100);
   if (rc) return rc;
   cp.in = ws.p3; cp.w = prep + L.tw[3]; cp.b = prep + L.tb[3]; cp.out = ws.p4; cp.wbm = prep + L.wbm[2];
   if (plain) rc = launch_conv<8, 8, 10, 50, 0, true, true>(h, cp, N, 50);  // (h,w,c) = Flatten order
-  else if (bf16 && fused12) rc = launch_convm<8, 10, 4, 0, true, 1, true>(h, cp, N, 50);
+  else if (lowp == 1 && fused12) rc = launch_convm<8, 10, 4, 0, true, 1, 1>(h, cp, N, 50);
+  else if (lowp == 2 && fused12) rc = launch_convm<8, 10, 4, 0, true, 1, 2>(h, cp, N, 50);
   else rc = launch_convm<8, 10, 4, 0, true, 1>(h, cp, N, 50);
   if (rc) return rc;
 
@@ -1568,7 +1569,7 @@ static int policy_forward_impl(ofx_handle *h, const float *weights, int N, int M
   hp2.w2fr = prep + L.w2fr; hp2.w3fr = prep + L.w3fr; hp2.efr = prep + L.efr;
   hp2.u2fr = ws.u2fr; hp2.u3fr = ws.u3fr; hp2.c4 = ws.c4;
   hp2.frames_ref = h->opt_frames_ref; hp2.legacy = h->opt_bilinear_legacy;
-  hp2.bf16 = bf16;  // the rollout's forward only: targets and fit stay fp32
+  hp2.bf16 = lowp;  // the rollout's forward only: targets and fit stay fp32
   hp2.mask = ship_mask; hp2.live = ws.live; hp2.live_ready = ship_mask != nullptr; hp2.best = ws.best; hp2.heat = heatmap; hp2.probe = probe; hp2.ptr_probe = probe ? ptr_probe : nullptr;
   const int pb = h->prof_base;  // ofx_policy_profile: events around the dominant kernel, until the ring is full
   hp2.event_base = pb;
