@@ -327,6 +327,19 @@ def test_error_behaviour():
     b = _batch(4, 4)
     with pytest.raises(OfxError):            # step before spawn
         b.step(actions_ptr=b._actions.ptr)
+    with pytest.raises(OfxError, match="before ofx_spawn"):
+        b.rollout(["idle"] * 4, 1, 0, 5)
+    b.spawn_random(1)
+    t_before = b.get(nat.F_TIME).copy()
+    b.rollout(["idle"] * 4, 1, 0, 0)         # zero lock-steps: a no-op
+    assert np.array_equal(b.get(nat.F_TIME), t_before)
+    with pytest.raises(OfxError, match="observe_map_type"):
+        b.rollout(["idle"] * 4, 1, 0, 3, observe=7)
+    with pytest.raises(Exception):           # agents/agent.py:51, before any lock-step runs
+        b.rollout(["idle", "kamikaze", "idle", "idle"], 1, 0, 3)
+    assert np.array_equal(b.get(nat.F_TIME), t_before)
+    b.close()
+    b = _batch(4, 4)
     with pytest.raises(Exception):           # agents/agent.py:51
         b.spawn_random(1)
         b.bot_actions(["kamikaze"] * 4, 1)
