@@ -906,10 +906,11 @@ __device__ __forceinline__ void ts_gemm_phase_bf16(const float *abase, const lp_
 //            the next step's bit rows are in flight meanwhile;
 //            (the step's last two p1 rows are also kept aside: they are the first two tile rows of the next step).
 // Separating the phases in time costs little as long as each phase has its four waves per SIMD busy; one workgroup per CU.
-// (r03: MFMA-only waves and table-only waves DO overlap on a SIMD, tools/ubench_coexec.hip, but the table phase is one
-// pass of ~8 400 cycles per WAVE whatever the number of waves - a chain of LDS latencies - so a form with two
-// half-workgroups in anti-phase, 8 table waves beside 8 GEMM waves on two images, halves the table throughput and took
-// 3.19 ms against 2.83 ms; measured on the chip and removed again)
+// (r03: a form with two half-workgroups in anti-phase, 8 table waves beside 8 GEMM waves on two images, took 3.19 ms
+// against 2.83 ms - measured on the chip and removed again, DESIGN.md section 3.  MFMA and VALU instructions share one
+// issue port per SIMD and a matrix wave with MFMAs queued starves the vector instructions of the waves beside it
+// (tools/ubench_coexec.hip, fixed-window form); the table phase is also one chain of LDS latencies of ~8 400 cycles
+// per WAVE whatever the number of waves, so halving the table waves halves the table throughput.)
 // Output = k_convm's: planar [img][8][100][100].
 constexpr int F12_TH = 10, F12_LS = 216, F12_ROWS = F12_TH + 2;
 constexpr int F12_PLS = (F12_ROWS * F12_LS + 63) / 64 * 64 + 16;  // plane stride = 16 mod 64, as k_convm

@@ -84,9 +84,14 @@ int main() {
     run<0, 2, 8, 8>(b);
     run<0, 2, 8, 16>(b);
     run<1, 0, 8, 0>(b);
+    run<1, 0, 8, 8>(b);
     run<1, 0, 8, 16>(b);
+    run<1, 0, 8, 24>(b);
     run<1, 0, 8, 32>(b);
+    run<1, 0, 8, 40>(b);
+    run<1, 0, 8, 48>(b);
     run<1, 0, 8, 64>(b);
+    run<1, 1, 8, 40>(b);
     run<1, 1, 8, 32>(b);
     run<1, 1, 8, 64>(b);
     run<1, 2, 8, 16>(b);
