@@ -293,6 +293,11 @@ int ofx_policy_pin_weights(ofx_handle *h, const float *weights);
  * path at the 3e-3 (bf16) / 4e-4 (fp16) level and near-ties of its arg-max can resolve differently; bench.py reports the
  * measured error against the float64 graph and the arg-max agreement next to the speed.                              */
 #define OFX_OPT_POLICY_BF16 5
+/* Diagnostic: ofx_dqn_fit / ofx_dqn_fit_reference in their PLAIN form (value 1): one kernel per layer and pass, every
+ * activation, pooled / up-sampled input and gradient of the graph in HBM (61 MB per row of the minibatch).  The default
+ * (0) is the lean form: only the pre-activation tensor of every convolution is kept (17.8 MB per row), everything else
+ * is recomputed inside fused tiles.  Same function; the results agree up to fp32 summation order (tests/test_train.py).*/
+#define OFX_OPT_FIT_PLAIN 6
 int ofx_set_option(ofx_handle *h, int32_t option, int32_t value);
 /* Exploration of the bi-head action space (Trainer.get_best_action epsilon branch, agents/qlearnIA_V2.py:199-204,
  * and the collecting phase :393-395): for every selected ship, with probability `epsilon` - or always when

@@ -1,0 +1,40 @@
+// ofx_fit.h - launchers of the lean fit's convolution kernels (ofx_fit.hip), called by ofx_train.hip's orchestration
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+// how a convolution's input is produced from what is kept in HBM
+#define OFX_FIT_SRC_BITS 0   /* 1-bit maps -> 0.f / 1.f */
+#define OFX_FIT_SRC_POOL 1   /* pool2(relu(bn(z_prev)))          (trunk) */
+#define OFX_FIT_SRC_UP 2     /* up2(relu(bn(z_prev)))            (head 2) */
+#define OFX_FIT_SRC_UPRAW 3  /* up2(u0), u0 already behind its ReLU */
+
+#define OFX_FIT_MAX_BLOCKS 2048 /* persistent grids: at most this many blocks, each with one row of partial sums */
+
+struct ofx_fit_src {
+  int kind;
+  const void *p;      // bits [n][C][5000] or the producing layer's z [n][C][h][w]
+  const float *act;   // the producing layer's {scale, shift} per channel; null for bits / raw
+  int h, w;           // dims of p's planes
+  int legacy;         // OFX_OPT_BILINEAR_LEGACY
+};
+
+size_t ofx_fit_part_doubles(void);  // size of the partial-sum buffer every launcher below may use
+// z = conv3x3(src) + b; part != null: the block sums of z, z*z per output channel (part[block][2 co]), *nblocks rows
+int ofx_fit_conv_fwd(hipStream_t st, int n, int ci, int co, int H, int W, const ofx_fit_src &src, const float *w,
+                     const float *b, float *z, double *part, int *nblocks);
+// ordered combine of part[nblocks][2 c] -> sums[2 c] (may be null); with stat != null also {mean, var} and {scale, shift}
+int ofx_fit_finish(hipStream_t st, int nblocks, int c_n, double count, const double *part, const float *gamma,
+                   const float *beta, double *sums, float *stat, float *act);
+int ofx_fit_pool_act(hipStream_t st, int n, int C, int H, int W, const float *z, const float *act, float *p);
+// g = d loss / d (BN output of the layer), ReLU-masked, through the pooling in front of the next convolution
+// (conv: dzn = that convolution's dz [n][8][H/2][W/2], wn its kernel; else dzn = d pooled output)
+int ofx_fit_b1_pool(hipStream_t st, int n, int H, int W, int conv, const float *dzn, const float *wn, const float *z,
+                    const float *stat, const float *act, float *g, double *part, int *nblocks);
+// the same through the x2 up-sampling in front of a convolution with `con` output channels at 2h x 2w
+int ofx_fit_b1_up(hipStream_t st, int n, int c, int con, int h, int w, int bn, const float *dzn, const float *wn,
+                  const float *zp, const float *stat, const float *act, int legacy, float *g, double *part, int *nblocks);
+// dz over g in place (bn), dw / db (/ dgamma, dbeta from sums)
+int ofx_fit_bw(hipStream_t st, int n, int ci, int co, int H, int W, const ofx_fit_src &src, int bn, float *g,
+               const float *z, const float *stat, const float *gamma, const double *sums, double *part, float *dw,
+               float *db, float *dgamma, float *dbeta);

@@ -1,0 +1,645 @@
+// ofx_fit.hip - the convolution side of model.fit (agents/qlearnIA_V2.py:284, graph :123-190) in its LEAN form:
+// only the pre-activation tensor z of every convolution is kept in HBM.  What the plain form (ofx_train.hip) also
+// stored - relu(bn(z)), the pooled / up-sampled inputs of the next convolution, x-hat, the gradient of every one of them -
+// is recomputed where it is used, from z and the layer's batch statistics, inside the kernel that needs it:
+//
+//   f_conv_fwd   z = conv3x3(src) + b for a tile of 10 x 100 pixels, the input tile built in LDS by a SOURCE functor:
+//                bits -> float | pool2(relu(bn(z_prev))) | up2(relu(bn(z_prev))) | up2(u0); a thread owns 4 pixels x
+//                all output channels; the epilogue keeps the per-channel sums of z and z*z of the block (doubles, one
+//                ordered combine per layer): BatchNorm's batch statistics without a pass of their own.
+//   f_b1_pool /  g = d loss / d z's activation, masked by the ReLU: the transposed convolution of the NEXT layer's dz
+//   f_b1_up      (tile in LDS) pushed back through the pooling (first maximum of the window, recomputed) or through the
+//                x2 bilinear up-sampling (gather form), plus the block's sums of g and g * xhat for BatchNorm's backward.
+//   f_bw         dz = gamma rs (g - mean(g) - xhat mean(g xhat)) written in place over g, and the weight gradient
+//                dW[tap][ci][co] = sum in[ci][p + tap] dz[co][p] with the input tile rebuilt by the same source functor:
+//                a wave owns an input channel, a lane a pixel, 9 x CO accumulators per lane, flushed into doubles.
+//
+// Every reduction has a fixed order (tile -> block assignment by index, ordered combines): two fits from the same state
+// give the same bits.  fp32 VALU with FMA contraction; checked against torch autograd in float64 and against the plain
+// form (tests/test_train.py).  Per row of the minibatch 17.8 MB of workspace instead of 61 MB.
+#include "ofx_internal.h"
+#include "ofx_fit.h"
+
+namespace {
+
+__device__ __forceinline__ float bn_act(float z, float sc, float sh) { return fmaxf(fmaf(z, sc, sh), 0.f); }
+
+// x2 bilinear taps of up-res index u over n source cells: half-pixel centres, or (legacy) src = dst / 2 - the same
+// conventions as ofx_train.hip's up_taps / the forward's OFX_OPT_BILINEAR_LEGACY
+__device__ __forceinline__ void fit_up_taps(int u, int n, int &i0, int &i1, float &w1, int legacy) {
+  const int k = u >> 1;
+  if (legacy) { i0 = k; i1 = min(k + 1, n - 1); w1 = (u & 1) ? 0.5f : 0.f; }
+  else if (u & 1) { i0 = k; i1 = min(k + 1, n - 1); w1 = 0.25f; }
+  else { i0 = max(k - 1, 0); i1 = k; w1 = 0.75f; }
+}
+
+struct FitSrc {
+  const void *p;      // bits [n][C][5000] or the producing layer's z [n][C][h][w]
+  const float *act;   // the producing layer's {scale, shift} per channel (relu(z * scale + shift)); unused for bits / raw
+  int h, w;           // dims of p's planes
+  int legacy;
+};
+
+// value of the convolution's input (channel c of sample s) at (y, x) of its H x W plane; zero outside
+template <int SRC, int C>
+__device__ __forceinline__ float src_value(const FitSrc &S, size_t s, int c, int y, int x, int H, int W) {
+  if (y < 0 || y >= H || x < 0 || x >= W) return 0.f;
+  if constexpr (SRC == OFX_FIT_SRC_BITS) {
+    const uint32_t *b = reinterpret_cast<const uint32_t *>(S.p) + (s * C + c) * (size_t)((H * W) >> 5);
+    const int p = y * W + x;
+    return (float)((b[p >> 5] >> (p & 31)) & 1u);
+  } else if constexpr (SRC == OFX_FIT_SRC_POOL) {
+    const float *z = reinterpret_cast<const float *>(S.p) + ((s * C + c) * (size_t)S.h + 2 * y) * S.w + 2 * x;
+    const float sc = S.act[2 * c], sh = S.act[2 * c + 1];
+    const float2 r0 = *reinterpret_cast<const float2 *>(z), r1 = *reinterpret_cast<const float2 *>(z + S.w);
+    return fmaxf(fmaxf(bn_act(r0.x, sc, sh), bn_act(r0.y, sc, sh)), fmaxf(bn_act(r1.x, sc, sh), bn_act(r1.y, sc, sh)));
+  } else {
+    int y0, y1, x0, x1;
+    float wy, wx;
+    fit_up_taps(y, S.h, y0, y1, wy, S.legacy);
+    fit_up_taps(x, S.w, x0, x1, wx, S.legacy);
+    const float *q = reinterpret_cast<const float *>(S.p) + (s * C + c) * (size_t)S.h * S.w;
+    float v00 = q[y0 * S.w + x0], v01 = q[y0 * S.w + x1], v10 = q[y1 * S.w + x0], v11 = q[y1 * S.w + x1];
+    if constexpr (SRC == OFX_FIT_SRC_UP) {
+      const float sc = S.act[2 * c], sh = S.act[2 * c + 1];
+      v00 = bn_act(v00, sc, sh); v01 = bn_act(v01, sc, sh); v10 = bn_act(v10, sc, sh); v11 = bn_act(v11, sc, sh);
+    }
+    const float top = v00 * (1.f - wx) + v01 * wx, bot = v10 * (1.f - wx) + v11 * wx;
+    return top * (1.f - wy) + bot * wy;
+  }
+}
+
+// sum of v over the 64 lanes (every lane gets it)
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// K consecutive floats of an LDS array at a wave-uniform offset (a broadcast read).  The kernels keep their weights in
+// LDS: read through the kernel argument they are loop-invariant scalar loads, the compiler hoists all 576 of an 8 -> 8
+// layer out of the tile loop and parks them in vector registers (351 VGPRs, one wave per SIMD).
+template <int K>
+__device__ __forceinline__ void lds_vec(const float *p, float (&o)[K]) {
+  if constexpr (K % 4 == 0) {
+#pragma unroll
+    for (int i = 0; i < K / 4; i++) {
+      const float4 v = reinterpret_cast<const float4 *>(p)[i];
+      o[4 * i] = v.x; o[4 * i + 1] = v.y; o[4 * i + 2] = v.z; o[4 * i + 3] = v.w;
+    }
+  } else if constexpr (K == 2) {
+    const float2 v = *reinterpret_cast<const float2 *>(p);
+    o[0] = v.x; o[1] = v.y;
+  } else {
+#pragma unroll
+    for (int i = 0; i < K; i++) o[i] = p[i];
+  }
+}
+
+// ---------------------------------------------------------------- forward
+constexpr int F_TR = 10;  // rows of a forward tile
+
+template <int CI, int CO, int SRC, int TW, bool STATS>
+__global__ __launch_bounds__(256, 3) void f_conv_fwd(int n, int H, int W, FitSrc S, const float *__restrict__ w,
+                                                  const float *__restrict__ b, float *__restrict__ z,
+                                                  double *__restrict__ part) {
+  constexpr int TPR = (TW + 3) / 4, LP = 4 * TPR + 4;
+  static_assert(F_TR * TPR <= 256, "tile does not fit the block");
+  __shared__ __align__(16) float in[CI][F_TR + 2][LP];
+  __shared__ __align__(16) float wl[9 * CI * CO];
+  __shared__ double red[4][2 * CO];
+  const int tid = threadIdx.x, r = tid / TPR, q = tid - r * TPR;
+  const bool active = r < F_TR;
+  for (int e = tid; e < 9 * CI * CO; e += 256) wl[e] = w[e];
+  const int tx_n = W / TW, ty_n = H / F_TR, per_s = tx_n * ty_n;
+  const long ntiles = (long)n * per_s;
+  double d1[CO], d2[CO];
+#pragma unroll
+  for (int co = 0; co < CO; co++) { d1[co] = 0.0; d2[co] = 0.0; }
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const size_t s = tile / per_s;
+    const int t = (int)(tile - (long)s * per_s), y0 = (t / tx_n) * F_TR, x0 = (t % tx_n) * TW;
+    __syncthreads();
+    for (int e = tid; e < CI * (F_TR + 2) * (TW + 2); e += 256) {
+      const int ci = e / ((F_TR + 2) * (TW + 2)), rem = e - ci * ((F_TR + 2) * (TW + 2));
+      const int yy = rem / (TW + 2), xx = rem - yy * (TW + 2);
+      in[ci][yy][xx] = src_value<SRC, CI>(S, s, ci, y0 - 1 + yy, x0 - 1 + xx, H, W);
+    }
+    __syncthreads();
+    if (!active) continue;
+    float acc[4][CO];
+#pragma unroll
+    for (int co = 0; co < CO; co++) {
+      const float bv = b[co];
+#pragma unroll
+      for (int px = 0; px < 4; px++) acc[px][co] = bv;
+    }
+    // one input channel at a time: unrolled over ci the scheduler requests all 9 CI CO weights up front (512 VGPRs)
+#pragma unroll 1
+    for (int ci = 0; ci < CI; ci++) {
+#pragma unroll
+      for (int ky = 0; ky < 3; ky++) {
+        const float4 a4 = *reinterpret_cast<const float4 *>(&in[ci][r + ky][4 * q]);
+        const float2 a2 = *reinterpret_cast<const float2 *>(&in[ci][r + ky][4 * q + 4]);
+        const float v[6] = {a4.x, a4.y, a4.z, a4.w, a2.x, a2.y};
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) {
+          float wv[CO];
+          lds_vec<CO>(&wl[((ky * 3 + kx) * CI + ci) * CO], wv);
+#pragma unroll
+          for (int co = 0; co < CO; co++) {
+#pragma unroll
+            for (int px = 0; px < 4; px++) acc[px][co] = fmaf(v[px + kx], wv[co], acc[px][co]);
+          }
+        }
+      }
+    }
+    const int y = y0 + r, x = x0 + 4 * q;
+#pragma unroll
+    for (int co = 0; co < CO; co++) {
+      float *zp = z + ((s * CO + co) * (size_t)H + y) * W + x;
+      float f1 = 0.f, f2 = 0.f;
+      if (4 * q + 4 <= TW) {
+        *reinterpret_cast<float4 *>(zp) = make_float4(acc[0][co], acc[1][co], acc[2][co], acc[3][co]);
+#pragma unroll
+        for (int px = 0; px < 4; px++) { f1 += acc[px][co]; f2 = fmaf(acc[px][co], acc[px][co], f2); }
+      } else {
+#pragma unroll
+        for (int px = 0; px < 4; px++)
+          if (4 * q + px < TW) { zp[px] = acc[px][co]; f1 += acc[px][co]; f2 = fmaf(acc[px][co], acc[px][co], f2); }
+      }
+      if (STATS) { d1[co] += (double)f1; d2[co] += (double)f2; }
+    }
+  }
+  if constexpr (STATS) {
+#pragma unroll
+    for (int co = 0; co < CO; co++) {
+      const double a = wave_sum(d1[co]), c = wave_sum(d2[co]);
+      if ((tid & 63) == 0) { red[tid >> 6][2 * co] = a; red[tid >> 6][2 * co + 1] = c; }
+    }
+    __syncthreads();
+    if (tid < 2 * CO) part[(size_t)blockIdx.x * 2 * CO + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+  }
+}
+
+// part[block][2 C] -> sums[2 C] in block order; with gamma: also the batch statistics {mean, biased variance} and the
+// activation's {scale, shift}
+__global__ void f_finish(int nblocks, int c_n, double count, const double *part, const float *gamma, const float *beta,
+                         double *sums, float *stat, float *act) {
+  const int k = threadIdx.x;
+  if (k >= 2 * c_n) return;
+  double acc = 0.0;
+  for (int i = 0; i < nblocks; i++) acc += part[(size_t)i * 2 * c_n + k];
+  if (sums) sums[k] = acc;
+  if (!stat) return;
+  __shared__ double sh[32];
+  sh[k] = acc;
+  __syncthreads();
+  if (k < c_n) {
+    const double m = sh[2 * k] / count, v = sh[2 * k + 1] / count - m * m;
+    const float mean = (float)m, var = (float)(v > 0.0 ? v : 0.0);
+    stat[2 * k] = mean;
+    stat[2 * k + 1] = var;
+    const float sc = gamma[k] * rsqrtf(var + 1e-3f);
+    act[2 * k] = sc;
+    act[2 * k + 1] = beta[k] - mean * sc;
+  }
+}
+
+// p[n][8][h/2][w/2] = pool2(relu(bn(z))) - the trunk's last layer feeds the dense head through the flatten
+__global__ void f_pool_act(int n, int C, int H, int W, const float *z, const float *act, float *p) {
+  const int H2 = H / 2, W2 = W / 2;
+  const size_t total = (size_t)n * C * H2 * W2;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int x = e % W2, y = (e / W2) % H2;
+    const size_t pl = e / ((size_t)W2 * H2);
+    const int c = pl % C;
+    const float sc = act[2 * c], sh = act[2 * c + 1];
+    const float *q = z + (pl * H + 2 * y) * W + 2 * x;
+    p[e] = fmaxf(fmaxf(bn_act(q[0], sc, sh), bn_act(q[1], sc, sh)), fmaxf(bn_act(q[W], sc, sh), bn_act(q[W + 1], sc, sh)));
+  }
+}
+
+// ---------------------------------------------------------------- backward 1: through the pooling
+// Layer L of the trunk (8 channels, H x W): dp = conv3x3^T(dz of layer L + 1) on the pooled H/2 x W/2 grid (CONV), or
+// dp given (the last trunk layer: the dense head's gradient); g = dp at the first maximum of each 2 x 2 window of
+// a = relu(bn(z)) where that maximum is positive, zero elsewhere; part[block] = {sum g, sum g xhat} per channel.
+constexpr int P_TR = 10, P_TW = 50;
+template <bool CONV>
+__global__ __launch_bounds__(256, 3) void f_b1_pool(int n, int H, int W, const float *__restrict__ dzn,
+                                                 const float *__restrict__ wn, const float *__restrict__ z,
+                                                 const float *__restrict__ stat, const float *__restrict__ act,
+                                                 float *__restrict__ g, double *__restrict__ part) {
+  constexpr int C = 8, LP = P_TW + 4;
+  __shared__ __align__(16) float dzt[CONV ? C : 1][P_TR + 2][LP];
+  __shared__ __align__(16) float wl[CONV ? 9 * C * C : 4];   // [tap][co][ci]: the C input channels of one read contiguous
+  __shared__ double red[4][2 * C];
+  const int Hp = H / 2, Wp = W / 2;
+  if constexpr (CONV)
+    for (int e = threadIdx.x; e < 9 * C * C; e += 256) {
+      const int ci = e % C, co = (e / C) % C, tap = e / (C * C);
+      wl[e] = wn[(tap * C + ci) * C + co];
+    }
+  const int tid = threadIdx.x, r = tid / (P_TW / 2), q = tid - r * (P_TW / 2);
+  const int tx_n = (Wp + P_TW - 1) / P_TW, ty_n = (Hp + P_TR - 1) / P_TR, per_s = tx_n * ty_n;
+  const long ntiles = (long)n * per_s;
+  double s1[C], s2[C];
+#pragma unroll
+  for (int c = 0; c < C; c++) { s1[c] = 0.0; s2[c] = 0.0; }
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const size_t s = tile / per_s;
+    const int t = (int)(tile - (long)s * per_s), y0 = (t / tx_n) * P_TR, x0 = (t % tx_n) * P_TW;
+    if constexpr (CONV) {
+      __syncthreads();
+      for (int e = tid; e < C * (P_TR + 2) * (P_TW + 2); e += 256) {
+        const int co = e / ((P_TR + 2) * (P_TW + 2)), rem = e - co * ((P_TR + 2) * (P_TW + 2));
+        const int yy = rem / (P_TW + 2), xx = rem - yy * (P_TW + 2);
+        const int y = y0 - 1 + yy, x = x0 - 1 + xx;
+        dzt[co][yy][xx] = (y >= 0 && y < Hp && x >= 0 && x < Wp) ? dzn[((s * C + co) * (size_t)Hp + y) * Wp + x] : 0.f;
+      }
+      __syncthreads();
+    }
+    const int yp = y0 + r, xp = x0 + 2 * q;
+    if (r >= P_TR || yp >= Hp || xp >= Wp) continue;
+    float dp[2][C];
+    if constexpr (CONV) {
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int ci = 0; ci < C; ci++) dp[j][ci] = 0.f;
+#pragma unroll 1
+      for (int co = 0; co < C; co++) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++) {
+          // dz row yp - (ky - 1) = tile row r - ky + 2; columns xp - 1 .. xp + 2 = tile columns 2 q .. 2 q + 3
+          const float2 a = *reinterpret_cast<const float2 *>(&dzt[co][r - ky + 2][2 * q]);
+          const float2 c2 = *reinterpret_cast<const float2 *>(&dzt[co][r - ky + 2][2 * q + 2]);
+          const float v[4] = {a.x, a.y, c2.x, c2.y};
+#pragma unroll
+          for (int kx = 0; kx < 3; kx++) {
+            float wv[C];
+            lds_vec<C>(&wl[((ky * 3 + kx) * C + co) * C], wv);
+#pragma unroll
+            for (int ci = 0; ci < C; ci++) {
+              dp[0][ci] = fmaf(v[2 - kx], wv[ci], dp[0][ci]);
+              dp[1][ci] = fmaf(v[3 - kx], wv[ci], dp[1][ci]);
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int ci = 0; ci < C; ci++) {
+      const float mean = stat[2 * ci], rs = rsqrtf(stat[2 * ci + 1] + 1e-3f), sc = act[2 * ci], sh = act[2 * ci + 1];
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        if (xp + j >= Wp) continue;
+        const size_t base = ((s * C + ci) * (size_t)H + 2 * yp) * W + 2 * (xp + j);
+        const float2 r0 = *reinterpret_cast<const float2 *>(z + base), r1 = *reinterpret_cast<const float2 *>(z + base + W);
+        const float zv[4] = {r0.x, r0.y, r1.x, r1.y};
+        float av[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) av[i] = bn_act(zv[i], sc, sh);
+        int k = 0;
+#pragma unroll
+        for (int i = 1; i < 4; i++) if (av[i] > av[k]) k = i;
+        const float d = CONV ? dp[j][ci] : dzn[((s * C + ci) * (size_t)Hp + yp) * Wp + xp + j];
+        const float gv = av[k] > 0.f ? d : 0.f;
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) o[i] = i == k ? gv : 0.f;
+        *reinterpret_cast<float2 *>(g + base) = make_float2(o[0], o[1]);
+        *reinterpret_cast<float2 *>(g + base + W) = make_float2(o[2], o[3]);
+        s1[ci] += (double)gv;
+        s2[ci] += (double)(gv * ((zv[k] - mean) * rs));
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < C; c++) {
+    const double a = wave_sum(s1[c]), b2 = wave_sum(s2[c]);
+    if ((tid & 63) == 0) { red[tid >> 6][2 * c] = a; red[tid >> 6][2 * c + 1] = b2; }
+  }
+  __syncthreads();
+  if (tid < 2 * C) part[(size_t)blockIdx.x * 2 * C + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
+// ---------------------------------------------------------------- backward 1: through the x2 up-sampling
+// Producer P (C channels, h x w: u0 or a head layer's z) feeds conv3x3(up2(act(P))) with CON output channels at
+// 2h x 2w.  dU = conv3x3^T(dz of that convolution) on the up-res grid (LDS), gathered back through the bilinear taps
+// (fixed order), masked by P's ReLU; with BN the block's {sum g, sum g xhat}.
+constexpr int U_TW = 50;
+template <int C, int CON, int TRL, bool BN>
+__global__ __launch_bounds__(256, 2) void f_b1_up(int n, int h, int w, const float *__restrict__ dzn,
+                                               const float *__restrict__ wn, const float *__restrict__ zp,
+                                               const float *__restrict__ stat, const float *__restrict__ act, int legacy,
+                                               float *__restrict__ g, double *__restrict__ part) {
+  constexpr int UR = 2 * TRL + 3, UC = 2 * U_TW + 3, UP_ = UC + 1;   // dU tile: up-res rows 2 y0 - 2 .., pitch
+  constexpr int DR = UR + 2, DC = UC + 2, DP = DC + 1;               // dz tile: one more cell all round
+  __shared__ float dzt[CON][DR][DP];
+  __shared__ float du[C][UR][UP_];
+  __shared__ __align__(16) float wl[9 * CON * C];            // [tap][co][c]
+  __shared__ double red[4][2 * C];
+  static_assert(sizeof(float) * (CON * DR * DP + C * UR * UP_ + 9 * CON * C) <= 62 * 1024, "LDS tiles too large");
+  for (int e = threadIdx.x; e < 9 * CON * C; e += 256) {
+    const int c = e % C, co = (e / C) % CON, tap = e / (C * CON);
+    wl[e] = wn[(tap * C + c) * CON + co];
+  }
+  const int H2 = 2 * h, W2 = 2 * w;
+  const int tid = threadIdx.x, r = tid / U_TW, q = tid - r * U_TW;
+  const int tx_n = (w + U_TW - 1) / U_TW, ty_n = (h + TRL - 1) / TRL, per_s = tx_n * ty_n;
+  const long ntiles = (long)n * per_s;
+  double s1[C], s2[C];
+#pragma unroll
+  for (int c = 0; c < C; c++) { s1[c] = 0.0; s2[c] = 0.0; }
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const size_t s = tile / per_s;
+    const int t = (int)(tile - (long)s * per_s), y0 = (t / tx_n) * TRL, x0 = (t % tx_n) * U_TW;
+    __syncthreads();
+    for (int e = tid; e < CON * DR * DC; e += 256) {
+      const int co = e / (DR * DC), rem = e - co * (DR * DC), i = rem / DC, j = rem - i * DC;
+      const int Y = 2 * y0 - 3 + i, X = 2 * x0 - 3 + j;
+      dzt[co][i][j] = (Y >= 0 && Y < H2 && X >= 0 && X < W2) ? dzn[((s * CON + co) * (size_t)H2 + Y) * W2 + X] : 0.f;
+    }
+    __syncthreads();
+    for (int e = tid; e < UR * UC; e += 256) {
+      const int i = e / UC, j = e - i * UC;
+      float acc[C];
+#pragma unroll
+      for (int c = 0; c < C; c++) acc[c] = 0.f;
+#pragma unroll 1
+      for (int co = 0; co < CON; co++)
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+          for (int kx = 0; kx < 3; kx++) {
+            const float v = dzt[co][i - ky + 2][j - kx + 2];
+            float wv[C];
+            lds_vec<C>(&wl[((ky * 3 + kx) * CON + co) * C], wv);
+#pragma unroll
+            for (int c = 0; c < C; c++) acc[c] = fmaf(v, wv[c], acc[c]);
+          }
+#pragma unroll
+      for (int c = 0; c < C; c++) du[c][i][j] = acc[c];
+    }
+    __syncthreads();
+    const int y = y0 + r, x = x0 + q;
+    if (r >= TRL || y >= h || x >= w) continue;
+    float cy[5], cx[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      const int uy = 2 * y - 2 + k, ux = 2 * x - 2 + k;
+      int a0, a1;
+      float wt;
+      cy[k] = 0.f; cx[k] = 0.f;
+      if (uy >= 0 && uy < H2) { fit_up_taps(uy, h, a0, a1, wt, legacy); cy[k] = (a0 == y ? 1.f - wt : 0.f) + (a1 == y ? wt : 0.f); }
+      if (ux >= 0 && ux < W2) { fit_up_taps(ux, w, a0, a1, wt, legacy); cx[k] = (a0 == x ? 1.f - wt : 0.f) + (a1 == x ? wt : 0.f); }
+    }
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+      float acc = 0.f;
+#pragma unroll
+      for (int ky = 0; ky < 5; ky++) {
+        float row = 0.f;
+#pragma unroll
+        for (int kx = 0; kx < 5; kx++) row = fmaf(cx[kx], du[c][2 * r + ky][2 * q + kx], row);
+        acc = fmaf(cy[ky], row, acc);
+      }
+      const size_t at = ((s * C + c) * (size_t)h + y) * w + x;
+      const float zv = zp[at];
+      if constexpr (BN) {
+        const float gv = bn_act(zv, act[2 * c], act[2 * c + 1]) > 0.f ? acc : 0.f;
+        g[at] = gv;
+        s1[c] += (double)gv;
+        s2[c] += (double)(gv * ((zv - stat[2 * c]) * rsqrtf(stat[2 * c + 1] + 1e-3f)));
+      } else {
+        g[at] = zv > 0.f ? acc : 0.f;
+      }
+    }
+  }
+  if constexpr (BN) {
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+      const double a = wave_sum(s1[c]), b2 = wave_sum(s2[c]);
+      if ((tid & 63) == 0) { red[tid >> 6][2 * c] = a; red[tid >> 6][2 * c + 1] = b2; }
+    }
+    __syncthreads();
+    if (tid < 2 * C) part[(size_t)blockIdx.x * 2 * C + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+  }
+}
+
+// ---------------------------------------------------------------- backward 2: dz + the weight gradient
+constexpr int W_TR = 8, W_FLUSH = 16;
+template <int CI, int CO, int SRC, int TW, bool BN>
+__global__ __launch_bounds__(512) void f_bw(int n, int H, int W, FitSrc S, float *__restrict__ g,
+                                            const float *__restrict__ z, const float *__restrict__ stat,
+                                            const float *__restrict__ gamma, const double *__restrict__ sums, double count,
+                                            double *__restrict__ part) {
+  constexpr int LP = TW + 2, NA = 9 * CO + CO, NSUB = 8 / CI, NPX = W_TR * TW, NGRP = (NPX + 63) / 64;
+  __shared__ float in[CI][W_TR + 2][LP];
+  __shared__ float dzt[CO][W_TR][TW];
+  __shared__ double dacc[8][NA];
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const int ci = wv % CI, sub = wv / CI;
+  const int tx_n = W / TW, ty_n = (H + W_TR - 1) / W_TR, per_s = tx_n * ty_n;
+  const long ntiles = (long)n * per_s;
+  for (int e = tid; e < 8 * NA; e += 512) (&dacc[0][0])[e] = 0.0;
+  float acc[NA];
+#pragma unroll
+  for (int k = 0; k < NA; k++) acc[k] = 0.f;
+  auto flush = [&]() {
+#pragma unroll
+    for (int k = 0; k < NA; k++) {
+      const float v = wave_sum(acc[k]);
+      if (lane == 0) dacc[wv][k] += (double)v;
+      acc[k] = 0.f;
+    }
+  };
+  int since = 0;
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const size_t s = tile / per_s;
+    const int t = (int)(tile - (long)s * per_s), y0 = (t / tx_n) * W_TR, x0 = (t % tx_n) * TW;
+    __syncthreads();
+    for (int e = tid; e < CI * (W_TR + 2) * (TW + 2); e += 512) {
+      const int c = e / ((W_TR + 2) * (TW + 2)), rem = e - c * ((W_TR + 2) * (TW + 2));
+      const int yy = rem / (TW + 2), xx = rem - yy * (TW + 2);
+      in[c][yy][xx] = src_value<SRC, CI>(S, s, c, y0 - 1 + yy, x0 - 1 + xx, H, W);
+    }
+    for (int e = tid; e < CO * W_TR * TW; e += 512) {
+      const int co = e / (W_TR * TW), rem = e - co * (W_TR * TW), yy = rem / TW, xx = rem - yy * TW;
+      const int y = y0 + yy;
+      float d = 0.f;
+      if (y < H) {
+        const size_t at = ((s * CO + co) * (size_t)H + y) * W + x0 + xx;
+        d = g[at];
+        if constexpr (BN) {
+          const float rs = rsqrtf(stat[2 * co + 1] + 1e-3f);
+          const float m0 = (float)(sums[2 * co] / count), m1 = (float)(sums[2 * co + 1] / count);
+          d = gamma[co] * rs * (d - m0 - (z[at] - stat[2 * co]) * rs * m1);
+          g[at] = d;
+        }
+      }
+      dzt[co][yy][xx] = d;
+    }
+    __syncthreads();
+    for (int grp = sub; grp < NGRP; grp += NSUB) {
+      const int p = 64 * grp + lane;
+      const bool ok = p < NPX;
+      const int pp = ok ? p : 0, yy = pp / TW, xx = pp - yy * TW;
+      float dv[CO];
+#pragma unroll
+      for (int co = 0; co < CO; co++) dv[co] = ok ? dzt[co][yy][xx] : 0.f;
+#pragma unroll
+      for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) {
+          const float v = in[ci][yy + ky][xx + kx];
+#pragma unroll
+          for (int co = 0; co < CO; co++) acc[(ky * 3 + kx) * CO + co] = fmaf(v, dv[co], acc[(ky * 3 + kx) * CO + co]);
+        }
+#pragma unroll
+      for (int co = 0; co < CO; co++) acc[9 * CO + co] += dv[co];
+    }
+    if (++since == W_FLUSH) { flush(); since = 0; }
+  }
+  flush();
+  __syncthreads();
+  // part[block] = [tap][ci][co] weights, then [co] bias: the layout of the weight tensors (HWIO)
+  for (int k = tid; k < 9 * CI * CO + CO; k += 512) {
+    double v = 0.0;
+    if (k < 9 * CI * CO) {
+      const int co = k % CO, c = (k / CO) % CI, tap = k / (CO * CI);
+      for (int sb = 0; sb < NSUB; sb++) v += dacc[sb * CI + c][tap * CO + co];
+    } else {
+      const int co = k - 9 * CI * CO;
+      for (int sb = 0; sb < NSUB; sb++) v += dacc[sb * CI][9 * CO + co];
+    }
+    part[(size_t)blockIdx.x * (9 * CI * CO + CO) + k] = v;
+  }
+}
+
+__global__ void f_bw_finish(int nv, int nw, int nblocks, const double *part, float *dw, float *db, int c_n,
+                            const double *sums, float *dgamma, float *dbeta) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < nv) {
+    double acc = 0.0;
+    for (int i = 0; i < nblocks; i++) acc += part[(size_t)i * nv + k];
+    if (k < nw) dw[k] = (float)acc;
+    else db[k - nw] = (float)acc;
+  }
+  if (sums && k < c_n) { dbeta[k] = (float)sums[2 * k]; dgamma[k] = (float)sums[2 * k + 1]; }
+}
+
+FitSrc dev_src(const ofx_fit_src &s) { return FitSrc{s.p, s.act, s.h, s.w, s.legacy}; }
+int grid_for(long ntiles, int cap) { return (int)(ntiles < cap ? ntiles : cap); }
+
+}  // namespace
+
+size_t ofx_fit_part_doubles(void) { return (size_t)OFX_FIT_MAX_BLOCKS * (9 * 8 * 8 + 8); }
+
+int ofx_fit_conv_fwd(hipStream_t st, int n, int ci, int co, int H, int W, const ofx_fit_src &src, const float *w,
+                     const float *b, float *z, double *part, int *nblocks) {
+  const int TW = W >= 100 ? 100 : 50;
+  if (W % TW || H % F_TR) { ofx_set_error("ofx_dqn_fit: no forward tiling for %d x %d", H, W); return OFX_ERR_STATE; }
+  const long ntiles = (long)n * (H / F_TR) * (W / TW);
+  const int grid = grid_for(ntiles, OFX_FIT_MAX_BLOCKS);
+  *nblocks = grid;
+  const FitSrc S = dev_src(src);
+#define FWD(CI_, CO_, SRC_, TW_, ST_) \
+  if (ci == CI_ && co == CO_ && src.kind == SRC_ && TW == TW_ && (part != nullptr) == ST_) { \
+    hipLaunchKernelGGL((f_conv_fwd<CI_, CO_, SRC_, TW_, ST_>), dim3(grid), dim3(256), 0, st, n, H, W, S, w, b, z, part); \
+    OFX_HIP(hipGetLastError()); return OFX_OK; }
+  FWD(2, 8, OFX_FIT_SRC_BITS, 100, true)
+  FWD(8, 8, OFX_FIT_SRC_POOL, 100, true)
+  FWD(8, 8, OFX_FIT_SRC_POOL, 50, true)
+  FWD(1, 2, OFX_FIT_SRC_UPRAW, 50, true)
+  FWD(2, 4, OFX_FIT_SRC_UP, 100, true)
+  FWD(4, 8, OFX_FIT_SRC_UP, 100, true)
+  FWD(8, 1, OFX_FIT_SRC_UP, 100, false)
+#undef FWD
+  ofx_set_error("ofx_dqn_fit: no forward kernel for %d -> %d channels, source %d, %d x %d", ci, co, src.kind, H, W);
+  return OFX_ERR_STATE;
+}
+
+int ofx_fit_finish(hipStream_t st, int nblocks, int c_n, double count, const double *part, const float *gamma,
+                   const float *beta, double *sums, float *stat, float *act) {
+  hipLaunchKernelGGL(f_finish, dim3(1), dim3(32), 0, st, nblocks, c_n, count, part, gamma, beta, sums, stat, act);
+  OFX_HIP(hipGetLastError());
+  return OFX_OK;
+}
+
+int ofx_fit_pool_act(hipStream_t st, int n, int C, int H, int W, const float *z, const float *act, float *p) {
+  const size_t total = (size_t)n * C * (H / 2) * (W / 2);
+  hipLaunchKernelGGL(f_pool_act, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, n, C, H, W, z, act, p);
+  OFX_HIP(hipGetLastError());
+  return OFX_OK;
+}
+
+int ofx_fit_b1_pool(hipStream_t st, int n, int H, int W, int conv, const float *dzn, const float *wn, const float *z,
+                    const float *stat, const float *act, float *g, double *part, int *nblocks) {
+  const int Hp = H / 2, Wp = W / 2;
+  const long ntiles = (long)n * ((Hp + P_TR - 1) / P_TR) * ((Wp + P_TW - 1) / P_TW);
+  const int grid = grid_for(ntiles, OFX_FIT_MAX_BLOCKS);
+  *nblocks = grid;
+  if (conv) hipLaunchKernelGGL(f_b1_pool<true>, dim3(grid), dim3(256), 0, st, n, H, W, dzn, wn, z, stat, act, g, part);
+  else hipLaunchKernelGGL(f_b1_pool<false>, dim3(grid), dim3(256), 0, st, n, H, W, dzn, wn, z, stat, act, g, part);
+  OFX_HIP(hipGetLastError());
+  return OFX_OK;
+}
+
+int ofx_fit_b1_up(hipStream_t st, int n, int c, int con, int h, int w, int bn, const float *dzn, const float *wn,
+                  const float *zp, const float *stat, const float *act, int legacy, float *g, double *part, int *nblocks) {
+#define B1U(C_, CON_, TRL_, BN_) \
+  if (c == C_ && con == CON_ && (bn != 0) == BN_) { \
+    const long ntiles = (long)n * ((h + TRL_ - 1) / TRL_) * ((w + U_TW - 1) / U_TW); \
+    const int grid = grid_for(ntiles, OFX_FIT_MAX_BLOCKS); \
+    *nblocks = grid; \
+    hipLaunchKernelGGL((f_b1_up<C_, CON_, TRL_, BN_>), dim3(grid), dim3(256), 0, st, n, h, w, dzn, wn, zp, stat, act, legacy, g, part); \
+    OFX_HIP(hipGetLastError()); return OFX_OK; }
+  B1U(1, 2, 5, false)
+  B1U(2, 4, 5, true)
+  B1U(4, 8, 3, true)
+  B1U(8, 1, 5, true)
+#undef B1U
+  ofx_set_error("ofx_dqn_fit: no up-sampling backward kernel for %d -> %d channels", c, con);
+  return OFX_ERR_STATE;
+}
+
+int ofx_fit_bw(hipStream_t st, int n, int ci, int co, int H, int W, const ofx_fit_src &src, int bn, float *g,
+               const float *z, const float *stat, const float *gamma, const double *sums, double *part, float *dw,
+               float *db, float *dgamma, float *dbeta) {
+  const int TW = W >= 100 ? 100 : 50;
+  if (W % TW) { ofx_set_error("ofx_dqn_fit: no weight-gradient tiling for %d x %d", H, W); return OFX_ERR_STATE; }
+  const long ntiles = (long)n * ((H + W_TR - 1) / W_TR) * (W / TW);
+  const int grid = grid_for(ntiles, OFX_FIT_MAX_BLOCKS / 2);
+  const FitSrc S = dev_src(src);
+  const double count = (double)n * H * W;
+  bool done = false;
+#define BWK(CI_, CO_, SRC_, TW_, BN_) \
+  if (!done && ci == CI_ && co == CO_ && src.kind == SRC_ && TW == TW_ && (bn != 0) == BN_) { \
+    hipLaunchKernelGGL((f_bw<CI_, CO_, SRC_, TW_, BN_>), dim3(grid), dim3(512), 0, st, n, H, W, S, g, z, stat, gamma, sums, count, part); \
+    done = true; }
+  BWK(2, 8, OFX_FIT_SRC_BITS, 100, true)
+  BWK(8, 8, OFX_FIT_SRC_POOL, 100, true)
+  BWK(8, 8, OFX_FIT_SRC_POOL, 50, true)
+  BWK(1, 2, OFX_FIT_SRC_UPRAW, 50, true)
+  BWK(2, 4, OFX_FIT_SRC_UP, 100, true)
+  BWK(4, 8, OFX_FIT_SRC_UP, 100, true)
+  BWK(8, 1, OFX_FIT_SRC_UP, 100, false)
+#undef BWK
+  if (!done) {
+    ofx_set_error("ofx_dqn_fit: no weight-gradient kernel for %d -> %d channels, source %d", ci, co, src.kind);
+    return OFX_ERR_STATE;
+  }
+  OFX_HIP(hipGetLastError());
+  const int nw = 9 * ci * co, nv = nw + co;
+  hipLaunchKernelGGL(f_bw_finish, dim3((nv + 255) / 256), dim3(256), 0, st, nv, nw, grid, part, dw, db, bn ? co : 0,
+                     bn ? sums : nullptr, dgamma, dbeta);
+  OFX_HIP(hipGetLastError());
+  return OFX_OK;
+}

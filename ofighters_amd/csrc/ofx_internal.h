@@ -72,6 +72,7 @@ struct ofx_handle {
   int n_cus;                       // compute units of the device (grid of the persistent trunk kernel)
   bool opt_trunk_plain, opt_frames_ref, opt_bilinear_legacy;  // ofx_set_option
   int opt_policy_lowp;             // OFX_OPT_POLICY_BF16: 0 fp32, 1 bf16 operands, 2 fp16 operands (opt-in)
+  bool opt_fit_plain;              // OFX_OPT_FIT_PLAIN: the fit's layer-by-layer form (test reference)
 };
 #define OFX_RING_MAX 65536         /* numbered events of ofx_event_record */
 

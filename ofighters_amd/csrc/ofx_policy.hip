@@ -1447,6 +1447,7 @@ extern "C" int ofx_set_option(ofx_handle *h, int32_t option, int32_t value) {
       if (value < 0 || value > 2) { ofx_set_error("ofx_set_option: OFX_OPT_TRUNK_FUSE takes 0 (auto), 1 (always), 2 (never)"); return OFX_ERR_INVALID; }
       h->opt_trunk_fuse = value; return OFX_OK;
     case OFX_OPT_FRAMES_REF: h->opt_frames_ref = value != 0; return OFX_OK;
+    case OFX_OPT_FIT_PLAIN: h->opt_fit_plain = value != 0; return OFX_OK;
     case OFX_OPT_POLICY_BF16:
       if (value < 0 || value > 2) { ofx_set_error("ofx_set_option: OFX_OPT_POLICY_BF16 takes 0 (fp32), 1 (bf16 operands), 2 (fp16 operands)"); return OFX_ERR_INVALID; }
       h->opt_policy_lowp = value; return OFX_OK;

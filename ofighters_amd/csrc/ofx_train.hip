@@ -14,6 +14,7 @@
 //     next_state as input, :280-283, are stated in include/ofx.h, not reproduced);
 //   * Adam: beta1 0.9, beta2 0.999, eps 1e-7, bias-corrected step size.
 #include "ofx_internal.h"
+#include "ofx_fit.h"
 #include <string.h>
 
 #define TPS 400
@@ -549,12 +550,157 @@ static int refuse_pads(ofx_handle *h, int n, const ofx_transition *rows, const c
   return OFX_OK;
 }
 
+// The lean form of one fit step (default; ofx_fit.hip): the same graph, loss and update as dqn_fit_impl below with only
+// z of every convolution in HBM.  The dense layers, the loss and Adam are the plain form's kernels.
+static int dqn_fit_lean(ofx_handle *h, float *weights, float *adam_m, float *adam_v, int32_t step, float lr, int32_t n,
+                        const ofx_transition *rows, const void *bits_prev, const float *y_act, const float *y_ptr,
+                        const float *t1, const float *t2, float *grad_out, float *loss_host) {
+  const bool dense = t1 != nullptr;
+  OFX_HIP(hipSetDevice(h->cfg.device));
+  hipStream_t st = h->stream;
+  ofx_policy_desc L;
+  int rc = ofx_policy_layout(h, &L);
+  if (rc) return rc;
+  if ((rc = refuse_pads(h, n, rows, "ofx_dqn_fit"))) return rc;
+  const size_t N = (size_t)n;
+  const int legacy = h->opt_bilinear_legacy;
+  static const int tS[4] = {400, 200, 100, 50}, uS[3] = {50, 100, 200};
+  size_t need = 0;
+  auto sz = [&](size_t bytes) { need += (bytes + 255) & ~(size_t)255; };
+  for (int i = 0; i < 4; i++) { sz(4 * N * 8 * tS[i] * tS[i]); sz(4 * N * 8 * tS[i] * tS[i]); }        // z, g
+  for (int j = 0; j < 3; j++) { sz(4 * N * kUO[j] * uS[j] * uS[j]); sz(4 * N * kUO[j] * uS[j] * uS[j]); }
+  sz(4 * N * 160000); sz(4 * N * 160000);                                                                  // o2, do2
+  sz(4 * N * 5000); sz(4 * N * 5008); sz(4 * N * 100); sz(4 * N * 50); sz(4 * N * 2); sz(4 * N * 625);      // p3 f d1 d2 o1 u0
+  sz(4 * N * 625); sz(4 * N * 2); sz(4 * N * 100); sz(4 * N * 50); sz(4 * N * 5008); sz(4 * N * 5000);      // gu0 do1 dd1 dd2 df dp3
+  sz(4 * (size_t)L.n_floats); sz(4 * 64); sz(4 * (2 * N + 4096)); sz(8 * ofx_fit_part_doubles()); sz(8 * 32);
+  for (int k = 0; k < 7; k++) { sz(4 * 16); sz(4 * 16); }
+  if ((rc = keep_workspace(h, &h->fitws, &h->fitws_bytes, need))) return rc;
+  Arena A{(char *)h->fitws, 0, need};
+  auto T = [&](int t) { return weights + L.offset[t]; };
+  float *grad = A.f(L.n_floats);
+  OFX_HIP(hipMemsetAsync(grad, 0, sizeof(float) * L.n_floats, st));
+  auto G = [&](int t) { return grad + L.offset[t]; };
+  float *loss = A.f(64);
+  OFX_HIP(hipMemsetAsync(loss, 0, 64 * sizeof(float), st));
+  float *lpart = A.f(2 * N + 4096);
+  double *part = A.d(ofx_fit_part_doubles()), *sums = A.d(32);
+  float *tz[4], *tg[4], *tstat[4], *tact[4], *uz[3], *ug[3], *ustat[3], *uact[3];
+  for (int i = 0; i < 4; i++) { tz[i] = A.f(N * 8 * tS[i] * tS[i]); tg[i] = A.f(N * 8 * tS[i] * tS[i]); tstat[i] = A.f(16); tact[i] = A.f(16); }
+  for (int j = 0; j < 3; j++) { uz[j] = A.f(N * kUO[j] * uS[j] * uS[j]); ug[j] = A.f(N * kUO[j] * uS[j] * uS[j]); ustat[j] = A.f(16); uact[j] = A.f(16); }
+  float *o2 = A.f(N * 160000), *do2 = A.f(N * 160000);
+  float *p3 = A.f(N * 5000), *f = A.f(N * 5008), *d1 = A.f(N * 100), *d2 = A.f(N * 50), *o1 = A.f(N * 2), *u0 = A.f(N * 625);
+  float *gu0 = A.f(N * 625), *do1 = A.f(N * 2), *dd1 = A.f(N * 100), *dd2 = A.f(N * 50), *df = A.f(N * 5008), *dp3 = A.f(N * 5000);
+  if (A.over) { ofx_set_error("ofx_dqn_fit: internal workspace sized too small"); return OFX_ERR_STATE; }
+  int nb = 0;
+  auto trunk_src = [&](int i) {  // input of trunk layer i
+    return i == 0 ? ofx_fit_src{OFX_FIT_SRC_BITS, bits_prev, nullptr, 400, 400, legacy}
+                  : ofx_fit_src{OFX_FIT_SRC_POOL, tz[i - 1], tact[i - 1], tS[i - 1], tS[i - 1], legacy};
+  };
+  auto head_src = [&](int j) {   // input of head-2 layer j (3 = the output convolution)
+    return j == 0 ? ofx_fit_src{OFX_FIT_SRC_UPRAW, u0, nullptr, 25, 25, legacy}
+                  : ofx_fit_src{OFX_FIT_SRC_UP, uz[j - 1], uact[j - 1], uS[j - 1], uS[j - 1], legacy};
+  };
+
+  // ---- forward (training mode) ----
+  for (int i = 0; i < 4; i++) {
+    const int s = tS[i];
+    if ((rc = ofx_fit_conv_fwd(st, n, kTI[i], 8, s, s, trunk_src(i), T(6 * i), T(6 * i + 1), tz[i], part, &nb))) return rc;
+    if ((rc = ofx_fit_finish(st, nb, 8, (double)N * s * s, part, T(6 * i + 2), T(6 * i + 3), nullptr, tstat[i], tact[i]))) return rc;
+  }
+  if ((rc = ofx_fit_pool_act(st, n, 8, 50, 50, tz[3], tact[3], p3))) return rc;
+  K(t_concat_fwd, N * 5008, n, rows, p3, f, dense ? 1 : 0);
+  if ((rc = ofx_launch_gemm(h, f, 5008, T(24), 100, T(25), d1, 100, n, 100, 5008, 1))) return rc;
+  if ((rc = ofx_launch_gemm(h, d1, 100, T(26), 50, T(27), d2, 50, n, 50, 100, 1))) return rc;
+  if ((rc = ofx_launch_gemm(h, d2, 50, T(28), 2, T(29), o1, 2, n, 2, 50, 0))) return rc;
+  if ((rc = ofx_launch_gemm(h, d1, 100, T(30), 625, T(31), u0, 625, n, 625, 100, 1))) return rc;
+  for (int j = 0; j < 3; j++) {
+    const int s = uS[j];
+    if ((rc = ofx_fit_conv_fwd(st, n, kUI[j], kUO[j], s, s, head_src(j), T(32 + 6 * j), T(33 + 6 * j), uz[j], part, &nb))) return rc;
+    if ((rc = ofx_fit_finish(st, nb, kUO[j], (double)N * s * s, part, T(34 + 6 * j), T(35 + 6 * j), nullptr, ustat[j], uact[j]))) return rc;
+  }
+  if ((rc = ofx_fit_conv_fwd(st, n, 8, 1, 400, 400, head_src(3), T(50), T(51), o2, nullptr, &nb))) return rc;
+
+  // ---- loss seeds ----
+  OFX_HIP(hipMemsetAsync(do1, 0, N * 2 * 4, st));
+  if (dense) {
+    const int nb1 = (int)((N * 2 + 255) / 256), nb2 = (int)(N * 160000 / 256 > 2048 ? 2048 : (N * 160000 + 255) / 256);
+    hipLaunchKernelGGL(t_loss_dense, dim3(nb1), dim3(256), 0, st, N * 2, 1.f / (2.f * n), o1, t1, do1, lpart);
+    hipLaunchKernelGGL(t_sum_ordered, dim3(1), dim3(64), 0, st, nb1, 1, lpart, loss);
+    hipLaunchKernelGGL(t_loss_dense, dim3(nb2), dim3(256), 0, st, N * 160000, 1.f / (160000.f * n), o2, t2, do2, lpart + 2048);
+    hipLaunchKernelGGL(t_sum_ordered, dim3(1), dim3(64), 0, st, nb2, 1, lpart + 2048, loss + 1);
+    OFX_HIP(hipGetLastError());
+  } else {
+    OFX_HIP(hipMemsetAsync(do2, 0, N * 160000 * 4, st));
+    K(t_loss_seed, N, n, rows, o1, o2, y_act, y_ptr, do1, do2, lpart);
+    hipLaunchKernelGGL(t_sum_ordered, dim3(1), dim3(64), 0, st, n, 2, lpart, loss);
+  }
+
+  // ---- backward: head 2 ----
+  if ((rc = ofx_fit_bw(st, n, 8, 1, 400, 400, head_src(3), 0, do2, nullptr, nullptr, nullptr, nullptr, part, G(50), G(51), nullptr, nullptr))) return rc;
+  const float *dzn = do2;
+  for (int j = 2; j >= 0; j--) {
+    const int s = uS[j];
+    if ((rc = ofx_fit_b1_up(st, n, kUO[j], kUO[j + 1], s, s, 1, dzn, T(32 + 6 * (j + 1)), uz[j], ustat[j], uact[j], legacy, ug[j], part, &nb))) return rc;
+    if ((rc = ofx_fit_finish(st, nb, kUO[j], 1.0, part, nullptr, nullptr, sums, nullptr, nullptr))) return rc;
+    if ((rc = ofx_fit_bw(st, n, kUI[j], kUO[j], s, s, head_src(j), 1, ug[j], uz[j], ustat[j], T(34 + 6 * j), sums, part,
+                         G(32 + 6 * j), G(33 + 6 * j), G(34 + 6 * j), G(35 + 6 * j)))) return rc;
+    dzn = ug[j];
+  }
+  if ((rc = ofx_fit_b1_up(st, n, 1, 2, 25, 25, 0, dzn, T(32), u0, nullptr, nullptr, legacy, gu0, part, &nb))) return rc;
+  // gu0 = d u0 [n][625], already behind u0's ReLU mask
+  K(t_dense_bwd_w, (size_t)101 * 625, n, 100, 625, d1, gu0, G(30), G(31));
+  K(t_dense_bwd_x, N * 100, n, 100, 625, gu0, T(30), dd1, 0);
+  // ---- backward: head 1 ----
+  K(t_dense_bwd_w, (size_t)51 * 2, n, 50, 2, d2, do1, G(28), G(29));
+  K(t_dense_bwd_x, N * 50, n, 50, 2, do1, T(28), dd2, 0);
+  K(t_relu_mask, N * 50, N * 50, d2, dd2);
+  K(t_dense_bwd_w, (size_t)101 * 50, n, 100, 50, d1, dd2, G(26), G(27));
+  K(t_dense_bwd_x, N * 100, n, 100, 50, dd2, T(26), dd1, 1);
+  // ---- dense1 + trunk ----
+  K(t_relu_mask, N * 100, N * 100, d1, dd1);
+  K(t_dense_bwd_w, (size_t)5009 * 100, n, 5008, 100, f, dd1, G(24), G(25));
+  K(t_dense_bwd_x, N * 5008, n, 5008, 100, dd1, T(24), df, 0);
+  K(t_concat_bwd, N * 5000, n, df, dp3);
+  dzn = dp3;
+  for (int i = 3; i >= 0; i--) {
+    const int s = tS[i];
+    if ((rc = ofx_fit_b1_pool(st, n, s, s, i < 3, dzn, i < 3 ? T(6 * (i + 1)) : nullptr, tz[i], tstat[i], tact[i], tg[i], part, &nb))) return rc;
+    if ((rc = ofx_fit_finish(st, nb, 8, 1.0, part, nullptr, nullptr, sums, nullptr, nullptr))) return rc;
+    if ((rc = ofx_fit_bw(st, n, kTI[i], 8, s, s, trunk_src(i), 1, tg[i], tz[i], tstat[i], T(6 * i + 2), sums, part,
+                         G(6 * i), G(6 * i + 1), G(6 * i + 2), G(6 * i + 3)))) return rc;
+    dzn = tg[i];
+  }
+  if (grad_out) OFX_HIP(hipMemcpyAsync(grad_out, grad, sizeof(float) * L.n_floats, hipMemcpyDeviceToDevice, st));
+
+  // ---- Adam + moving statistics ----
+  const float b1 = 0.9f, b2 = 0.999f;
+  const float lr_t = lr * sqrtf(1.f - powf(b2, (float)step)) / (1.f - powf(b1, (float)step));
+  for (int t = 0; t < L.n_tensors; t++) {
+    const bool conv_bn = t < 24 || (t >= 32 && t < 50);
+    const int k = conv_bn ? (t < 24 ? t % 6 : (t - 32) % 6) : -1;
+    if (k == 4 || k == 5) continue;  // moving mean / variance: not trained
+    K(t_adam, (size_t)L.count[t], (size_t)L.count[t], weights + L.offset[t], grad + L.offset[t], adam_m + L.offset[t],
+      adam_v + L.offset[t], lr_t, b1, b2, 1e-7f);
+  }
+  for (int i = 0; i < 4; i++) hipLaunchKernelGGL(t_moving, dim3(1), dim3(64), 0, st, 8, weights + L.offset[6 * i + 4], weights + L.offset[6 * i + 5], tstat[i]);
+  for (int j = 0; j < 3; j++) hipLaunchKernelGGL(t_moving, dim3(1), dim3(64), 0, st, kUO[j], weights + L.offset[32 + 6 * j + 4], weights + L.offset[32 + 6 * j + 5], ustat[j]);
+  OFX_HIP(hipGetLastError());
+  float lh[2] = {0.f, 0.f};
+  OFX_HIP(hipMemcpyAsync(lh, loss, sizeof(lh), hipMemcpyDeviceToHost, st));
+  OFX_HIP(hipStreamSynchronize(st));
+  if (loss_host) { loss_host[0] = lh[0]; loss_host[1] = lh[1]; }
+  if ((rc = ofx_policy_weights_updated(h, weights))) return rc;  // a pinned blob is prepared again
+  return OFX_OK;
+}
+
 // One fit step.  Two forms of the targets: the sparse one of ofx_dqn_fit (one error per head and sample: y_act / y_ptr,
 // inputs = `state`) and the dense one of ofx_dqn_fit_reference (t1 [n][2] / t2 [n][400][400] whole target tensors,
 // inputs = bits_in + the rows' next_state head).
 static int dqn_fit_impl(ofx_handle *h, float *weights, float *adam_m, float *adam_v, int32_t step, float lr, int32_t n,
                         const ofx_transition *rows, const void *bits_prev, const float *y_act, const float *y_ptr,
                         const float *t1, const float *t2, float *grad_out, float *loss_host) {
+  if (!h->opt_fit_plain)
+    return dqn_fit_lean(h, weights, adam_m, adam_v, step, lr, n, rows, bits_prev, y_act, y_ptr, t1, t2, grad_out, loss_host);
   const bool dense = t1 != nullptr;
   OFX_HIP(hipSetDevice(h->cfg.device));
   hipStream_t st = h->stream;

@@ -93,13 +93,17 @@ def _compare_gradients(shapes, rg, g, loose=()):
     assert all(r[3] for r in report), [r for r in report if not r[3]]
 
 
+@pytest.mark.parametrize("form", ["lean", "plain"])
 @pytest.mark.parametrize("legacy", [False, True])
-def test_dqn_fit_vs_torch_autograd(legacy):
-    """legacy: OFX_OPT_BILINEAR_LEGACY - the fit's up-sampling (forward and backward) follows the same switch."""
+def test_dqn_fit_vs_torch_autograd(legacy, form):
+    """legacy: OFX_OPT_BILINEAR_LEGACY - the fit's up-sampling (forward and backward) follows the same switch.
+    form: the lean fit (default: only z of every convolution kept, the rest recomputed in fused tiles, ofx_fit.hip) and the
+    plain layer-by-layer form (OFX_OPT_FIT_PLAIN) are both checked against the float64 graph."""
     from ofighters_amd import ArenaBatch, DeviceBuffer, _native as nat
     N, M, seed, batch, lr = 2, 4, 0x0F160001, 2, 1e-4
     b = ArenaBatch(N, M)
     b.set_option(nat.OPT_BILINEAR_LEGACY, int(legacy))
+    b.set_option(nat.OPT_FIT_PLAIN, int(form == "plain"))
     b.replay_create(16, 0)
     b.spawn_random(seed)
     w, shapes = pyoracle.policy_init(9, trained_like=True)
@@ -152,15 +156,17 @@ def test_dqn_fit_vs_torch_autograd(legacy):
     b.close()
 
 
-def test_dqn_fit_reference_quirks():
+@pytest.mark.parametrize("form", ["lean", "plain"])
+def test_dqn_fit_reference_quirks(form):
     """ofx_dqn_fit_reference = Trainer.replay as written (qlearnIA_V2.py:251-285): targets are float64 predictions of
     `state` (tests/policy_ref64.py) with target[iaction] and ptr_target[x][y] (row x, column y - the quirk) replaced by
     reward + gamma * max(prediction(next_state)) * (not done); the fit runs in training mode on NEXT_state's maps and
     head; dense mse on both outputs.  Checked against torch autograd in float64, like the textbook step above."""
-    from ofighters_amd import ArenaBatch, DeviceBuffer
+    from ofighters_amd import ArenaBatch, DeviceBuffer, _native as nat
     from tests import policy_ref64 as R
     N, M, seed, batch, lr, gamma = 2, 4, 0x0F160001, 2, 1e-4, 0.9
     b = ArenaBatch(N, M)
+    b.set_option(nat.OPT_FIT_PLAIN, int(form == "plain"))
     b.replay_create(16, 0)
     b.spawn_random(seed)
     w, shapes = pyoracle.policy_init(9, trained_like=True)
@@ -207,6 +213,68 @@ def test_dqn_fit_reference_quirks():
     # that fp32 and float64 decide differently - not in cancellation noise as r02 guessed: torch's own fp32 autograd on
     # the CPU lands at 1.7e-6 on this minibatch (its rounding leaves that activation on the float64 side).
     _compare_gradients(shapes, rg, g, loose=("updense1",))
+    b.close()
+
+
+def test_lean_fit_equals_plain_fit():
+    """The two forms of the fit (OFX_OPT_FIT_PLAIN) are the same function: on a minibatch of 24 rows - more tiles per layer
+    and several blocks per reduction than the float64 comparisons above afford - every gradient tensor, both losses and
+    the batch statistics (through the moved statistics) agree to fp32 summation order, in the textbook and in the
+    reference's dense form."""
+    from ofighters_amd import ArenaBatch, DeviceBuffer, _native as nat
+    N, M, seed, batch = 6, 4, 0x0F160077, 4
+    b = ArenaBatch(N, M)
+    b.replay_create(16, 0)
+    b.spawn_random(seed)
+    w, shapes = pyoracle.policy_init(5, trained_like=True)
+    mask = np.zeros((N, M), np.uint8)
+    mask[:, [0, 3]] = 1
+    mask_d = DeviceBuffer(mask.nbytes).upload(mask)
+    ia_d, ip_d = DeviceBuffer(4 * N * M), DeviceBuffer(8 * N * M)
+    for t in range(10):
+        b.bot_actions(["random"] * M, seed, tick=t)
+        b.policy_explore(1.0, seed, tick=t, collecting=True, ship_mask_ptr=mask_d.ptr, iaction_ptr=ia_d.ptr, ipointer_ptr=ip_d.ptr)
+        b.policy_actions(out_ptr=b._actions.ptr, ship_mask_ptr=mask_d.ptr, iaction_ptr=ia_d.ptr, ipointer_ptr=ip_d.ptr)
+        b.replay_capture(t, mask_d.ptr, ia_d.ptr, ip_d.ptr)
+        b.step(actions_ptr=b._actions.ptr)
+    slot, _ = b.replay_sample(7, 0, batch)
+    rows_d, bp_d, bn_d = b.replay_gather_device(slot, batch)
+    n = N * batch
+    assert (rows_d.download(b.TRANSITION_DTYPE, (n,))["ship"] >= 0).all()
+    rs = np.random.RandomState(3)
+    y = DeviceBuffer(4 * n).upload(rs.uniform(-1, 2, n).astype(np.float32))
+    y2 = DeviceBuffer(4 * n).upload(rs.uniform(-1, 2, n).astype(np.float32))
+    zeros = np.zeros_like(w)
+    w_d, m_d, v_d, g_d = (DeviceBuffer(w.nbytes) for _ in range(4))
+    out = {}
+    for kind in ("textbook", "reference"):
+        for form in ("lean", "plain"):
+            b.set_option(nat.OPT_FIT_PLAIN, int(form == "plain"))
+            w_d.upload(w); m_d.upload(zeros); v_d.upload(zeros)
+            if kind == "textbook":
+                l = b.dqn_fit(w_d, m_d, v_d, 1, 1e-4, n, rows_d.ptr, bp_d.ptr, y.ptr, y2.ptr, g_d)
+            else:
+                l = b.dqn_fit_reference(w_d, m_d, v_d, 1, 1e-4, n, rows_d.ptr, bp_d.ptr, bn_d.ptr, 0.9, g_d)
+            out[kind, form] = (l, g_d.download(np.float32, w.shape).astype(np.float64), w_d.download(np.float32, w.shape))
+    for kind in ("textbook", "reference"):
+        (la, ga, wa), (lb, gb, wb) = out[kind, "lean"], out[kind, "plain"]
+        assert np.isfinite(ga).all() and np.abs(ga).max() > 0
+        assert abs(la[0] - lb[0]) <= 1e-5 * max(1.0, abs(lb[0])) and abs(la[1] - lb[1]) <= 1e-5 * abs(lb[1]) + 1e-12, (kind, la, lb)
+        bad = []
+        for name, (o, shp) in shapes.items():
+            c = int(np.prod(shp))
+            layer, what = name.split(".")
+            if what in ("mean", "var"):      # moved by the batch statistics of the fit
+                np.testing.assert_allclose(wa[o:o + c], wb[o:o + c], rtol=1e-5, atol=1e-7, err_msg=kind + " " + name)
+                continue
+            ko, kshp = shapes[layer + ".kernel"]
+            kscale = float(np.abs(gb[ko:ko + int(np.prod(kshp))]).max())
+            scale, err = float(np.abs(gb[o:o + c]).max()), float(np.abs(ga[o:o + c] - gb[o:o + c]).max())
+            # the two forms round BatchNorm's activation differently (z * scale + shift against gamma * xhat + beta): a
+            # ReLU within rounding of zero may be gated differently - the same allowance as against float64
+            if err > 1e-4 * scale + 5e-5 * kscale:
+                bad.append((name, scale, err))
+        assert not bad, (kind, bad)
     b.close()
 
 
