@@ -69,6 +69,54 @@ __device__ __forceinline__ float src_value(const FitSrc &S, size_t s, int c, int
   }
 }
 
+// The input tile of a convolution: in[CI][TR + 2][LP] <- source values of rows y0 - 1 .. y0 + TR, columns x0 - 1 ..
+// x0 + TW (zero outside the plane).  Up-sampling sources first stage the low-res activation they interpolate
+// (lo[CI][TR / 2 + 3][TW / 2 + 3], coordinates clamped like the taps): every low-res value is read and passed through
+// BatchNorm + ReLU once instead of up to 16 times.  Barriers inside: call from all NT threads.
+template <int SRC> constexpr bool src_is_up = SRC == OFX_FIT_SRC_UP || SRC == OFX_FIT_SRC_UPRAW;
+template <int SRC, int CI, int TR, int TW> constexpr int lo_floats = src_is_up<SRC> ? CI * (TR / 2 + 3) * (TW / 2 + 3) : 1;
+template <int SRC, int CI, int TR, int TW, int LP, int NT>
+__device__ __forceinline__ void fill_input(float (*in)[TR + 2][LP], float *lo, const FitSrc &S, size_t s, int y0, int x0,
+                                           int H, int W, int tid) {
+  if constexpr (src_is_up<SRC>) {
+    static_assert(TR % 2 == 0 && TW % 2 == 0, "tile origin must be even");
+    constexpr int LR = TR / 2 + 3, LC = TW / 2 + 3;
+    const int ly0 = y0 / 2 - 1, lx0 = x0 / 2 - 1;
+    for (int e = tid; e < CI * LR * LC; e += NT) {
+      const int c = e / (LR * LC), rem = e - c * (LR * LC), i = rem / LC, j = rem - i * LC;
+      const int yy = min(max(ly0 + i, 0), S.h - 1), xx = min(max(lx0 + j, 0), S.w - 1);
+      float v = reinterpret_cast<const float *>(S.p)[((s * CI + c) * (size_t)S.h + yy) * S.w + xx];
+      if constexpr (SRC == OFX_FIT_SRC_UP) v = bn_act(v, S.act[2 * c], S.act[2 * c + 1]);
+      lo[e] = v;
+    }
+    __syncthreads();
+    for (int e = tid; e < CI * (TR + 2) * (TW + 2); e += NT) {
+      const int c = e / ((TR + 2) * (TW + 2)), rem = e - c * ((TR + 2) * (TW + 2));
+      const int yy = rem / (TW + 2), xx = rem - yy * (TW + 2);
+      const int y = y0 - 1 + yy, x = x0 - 1 + xx;
+      float v = 0.f;
+      if (y >= 0 && y < H && x >= 0 && x < W) {
+        int a0, a1, b0, b1;
+        float wy, wx;
+        fit_up_taps(y, S.h, a0, a1, wy, S.legacy);
+        fit_up_taps(x, S.w, b0, b1, wx, S.legacy);
+        const float *q = lo + c * (LR * LC);
+        a0 -= ly0; a1 -= ly0; b0 -= lx0; b1 -= lx0;
+        const float top = q[a0 * LC + b0] * (1.f - wx) + q[a0 * LC + b1] * wx;
+        const float bot = q[a1 * LC + b0] * (1.f - wx) + q[a1 * LC + b1] * wx;
+        v = top * (1.f - wy) + bot * wy;
+      }
+      in[c][yy][xx] = v;
+    }
+  } else {
+    for (int e = tid; e < CI * (TR + 2) * (TW + 2); e += NT) {
+      const int c = e / ((TR + 2) * (TW + 2)), rem = e - c * ((TR + 2) * (TW + 2));
+      const int yy = rem / (TW + 2), xx = rem - yy * (TW + 2);
+      in[c][yy][xx] = src_value<SRC, CI>(S, s, c, y0 - 1 + yy, x0 - 1 + xx, H, W);
+    }
+  }
+}
+
 // sum of v over the 64 lanes (every lane gets it)
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -112,6 +160,7 @@ __global__ __launch_bounds__(256, 3) void f_conv_fwd(int n, int H, int W, FitSrc
   static_assert(F_TR * TPR <= 256, "tile does not fit the block");
   __shared__ __align__(16) float in[CI][F_TR + 2][LP];
   __shared__ __align__(16) float wl[9 * CI * CO];
+  __shared__ float lo[lo_floats<SRC, CI, F_TR, TW>];
   __shared__ double red[4][2 * CO];
   const int tid = threadIdx.x, r = tid / TPR, q = tid - r * TPR;
   const bool active = r < F_TR;
@@ -125,11 +174,7 @@ __global__ __launch_bounds__(256, 3) void f_conv_fwd(int n, int H, int W, FitSrc
     const size_t s = tile / per_s;
     const int t = (int)(tile - (long)s * per_s), y0 = (t / tx_n) * F_TR, x0 = (t % tx_n) * TW;
     __syncthreads();
-    for (int e = tid; e < CI * (F_TR + 2) * (TW + 2); e += 256) {
-      const int ci = e / ((F_TR + 2) * (TW + 2)), rem = e - ci * ((F_TR + 2) * (TW + 2));
-      const int yy = rem / (TW + 2), xx = rem - yy * (TW + 2);
-      in[ci][yy][xx] = src_value<SRC, CI>(S, s, ci, y0 - 1 + yy, x0 - 1 + xx, H, W);
-    }
+    fill_input<SRC, CI, F_TR, TW, LP, 256>(in, lo, S, s, y0, x0, H, W, tid);
     __syncthreads();
     if (!active) continue;
     float acc[4][CO];
@@ -189,18 +234,27 @@ __global__ __launch_bounds__(256, 3) void f_conv_fwd(int n, int H, int W, FitSrc
 
 // part[block][2 C] -> sums[2 C] in block order; with gamma: also the batch statistics {mean, biased variance} and the
 // activation's {scale, shift}
-__global__ void f_finish(int nblocks, int c_n, double count, const double *part, const float *gamma, const float *beta,
-                         double *sums, float *stat, float *act) {
-  const int k = threadIdx.x;
-  if (k >= 2 * c_n) return;
+// (two levels, both in a fixed order: 16 threads per value take the rows i = j, j + 16, ..., then the 16 shares are added
+// in j order - one thread walking 2048 rows took 0.5 ms per layer and pass)
+__global__ __launch_bounds__(256) void f_finish(int nblocks, int c_n, double count, const double *part, const float *gamma,
+                                                const float *beta, double *sums, float *stat, float *act) {
+  __shared__ double share[16][17], sh[16];
+  const int k = threadIdx.x & 15, j = threadIdx.x >> 4, nv = 2 * c_n;
   double acc = 0.0;
-  for (int i = 0; i < nblocks; i++) acc += part[(size_t)i * 2 * c_n + k];
-  if (sums) sums[k] = acc;
-  if (!stat) return;
-  __shared__ double sh[32];
-  sh[k] = acc;
+  if (k < nv)
+    for (int i = j; i < nblocks; i += 16) acc += part[(size_t)i * nv + k];
+  share[k][j] = acc;
   __syncthreads();
-  if (k < c_n) {
+  if (threadIdx.x < 16) {
+    double t = 0.0;
+    for (int q = 0; q < 16; q++) t += share[threadIdx.x][q];
+    sh[threadIdx.x] = t;
+    if (sums && threadIdx.x < nv) sums[threadIdx.x] = t;
+  }
+  __syncthreads();
+  if (!stat) return;
+  if (threadIdx.x < c_n) {
+    const int k = threadIdx.x;
     const double m = sh[2 * k] / count, v = sh[2 * k + 1] / count - m * m;
     const float mean = (float)m, var = (float)(v > 0.0 ? v : 0.0);
     stat[2 * k] = mean;
@@ -442,6 +496,7 @@ __global__ __launch_bounds__(512) void f_bw(int n, int H, int W, FitSrc S, float
                                             double *__restrict__ part) {
   constexpr int LP = TW + 2, NA = 9 * CO + CO, NSUB = 8 / CI, NPX = W_TR * TW, NGRP = (NPX + 63) / 64;
   __shared__ float in[CI][W_TR + 2][LP];
+  __shared__ float lo[lo_floats<SRC, CI, W_TR, TW>];
   __shared__ float dzt[CO][W_TR][TW];
   __shared__ double dacc[8][NA];
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
@@ -465,11 +520,7 @@ __global__ __launch_bounds__(512) void f_bw(int n, int H, int W, FitSrc S, float
     const size_t s = tile / per_s;
     const int t = (int)(tile - (long)s * per_s), y0 = (t / tx_n) * W_TR, x0 = (t % tx_n) * TW;
     __syncthreads();
-    for (int e = tid; e < CI * (W_TR + 2) * (TW + 2); e += 512) {
-      const int c = e / ((W_TR + 2) * (TW + 2)), rem = e - c * ((W_TR + 2) * (TW + 2));
-      const int yy = rem / (TW + 2), xx = rem - yy * (TW + 2);
-      in[c][yy][xx] = src_value<SRC, CI>(S, s, c, y0 - 1 + yy, x0 - 1 + xx, H, W);
-    }
+    fill_input<SRC, CI, W_TR, TW, LP, 512>(in, lo, S, s, y0, x0, H, W, tid);
     for (int e = tid; e < CO * W_TR * TW; e += 512) {
       const int co = e / (W_TR * TW), rem = e - co * (W_TR * TW), yy = rem / TW, xx = rem - yy * TW;
       const int y = y0 + yy;
@@ -481,7 +532,7 @@ __global__ __launch_bounds__(512) void f_bw(int n, int H, int W, FitSrc S, float
           const float rs = rsqrtf(stat[2 * co + 1] + 1e-3f);
           const float m0 = (float)(sums[2 * co] / count), m1 = (float)(sums[2 * co + 1] / count);
           d = gamma[co] * rs * (d - m0 - (z[at] - stat[2 * co]) * rs * m1);
-          g[at] = d;
+          if constexpr (SRC != OFX_FIT_SRC_BITS) g[at] = d;   // nothing reads the first layer's dz
         }
       }
       dzt[co][yy][xx] = d;
@@ -523,16 +574,24 @@ __global__ __launch_bounds__(512) void f_bw(int n, int H, int W, FitSrc S, float
   }
 }
 
-__global__ void f_bw_finish(int nv, int nw, int nblocks, const double *part, float *dw, float *db, int c_n,
-                            const double *sums, float *dgamma, float *dbeta) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < nv) {
-    double acc = 0.0;
-    for (int i = 0; i < nblocks; i++) acc += part[(size_t)i * nv + k];
-    if (k < nw) dw[k] = (float)acc;
-    else db[k - nw] = (float)acc;
+// block = 16 values x 16 row shares, combined in share order (fixed)
+__global__ __launch_bounds__(256) void f_bw_finish(int nv, int nw, int nblocks, const double *part, float *dw, float *db,
+                                                   int c_n, const double *sums, float *dgamma, float *dbeta) {
+  __shared__ double share[16][17];
+  const int k = blockIdx.x * 16 + (threadIdx.x & 15), j = threadIdx.x >> 4;
+  double acc = 0.0;
+  if (k < nv)
+    for (int i = j; i < nblocks; i += 16) acc += part[(size_t)i * nv + k];
+  share[threadIdx.x & 15][j] = acc;
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    const int kk = blockIdx.x * 16 + threadIdx.x;
+    double t = 0.0;
+    for (int q = 0; q < 16; q++) t += share[threadIdx.x][q];
+    if (kk < nw) dw[kk] = (float)t;
+    else if (kk < nv) db[kk - nw] = (float)t;
+    if (sums && kk < c_n) { dbeta[kk] = (float)sums[2 * kk]; dgamma[kk] = (float)sums[2 * kk + 1]; }
   }
-  if (sums && k < c_n) { dbeta[k] = (float)sums[2 * k]; dgamma[k] = (float)sums[2 * k + 1]; }
 }
 
 FitSrc dev_src(const ofx_fit_src &s) { return FitSrc{s.p, s.act, s.h, s.w, s.legacy}; }
@@ -568,7 +627,7 @@ int ofx_fit_conv_fwd(hipStream_t st, int n, int ci, int co, int H, int W, const 
 
 int ofx_fit_finish(hipStream_t st, int nblocks, int c_n, double count, const double *part, const float *gamma,
                    const float *beta, double *sums, float *stat, float *act) {
-  hipLaunchKernelGGL(f_finish, dim3(1), dim3(32), 0, st, nblocks, c_n, count, part, gamma, beta, sums, stat, act);
+  hipLaunchKernelGGL(f_finish, dim3(1), dim3(256), 0, st, nblocks, c_n, count, part, gamma, beta, sums, stat, act);
   OFX_HIP(hipGetLastError());
   return OFX_OK;
 }
@@ -638,7 +697,7 @@ int ofx_fit_bw(hipStream_t st, int n, int ci, int co, int H, int W, const ofx_fi
   }
   OFX_HIP(hipGetLastError());
   const int nw = 9 * ci * co, nv = nw + co;
-  hipLaunchKernelGGL(f_bw_finish, dim3((nv + 255) / 256), dim3(256), 0, st, nv, nw, grid, part, dw, db, bn ? co : 0,
+  hipLaunchKernelGGL(f_bw_finish, dim3((nv + 15) / 16), dim3(256), 0, st, nv, nw, grid, part, dw, db, bn ? co : 0,
                      bn ? sums : nullptr, dgamma, dbeta);
   OFX_HIP(hipGetLastError());
   return OFX_OK;
