@@ -69,50 +69,100 @@ __device__ __forceinline__ float src_value(const FitSrc &S, size_t s, int c, int
   }
 }
 
+// Fill loops run in batches of FILL_U elements per thread, all global loads of a batch requested before the first value
+// is used: written as a plain `load, compute, store to LDS` loop the compiler waits for every load in turn, and with two
+// or three workgroups per CU nothing hides ~2 us of HBM latency per iteration (the first lean build spent 38 000 cycles
+// on a tile that holds 4 000 cycles of instructions).
+constexpr int FILL_U = 8;
+
 // The input tile of a convolution: in[CI][TR + 2][LP] <- source values of rows y0 - 1 .. y0 + TR, columns x0 - 1 ..
 // x0 + TW (zero outside the plane).  Up-sampling sources first stage the low-res activation they interpolate
 // (lo[CI][TR / 2 + 3][TW / 2 + 3], coordinates clamped like the taps): every low-res value is read and passed through
 // BatchNorm + ReLU once instead of up to 16 times.  Barriers inside: call from all NT threads.
 template <int SRC> constexpr bool src_is_up = SRC == OFX_FIT_SRC_UP || SRC == OFX_FIT_SRC_UPRAW;
 template <int SRC, int CI, int TR, int TW> constexpr int lo_floats = src_is_up<SRC> ? CI * (TR / 2 + 3) * (TW / 2 + 3) : 1;
-template <int SRC, int CI, int TR, int TW, int LP, int NT>
+// STAGE = false: every tile value straight from global memory (src_value), in a plain loop - what measured faster in
+// f_bw, whose 512-thread workgroups lose their second workgroup per CU to the registers of the batched form.
+template <int SRC, int CI, int TR, int TW, int LP, int NT, int FU = 8, bool STAGE = true>
 __device__ __forceinline__ void fill_input(float (*in)[TR + 2][LP], float *lo, const FitSrc &S, size_t s, int y0, int x0,
                                            int H, int W, int tid) {
-  if constexpr (src_is_up<SRC>) {
-    static_assert(TR % 2 == 0 && TW % 2 == 0, "tile origin must be even");
-    constexpr int LR = TR / 2 + 3, LC = TW / 2 + 3;
-    const int ly0 = y0 / 2 - 1, lx0 = x0 / 2 - 1;
-    for (int e = tid; e < CI * LR * LC; e += NT) {
-      const int c = e / (LR * LC), rem = e - c * (LR * LC), i = rem / LC, j = rem - i * LC;
-      const int yy = min(max(ly0 + i, 0), S.h - 1), xx = min(max(lx0 + j, 0), S.w - 1);
-      float v = reinterpret_cast<const float *>(S.p)[((s * CI + c) * (size_t)S.h + yy) * S.w + xx];
-      if constexpr (SRC == OFX_FIT_SRC_UP) v = bn_act(v, S.act[2 * c], S.act[2 * c + 1]);
-      lo[e] = v;
-    }
-    __syncthreads();
-    for (int e = tid; e < CI * (TR + 2) * (TW + 2); e += NT) {
-      const int c = e / ((TR + 2) * (TW + 2)), rem = e - c * ((TR + 2) * (TW + 2));
-      const int yy = rem / (TW + 2), xx = rem - yy * (TW + 2);
-      const int y = y0 - 1 + yy, x = x0 - 1 + xx;
-      float v = 0.f;
-      if (y >= 0 && y < H && x >= 0 && x < W) {
-        int a0, a1, b0, b1;
-        float wy, wx;
-        fit_up_taps(y, S.h, a0, a1, wy, S.legacy);
-        fit_up_taps(x, S.w, b0, b1, wx, S.legacy);
-        const float *q = lo + c * (LR * LC);
-        a0 -= ly0; a1 -= ly0; b0 -= lx0; b1 -= lx0;
-        const float top = q[a0 * LC + b0] * (1.f - wx) + q[a0 * LC + b1] * wx;
-        const float bot = q[a1 * LC + b0] * (1.f - wx) + q[a1 * LC + b1] * wx;
-        v = top * (1.f - wy) + bot * wy;
-      }
-      in[c][yy][xx] = v;
-    }
-  } else {
+  if constexpr (!STAGE) {
     for (int e = tid; e < CI * (TR + 2) * (TW + 2); e += NT) {
       const int c = e / ((TR + 2) * (TW + 2)), rem = e - c * ((TR + 2) * (TW + 2));
       const int yy = rem / (TW + 2), xx = rem - yy * (TW + 2);
       in[c][yy][xx] = src_value<SRC, CI>(S, s, c, y0 - 1 + yy, x0 - 1 + xx, H, W);
+    }
+  } else if constexpr (src_is_up<SRC>) {
+    static_assert(TR % 2 == 0 && TW % 2 == 0, "tile origin must be even");
+    constexpr int LR = TR / 2 + 3, LC = TW / 2 + 3;
+    const int ly0 = y0 / 2 - 1, lx0 = x0 / 2 - 1;
+    for (int e0 = tid; e0 < CI * LR * LC; e0 += NT * FU) {
+      float v[FU];
+#pragma unroll
+      for (int u = 0; u < FU; u++) {
+        const int e = min(e0 + u * NT, CI * LR * LC - 1);
+        const int c = e / (LR * LC), rem = e - c * (LR * LC), i = rem / LC, j = rem - i * LC;
+        const int yy = min(max(ly0 + i, 0), S.h - 1), xx = min(max(lx0 + j, 0), S.w - 1);
+        v[u] = reinterpret_cast<const float *>(S.p)[((s * CI + c) * (size_t)S.h + yy) * S.w + xx];
+      }
+#pragma unroll
+      for (int u = 0; u < FU; u++) {
+        const int e = e0 + u * NT;
+        if (e < CI * LR * LC) {
+          if constexpr (SRC == OFX_FIT_SRC_UP) { const int c = e / (LR * LC); v[u] = bn_act(v[u], S.act[2 * c], S.act[2 * c + 1]); }
+          lo[e] = v[u];
+        }
+      }
+    }
+    __syncthreads();
+    // one thread per low-res cell (k, m): its 2 x 2 up-res block from the cell's 3 x 3 neighbourhood.  Along an axis
+    // up(2 k + a) = wm[a] lo[max(k - 1, 0)] + w0[a] lo[k] + wp[a] lo[min(k + 1, n - 1)] - fit_up_taps written per cell:
+    // half-pixel (.25, .75, 0) / (0, .75, .25), legacy (0, 1, 0) / (0, .5, .5).
+    constexpr int CR = TR / 2 + 2, CC = TW / 2 + 2;
+    const float wm[2] = {S.legacy ? 0.f : 0.25f, 0.f}, w0[2] = {S.legacy ? 1.f : 0.75f, S.legacy ? 0.5f : 0.75f},
+                wp[2] = {0.f, S.legacy ? 0.5f : 0.25f};
+    for (int e = tid; e < CI * CR * CC; e += NT) {
+      const int c = e / (CR * CC), rem = e - c * (CR * CC), i = rem / CC, j = rem - i * CC;
+      const int k = ly0 + i, m = lx0 + j;                       // the cell; lo row index of low-res row r is r - ly0
+      const int ri[3] = {min(max(k - 1, 0), S.h - 1) - ly0, min(max(k, 0), S.h - 1) - ly0, min(max(k + 1, 0), S.h - 1) - ly0};
+      const int cj[3] = {min(max(m - 1, 0), S.w - 1) - lx0, min(max(m, 0), S.w - 1) - lx0, min(max(m + 1, 0), S.w - 1) - lx0};
+      const float *q = lo + c * (LR * LC);
+      float hb[3][2];
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        const float vm = q[max(ri[r], 0) * LC + max(cj[0], 0)], v0 = q[max(ri[r], 0) * LC + cj[1]], vp = q[max(ri[r], 0) * LC + cj[2]];
+#pragma unroll
+        for (int b = 0; b < 2; b++) hb[r][b] = wm[b] * vm + w0[b] * v0 + wp[b] * vp;
+      }
+#pragma unroll
+      for (int a = 0; a < 2; a++) {
+        const int y = 2 * k + a, yy = y - (y0 - 1);
+        if (yy < 0 || yy >= TR + 2) continue;
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+          const int x = 2 * m + b, xx = x - (x0 - 1);
+          if (xx < 0 || xx >= TW + 2) continue;
+          const float v = wm[a] * hb[0][b] + w0[a] * hb[1][b] + wp[a] * hb[2][b];
+          in[c][yy][xx] = (y >= 0 && y < H && x >= 0 && x < W) ? v : 0.f;
+        }
+      }
+    }
+  } else {
+    constexpr int NE = CI * (TR + 2) * (TW + 2);
+    for (int e0 = tid; e0 < NE; e0 += NT * FU) {
+      float v[FU];
+#pragma unroll
+      for (int u = 0; u < FU; u++) {
+        const int e = e0 + u * NT;
+        const int c = e / ((TR + 2) * (TW + 2)), rem = e - c * ((TR + 2) * (TW + 2));
+        const int yy = rem / (TW + 2), xx = rem - yy * (TW + 2);
+        v[u] = e < NE ? src_value<SRC, CI>(S, s, c, y0 - 1 + yy, x0 - 1 + xx, H, W) : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < FU; u++) {
+        const int e = e0 + u * NT;
+        if (e < NE) (&in[0][0][0])[(e / (TW + 2)) * LP + e % (TW + 2)] = v[u];
+      }
     }
   }
 }
@@ -310,11 +360,22 @@ __global__ __launch_bounds__(256, 3) void f_b1_pool(int n, int H, int W, const f
     const int t = (int)(tile - (long)s * per_s), y0 = (t / tx_n) * P_TR, x0 = (t % tx_n) * P_TW;
     if constexpr (CONV) {
       __syncthreads();
-      for (int e = tid; e < C * (P_TR + 2) * (P_TW + 2); e += 256) {
-        const int co = e / ((P_TR + 2) * (P_TW + 2)), rem = e - co * ((P_TR + 2) * (P_TW + 2));
-        const int yy = rem / (P_TW + 2), xx = rem - yy * (P_TW + 2);
-        const int y = y0 - 1 + yy, x = x0 - 1 + xx;
-        dzt[co][yy][xx] = (y >= 0 && y < Hp && x >= 0 && x < Wp) ? dzn[((s * C + co) * (size_t)Hp + y) * Wp + x] : 0.f;
+      constexpr int NE = C * (P_TR + 2) * (P_TW + 2);
+      for (int e0 = tid; e0 < NE; e0 += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int e = e0 + u * 256;
+          const int co = e / ((P_TR + 2) * (P_TW + 2)), rem = e - co * ((P_TR + 2) * (P_TW + 2));
+          const int yy = rem / (P_TW + 2), xx = rem - yy * (P_TW + 2);
+          const int y = y0 - 1 + yy, x = x0 - 1 + xx;
+          v[u] = (e < NE && y >= 0 && y < Hp && x >= 0 && x < Wp) ? dzn[((s * C + co) * (size_t)Hp + y) * Wp + x] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < FILL_U; u++) {
+          const int e = e0 + u * 256;
+          if (e < NE) (&dzt[0][0][0])[(e / (P_TW + 2)) * LP + e % (P_TW + 2)] = v[u];
+        }
       }
       __syncthreads();
     }
@@ -415,10 +476,20 @@ __global__ __launch_bounds__(256, 2) void f_b1_up(int n, int h, int w, const flo
     const size_t s = tile / per_s;
     const int t = (int)(tile - (long)s * per_s), y0 = (t / tx_n) * TRL, x0 = (t % tx_n) * U_TW;
     __syncthreads();
-    for (int e = tid; e < CON * DR * DC; e += 256) {
-      const int co = e / (DR * DC), rem = e - co * (DR * DC), i = rem / DC, j = rem - i * DC;
-      const int Y = 2 * y0 - 3 + i, X = 2 * x0 - 3 + j;
-      dzt[co][i][j] = (Y >= 0 && Y < H2 && X >= 0 && X < W2) ? dzn[((s * CON + co) * (size_t)H2 + Y) * W2 + X] : 0.f;
+    for (int e0 = tid; e0 < CON * DR * DC; e0 += 256 * 8) {
+      float v[FILL_U];
+#pragma unroll
+      for (int u = 0; u < FILL_U; u++) {
+        const int e = e0 + u * 256;
+        const int co = e / (DR * DC), rem = e - co * (DR * DC), i = rem / DC, j = rem - i * DC;
+        const int Y = 2 * y0 - 3 + i, X = 2 * x0 - 3 + j;
+        v[u] = (e < CON * DR * DC && Y >= 0 && Y < H2 && X >= 0 && X < W2) ? dzn[((s * CON + co) * (size_t)H2 + Y) * W2 + X] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < FILL_U; u++) {
+        const int e = e0 + u * 256;
+        if (e < CON * DR * DC) (&dzt[0][0][0])[(e / DC) * DP + e % DC] = v[u];
+      }
     }
     __syncthreads();
     for (int e = tid; e < UR * UC; e += 256) {
@@ -496,7 +567,7 @@ __global__ __launch_bounds__(512) void f_bw(int n, int H, int W, FitSrc S, float
                                             double *__restrict__ part) {
   constexpr int LP = TW + 2, NA = 9 * CO + CO, NSUB = 8 / CI, NPX = W_TR * TW, NGRP = (NPX + 63) / 64;
   __shared__ float in[CI][W_TR + 2][LP];
-  __shared__ float lo[lo_floats<SRC, CI, W_TR, TW>];
+  float *const lo = nullptr;   // no staging here (STAGE = false)
   __shared__ float dzt[CO][W_TR][TW];
   __shared__ double dacc[8][NA];
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
@@ -520,7 +591,7 @@ __global__ __launch_bounds__(512) void f_bw(int n, int H, int W, FitSrc S, float
     const size_t s = tile / per_s;
     const int t = (int)(tile - (long)s * per_s), y0 = (t / tx_n) * W_TR, x0 = (t % tx_n) * TW;
     __syncthreads();
-    fill_input<SRC, CI, W_TR, TW, LP, 512>(in, lo, S, s, y0, x0, H, W, tid);
+    fill_input<SRC, CI, W_TR, TW, LP, 512, 1, false>(in, lo, S, s, y0, x0, H, W, tid);
     for (int e = tid; e < CO * W_TR * TW; e += 512) {
       const int co = e / (W_TR * TW), rem = e - co * (W_TR * TW), yy = rem / TW, xx = rem - yy * TW;
       const int y = y0 + yy;
@@ -571,6 +642,109 @@ __global__ __launch_bounds__(512) void f_bw(int n, int H, int W, FitSrc S, float
       for (int sb = 0; sb < NSUB; sb++) v += dacc[sb * CI][9 * CO + co];
     }
     part[(size_t)blockIdx.x * (9 * CI * CO + CO) + k] = v;
+  }
+}
+
+// The same for layers with few weights (CI x CO <= 8: upconv1, upconv2, the output convolution): a wave per input channel
+// would read one LDS value per FMA there.  A thread owns 4 pixels of a row and ALL 9 CI CO sums: 6 input values of a row
+// serve 12 FMAs per output channel.
+template <int CI, int CO, int SRC, int TW, bool BN>
+__global__ __launch_bounds__(256) void f_bw_small(int n, int H, int W, FitSrc S, float *__restrict__ g,
+                                                  const float *__restrict__ z, const float *__restrict__ stat,
+                                                  const float *__restrict__ gamma, const double *__restrict__ sums,
+                                                  double count, double *__restrict__ part) {
+  constexpr int TPR = (TW + 3) / 4, LP = 4 * TPR + 4, DP = 4 * TPR, NA = 9 * CI * CO + CO;
+  static_assert(W_TR * TPR <= 256 && CI * CO <= 8, "tile / accumulators do not fit");
+  __shared__ __align__(16) float in[CI][W_TR + 2][LP];
+  __shared__ float lo[lo_floats<SRC, CI, W_TR, TW>];
+  __shared__ __align__(16) float dzt[CO][W_TR][DP];
+  __shared__ double dacc[4][NA];
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, r = tid / TPR, q = tid - r * TPR;
+  const bool active = r < W_TR;
+  const int tx_n = W / TW, ty_n = (H + W_TR - 1) / W_TR, per_s = tx_n * ty_n;
+  const long ntiles = (long)n * per_s;
+  for (int e = tid; e < 4 * NA; e += 256) (&dacc[0][0])[e] = 0.0;
+  float acc[NA];
+#pragma unroll
+  for (int k = 0; k < NA; k++) acc[k] = 0.f;
+  auto flush = [&]() {
+#pragma unroll
+    for (int k = 0; k < NA; k++) {
+      const float v = wave_sum(acc[k]);
+      if (lane == 0) dacc[wv][k] += (double)v;
+      acc[k] = 0.f;
+    }
+  };
+  int since = 0;
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const size_t s = tile / per_s;
+    const int t = (int)(tile - (long)s * per_s), y0 = (t / tx_n) * W_TR, x0 = (t % tx_n) * TW;
+    __syncthreads();
+    fill_input<SRC, CI, W_TR, TW, LP, 256>(in, lo, S, s, y0, x0, H, W, tid);
+    for (int e0 = tid; e0 < CO * W_TR * DP; e0 += 256 * 8) {
+      float gv[FILL_U], zv[FILL_U];
+#pragma unroll
+      for (int u = 0; u < FILL_U; u++) {
+        const int e = e0 + u * 256;
+        const int co = e / (W_TR * DP), rem = e - co * (W_TR * DP), yy = rem / DP, xx = rem - yy * DP;
+        const bool ok = e < CO * W_TR * DP && y0 + yy < H && xx < TW;
+        const size_t at = ((s * CO + co) * (size_t)H + y0 + yy) * W + x0 + xx;
+        gv[u] = ok ? g[at] : 0.f;
+        zv[u] = (BN && ok) ? z[at] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < FILL_U; u++) {
+        const int e = e0 + u * 256;
+        if (e >= CO * W_TR * DP) continue;
+        const int co = e / (W_TR * DP), rem = e - co * (W_TR * DP), yy = rem / DP, xx = rem - yy * DP;
+        float d = gv[u];
+        if constexpr (BN) {
+          if (y0 + yy < H && xx < TW) {
+            const float rs = rsqrtf(stat[2 * co + 1] + 1e-3f);
+            const float m0 = (float)(sums[2 * co] / count), m1 = (float)(sums[2 * co + 1] / count);
+            d = gamma[co] * rs * (d - m0 - (zv[u] - stat[2 * co]) * rs * m1);
+            g[((s * CO + co) * (size_t)H + y0 + yy) * W + x0 + xx] = d;
+          }
+        }
+        dzt[co][yy][xx] = d;
+      }
+    }
+    __syncthreads();
+    if (active) {
+      float dv[CO][4];
+#pragma unroll
+      for (int co = 0; co < CO; co++) {
+        const float4 d4 = *reinterpret_cast<const float4 *>(&dzt[co][r][4 * q]);
+        dv[co][0] = d4.x; dv[co][1] = d4.y; dv[co][2] = d4.z; dv[co][3] = d4.w;
+        acc[9 * CI * CO + co] += (d4.x + d4.y) + (d4.z + d4.w);
+      }
+#pragma unroll
+      for (int ci = 0; ci < CI; ci++)
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++) {
+          const float4 a4 = *reinterpret_cast<const float4 *>(&in[ci][r + ky][4 * q]);
+          const float2 a2 = *reinterpret_cast<const float2 *>(&in[ci][r + ky][4 * q + 4]);
+          const float v[6] = {a4.x, a4.y, a4.z, a4.w, a2.x, a2.y};
+#pragma unroll
+          for (int kx = 0; kx < 3; kx++)
+#pragma unroll
+            for (int co = 0; co < CO; co++)
+#pragma unroll
+              for (int px = 0; px < 4; px++)
+                acc[(ci * CO + co) * 9 + ky * 3 + kx] = fmaf(v[px + kx], dv[co][px], acc[(ci * CO + co) * 9 + ky * 3 + kx]);
+        }
+    }
+    if (++since == W_FLUSH) { flush(); since = 0; }
+  }
+  flush();
+  __syncthreads();
+  for (int k = tid; k < NA; k += 256) {
+    int a = k;
+    if (k < 9 * CI * CO) {
+      const int co = k % CO, c = (k / CO) % CI, tap = k / (CO * CI);
+      a = (c * CO + co) * 9 + tap;
+    }
+    part[(size_t)blockIdx.x * NA + k] = (dacc[0][a] + dacc[1][a]) + (dacc[2][a] + dacc[3][a]);
   }
 }
 
@@ -686,11 +860,16 @@ int ofx_fit_bw(hipStream_t st, int n, int ci, int co, int H, int W, const ofx_fi
   BWK(2, 8, OFX_FIT_SRC_BITS, 100, true)
   BWK(8, 8, OFX_FIT_SRC_POOL, 100, true)
   BWK(8, 8, OFX_FIT_SRC_POOL, 50, true)
-  BWK(1, 2, OFX_FIT_SRC_UPRAW, 50, true)
-  BWK(2, 4, OFX_FIT_SRC_UP, 100, true)
   BWK(4, 8, OFX_FIT_SRC_UP, 100, true)
-  BWK(8, 1, OFX_FIT_SRC_UP, 100, false)
 #undef BWK
+#define BWS(CI_, CO_, SRC_, TW_, BN_) \
+  if (!done && ci == CI_ && co == CO_ && src.kind == SRC_ && TW == TW_ && (bn != 0) == BN_) { \
+    hipLaunchKernelGGL((f_bw_small<CI_, CO_, SRC_, TW_, BN_>), dim3(grid), dim3(256), 0, st, n, H, W, S, g, z, stat, gamma, sums, count, part); \
+    done = true; }
+  BWS(1, 2, OFX_FIT_SRC_UPRAW, 50, true)
+  BWS(2, 4, OFX_FIT_SRC_UP, 100, true)
+  BWS(8, 1, OFX_FIT_SRC_UP, 100, false)
+#undef BWS
   if (!done) {
     ofx_set_error("ofx_dqn_fit: no weight-gradient kernel for %d -> %d channels, source %d", ci, co, src.kind);
     return OFX_ERR_STATE;
