@@ -86,7 +86,33 @@ template <int SRC, int CI, int TR, int TW> constexpr int lo_floats = src_is_up<S
 template <int SRC, int CI, int TR, int TW, int LP, int NT, int FU = 8, bool STAGE = true>
 __device__ __forceinline__ void fill_input(float (*in)[TR + 2][LP], float *lo, const FitSrc &S, size_t s, int y0, int x0,
                                            int H, int W, int tid) {
-  if constexpr (!STAGE) {
+  if constexpr (SRC == OFX_FIT_SRC_POOL) {
+    // two pooled pixels per step from two 16-byte loads (tile column 0 is an odd plane column: one single step at either
+    // end of a row, TW / 2 pairs between them)
+    static_assert(TW % 2 == 0, "tile width");
+    constexpr int ST = TW / 2 + 2;
+    const float *zp = reinterpret_cast<const float *>(S.p);
+    for (int e = tid; e < CI * (TR + 2) * ST; e += NT) {
+      const int c = e / ((TR + 2) * ST), rem = e - c * ((TR + 2) * ST), yy = rem / ST, st = rem - yy * ST;
+      const int y = y0 - 1 + yy, xx = st == 0 ? 0 : 2 * st - 1, x = x0 - 1 + xx;
+      const bool pair = st != 0 && st != ST - 1;
+      float v0 = 0.f, v1 = 0.f;
+      if (y >= 0 && y < H) {
+        const float sc = S.act[2 * c], sh = S.act[2 * c + 1];
+        const float *zr = zp + ((s * CI + c) * (size_t)S.h + 2 * y) * S.w + 2 * x;
+        if (pair) {
+          const float4 r0 = *reinterpret_cast<const float4 *>(zr), r1 = *reinterpret_cast<const float4 *>(zr + S.w);
+          v0 = fmaxf(fmaxf(bn_act(r0.x, sc, sh), bn_act(r0.y, sc, sh)), fmaxf(bn_act(r1.x, sc, sh), bn_act(r1.y, sc, sh)));
+          v1 = fmaxf(fmaxf(bn_act(r0.z, sc, sh), bn_act(r0.w, sc, sh)), fmaxf(bn_act(r1.z, sc, sh), bn_act(r1.w, sc, sh)));
+        } else if (x >= 0 && x < W) {
+          const float2 r0 = *reinterpret_cast<const float2 *>(zr), r1 = *reinterpret_cast<const float2 *>(zr + S.w);
+          v0 = fmaxf(fmaxf(bn_act(r0.x, sc, sh), bn_act(r0.y, sc, sh)), fmaxf(bn_act(r1.x, sc, sh), bn_act(r1.y, sc, sh)));
+        }
+      }
+      in[c][yy][xx] = v0;
+      if (pair) in[c][yy][xx + 1] = v1;
+    }
+  } else if constexpr (!STAGE) {
     for (int e = tid; e < CI * (TR + 2) * (TW + 2); e += NT) {
       const int c = e / ((TR + 2) * (TW + 2)), rem = e - c * ((TR + 2) * (TW + 2));
       const int yy = rem / (TW + 2), xx = rem - yy * (TW + 2);
@@ -408,30 +434,54 @@ __global__ __launch_bounds__(256, 3) void f_b1_pool(int n, int H, int W, const f
         }
       }
     }
+    const bool both = xp + 1 < Wp;   // the thread's second pooled pixel exists (always, but for the odd-width last layer)
 #pragma unroll
     for (int ci = 0; ci < C; ci++) {
       const float mean = stat[2 * ci], rs = rsqrtf(stat[2 * ci + 1] + 1e-3f), sc = act[2 * ci], sh = act[2 * ci + 1];
+      const size_t base = ((s * C + ci) * (size_t)H + 2 * yp) * W + 2 * xp;
+      float zr[2][4];   // rows 2 yp, 2 yp + 1; columns 2 xp .. 2 xp + 3
+      const bool vec = both && (W & 3) == 0;   // 16-byte accesses: the rows of the 50 x 50 layer are only 8-byte aligned
+      if (vec) {
+        const float4 r0 = *reinterpret_cast<const float4 *>(z + base), r1 = *reinterpret_cast<const float4 *>(z + base + W);
+        zr[0][0] = r0.x; zr[0][1] = r0.y; zr[0][2] = r0.z; zr[0][3] = r0.w;
+        zr[1][0] = r1.x; zr[1][1] = r1.y; zr[1][2] = r1.z; zr[1][3] = r1.w;
+      } else {
+        const float2 r0 = *reinterpret_cast<const float2 *>(z + base), r1 = *reinterpret_cast<const float2 *>(z + base + W);
+        zr[0][0] = r0.x; zr[0][1] = r0.y; zr[1][0] = r1.x; zr[1][1] = r1.y;
+        zr[0][2] = zr[0][3] = zr[1][2] = zr[1][3] = 0.f;
+        if (both) {
+          const float2 q0 = *reinterpret_cast<const float2 *>(z + base + 2), q1 = *reinterpret_cast<const float2 *>(z + base + W + 2);
+          zr[0][2] = q0.x; zr[0][3] = q0.y; zr[1][2] = q1.x; zr[1][3] = q1.y;
+        }
+      }
+      float o[2][4];
 #pragma unroll
       for (int j = 0; j < 2; j++) {
-        if (xp + j >= Wp) continue;
-        const size_t base = ((s * C + ci) * (size_t)H + 2 * yp) * W + 2 * (xp + j);
-        const float2 r0 = *reinterpret_cast<const float2 *>(z + base), r1 = *reinterpret_cast<const float2 *>(z + base + W);
-        const float zv[4] = {r0.x, r0.y, r1.x, r1.y};
+        const float zv[4] = {zr[0][2 * j], zr[0][2 * j + 1], zr[1][2 * j], zr[1][2 * j + 1]};
         float av[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) av[i] = bn_act(zv[i], sc, sh);
         int k = 0;
 #pragma unroll
         for (int i = 1; i < 4; i++) if (av[i] > av[k]) k = i;
-        const float d = CONV ? dp[j][ci] : dzn[((s * C + ci) * (size_t)Hp + yp) * Wp + xp + j];
-        const float gv = av[k] > 0.f ? d : 0.f;
-        float o[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) o[i] = i == k ? gv : 0.f;
-        *reinterpret_cast<float2 *>(g + base) = make_float2(o[0], o[1]);
-        *reinterpret_cast<float2 *>(g + base + W) = make_float2(o[2], o[3]);
+        float d = 0.f;
+        if (j == 0 || both) d = CONV ? dp[j][ci] : dzn[((s * C + ci) * (size_t)Hp + yp) * Wp + xp + j];
+        const float gv = (av[k] > 0.f && (j == 0 || both)) ? d : 0.f;
+        o[0][2 * j] = k == 0 ? gv : 0.f; o[0][2 * j + 1] = k == 1 ? gv : 0.f;
+        o[1][2 * j] = k == 2 ? gv : 0.f; o[1][2 * j + 1] = k == 3 ? gv : 0.f;
         s1[ci] += (double)gv;
         s2[ci] += (double)(gv * ((zv[k] - mean) * rs));
+      }
+      if (vec) {
+        *reinterpret_cast<float4 *>(g + base) = make_float4(o[0][0], o[0][1], o[0][2], o[0][3]);
+        *reinterpret_cast<float4 *>(g + base + W) = make_float4(o[1][0], o[1][1], o[1][2], o[1][3]);
+      } else {
+        *reinterpret_cast<float2 *>(g + base) = make_float2(o[0][0], o[0][1]);
+        *reinterpret_cast<float2 *>(g + base + W) = make_float2(o[1][0], o[1][1]);
+        if (both) {
+          *reinterpret_cast<float2 *>(g + base + 2) = make_float2(o[0][2], o[0][3]);
+          *reinterpret_cast<float2 *>(g + base + W + 2) = make_float2(o[1][2], o[1][3]);
+        }
       }
     }
   }
@@ -470,8 +520,9 @@ __global__ __launch_bounds__(256, 2) void f_b1_up(int n, int h, int w, const flo
   const int tx_n = (w + U_TW - 1) / U_TW, ty_n = (h + TRL - 1) / TRL, per_s = tx_n * ty_n;
   const long ntiles = (long)n * per_s;
   double s1[C], s2[C];
+  float rsv[C];
 #pragma unroll
-  for (int c = 0; c < C; c++) { s1[c] = 0.0; s2[c] = 0.0; }
+  for (int c = 0; c < C; c++) { s1[c] = 0.0; s2[c] = 0.0; rsv[c] = BN ? rsqrtf(stat[2 * c + 1] + 1e-3f) : 0.f; }
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const size_t s = tile / per_s;
     const int t = (int)(tile - (long)s * per_s), y0 = (t / tx_n) * TRL, x0 = (t % tx_n) * U_TW;
@@ -541,7 +592,7 @@ __global__ __launch_bounds__(256, 2) void f_b1_up(int n, int h, int w, const flo
         const float gv = bn_act(zv, act[2 * c], act[2 * c + 1]) > 0.f ? acc : 0.f;
         g[at] = gv;
         s1[c] += (double)gv;
-        s2[c] += (double)(gv * ((zv - stat[2 * c]) * rsqrtf(stat[2 * c + 1] + 1e-3f)));
+        s2[c] += (double)(gv * ((zv - stat[2 * c]) * rsv[c]));
       } else {
         g[at] = zv > 0.f ? acc : 0.f;
       }
@@ -560,21 +611,37 @@ __global__ __launch_bounds__(256, 2) void f_b1_up(int n, int h, int w, const flo
 
 // ---------------------------------------------------------------- backward 2: dz + the weight gradient
 constexpr int W_TR = 8, W_FLUSH = 16;
-template <int CI, int CO, int SRC, int TW, bool BN>
-__global__ __launch_bounds__(512) void f_bw(int n, int H, int W, FitSrc S, float *__restrict__ g,
+#ifndef OFX_FIT_BW_NT
+#define OFX_FIT_BW_NT 512
+#define OFX_FIT_BW_TR 8
+#endif
+template <int CI, int CO, int SRC, int TW, bool BN, int NT, int TR>
+__global__ __launch_bounds__(NT) void f_bw(int n, int H, int W, FitSrc S, float *__restrict__ g,
                                             const float *__restrict__ z, const float *__restrict__ stat,
                                             const float *__restrict__ gamma, const double *__restrict__ sums, double count,
                                             double *__restrict__ part) {
-  constexpr int LP = TW + 2, NA = 9 * CO + CO, NSUB = 8 / CI, NPX = W_TR * TW, NGRP = (NPX + 63) / 64;
-  __shared__ float in[CI][W_TR + 2][LP];
+  constexpr int LP = TW + 2, NA = 9 * CO + CO, NSUB = (NT / 64) / CI, NPX = TR * TW, NGRP = (NPX + 63) / 64;
+  __shared__ float in[CI][TR + 2][LP];
   float *const lo = nullptr;   // no staging here (STAGE = false)
-  __shared__ float dzt[CO][W_TR][TW];
-  __shared__ double dacc[8][NA];
+  __shared__ float dzt[CO][TR][TW];
+  __shared__ double dacc[NT / 64][NA];
+  // BatchNorm's backward per channel: dz = a (g - m0 - (z - mean) c).  Computed once: written out per element, the two
+  // double divisions by `count` alone were ~100 instructions for every one of a tile's 6 400 gradient values.
+  __shared__ float cf[BN ? CO : 1][4];
+  if constexpr (BN)
+    if (threadIdx.x < CO) {
+      const int co = threadIdx.x;
+      const float rs = rsqrtf(stat[2 * co + 1] + 1e-3f);
+      cf[co][0] = gamma[co] * rs;
+      cf[co][1] = (float)(sums[2 * co] / count);
+      cf[co][2] = rs * (float)(sums[2 * co + 1] / count);
+      cf[co][3] = stat[2 * co];
+    }
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const int ci = wv % CI, sub = wv / CI;
-  const int tx_n = W / TW, ty_n = (H + W_TR - 1) / W_TR, per_s = tx_n * ty_n;
+  const int tx_n = W / TW, ty_n = (H + TR - 1) / TR, per_s = tx_n * ty_n;
   const long ntiles = (long)n * per_s;
-  for (int e = tid; e < 8 * NA; e += 512) (&dacc[0][0])[e] = 0.0;
+  for (int e = tid; e < (NT / 64) * NA; e += NT) (&dacc[0][0])[e] = 0.0;
   float acc[NA];
 #pragma unroll
   for (int k = 0; k < NA; k++) acc[k] = 0.f;
@@ -589,24 +656,41 @@ __global__ __launch_bounds__(512) void f_bw(int n, int H, int W, FitSrc S, float
   int since = 0;
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const size_t s = tile / per_s;
-    const int t = (int)(tile - (long)s * per_s), y0 = (t / tx_n) * W_TR, x0 = (t % tx_n) * TW;
+    const int t = (int)(tile - (long)s * per_s), y0 = (t / tx_n) * TR, x0 = (t % tx_n) * TW;
     __syncthreads();
-    fill_input<SRC, CI, W_TR, TW, LP, 512, 1, false>(in, lo, S, s, y0, x0, H, W, tid);
-    for (int e = tid; e < CO * W_TR * TW; e += 512) {
-      const int co = e / (W_TR * TW), rem = e - co * (W_TR * TW), yy = rem / TW, xx = rem - yy * TW;
+    fill_input<SRC, CI, TR, TW, LP, NT, 1, false>(in, lo, S, s, y0, x0, H, W, tid);
+    // V gradient values per step (16-byte loads where the rows allow): the index arithmetic is paid once per V values
+    constexpr int V = TW % 4 == 0 ? 4 : 2, TWV = TW / V;
+    static_assert(TW % V == 0, "tile width");
+    for (int e = tid; e < CO * TR * TWV; e += NT) {
+      const int co = e / (TR * TWV), rem = e - co * (TR * TWV), yy = rem / TWV, xv = rem - yy * TWV;
       const int y = y0 + yy;
-      float d = 0.f;
+      float d[V];
+#pragma unroll
+      for (int k = 0; k < V; k++) d[k] = 0.f;
       if (y < H) {
-        const size_t at = ((s * CO + co) * (size_t)H + y) * W + x0 + xx;
-        d = g[at];
+        const size_t at = ((s * CO + co) * (size_t)H + y) * W + x0 + V * xv;
+        float zz[V];
+        if constexpr (V == 4) {
+          const float4 g4 = *reinterpret_cast<const float4 *>(g + at);
+          d[0] = g4.x; d[1] = g4.y; d[2] = g4.z; d[3] = g4.w;
+          if constexpr (BN) { const float4 z4 = *reinterpret_cast<const float4 *>(z + at); zz[0] = z4.x; zz[1] = z4.y; zz[2] = z4.z; zz[3] = z4.w; }
+        } else {
+          const float2 g2 = *reinterpret_cast<const float2 *>(g + at);
+          d[0] = g2.x; d[1] = g2.y;
+          if constexpr (BN) { const float2 z2 = *reinterpret_cast<const float2 *>(z + at); zz[0] = z2.x; zz[1] = z2.y; }
+        }
         if constexpr (BN) {
-          const float rs = rsqrtf(stat[2 * co + 1] + 1e-3f);
-          const float m0 = (float)(sums[2 * co] / count), m1 = (float)(sums[2 * co + 1] / count);
-          d = gamma[co] * rs * (d - m0 - (z[at] - stat[2 * co]) * rs * m1);
-          if constexpr (SRC != OFX_FIT_SRC_BITS) g[at] = d;   // nothing reads the first layer's dz
+#pragma unroll
+          for (int k = 0; k < V; k++) d[k] = cf[co][0] * (d[k] - cf[co][1] - (zz[k] - cf[co][3]) * cf[co][2]);
+          if constexpr (SRC != OFX_FIT_SRC_BITS) {   // nothing reads the first layer's dz
+            if constexpr (V == 4) *reinterpret_cast<float4 *>(g + at) = make_float4(d[0], d[1], d[2], d[3]);
+            else *reinterpret_cast<float2 *>(g + at) = make_float2(d[0], d[1]);
+          }
         }
       }
-      dzt[co][yy][xx] = d;
+#pragma unroll
+      for (int k = 0; k < V; k++) dzt[co][yy][V * xv + k] = d[k];
     }
     __syncthreads();
     for (int grp = sub; grp < NGRP; grp += NSUB) {
@@ -632,7 +716,7 @@ __global__ __launch_bounds__(512) void f_bw(int n, int H, int W, FitSrc S, float
   flush();
   __syncthreads();
   // part[block] = [tap][ci][co] weights, then [co] bias: the layout of the weight tensors (HWIO)
-  for (int k = tid; k < 9 * CI * CO + CO; k += 512) {
+  for (int k = tid; k < 9 * CI * CO + CO; k += NT) {
     double v = 0.0;
     if (k < 9 * CI * CO) {
       const int co = k % CO, c = (k / CO) % CI, tap = k / (CO * CI);
@@ -659,6 +743,16 @@ __global__ __launch_bounds__(256) void f_bw_small(int n, int H, int W, FitSrc S,
   __shared__ float lo[lo_floats<SRC, CI, W_TR, TW>];
   __shared__ __align__(16) float dzt[CO][W_TR][DP];
   __shared__ double dacc[4][NA];
+  __shared__ float cf[BN ? CO : 1][4];   // see f_bw
+  if constexpr (BN)
+    if (threadIdx.x < CO) {
+      const int co = threadIdx.x;
+      const float rs = rsqrtf(stat[2 * co + 1] + 1e-3f);
+      cf[co][0] = gamma[co] * rs;
+      cf[co][1] = (float)(sums[2 * co] / count);
+      cf[co][2] = rs * (float)(sums[2 * co + 1] / count);
+      cf[co][3] = stat[2 * co];
+    }
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, r = tid / TPR, q = tid - r * TPR;
   const bool active = r < W_TR;
   const int tx_n = W / TW, ty_n = (H + W_TR - 1) / W_TR, per_s = tx_n * ty_n;
@@ -700,9 +794,7 @@ __global__ __launch_bounds__(256) void f_bw_small(int n, int H, int W, FitSrc S,
         float d = gv[u];
         if constexpr (BN) {
           if (y0 + yy < H && xx < TW) {
-            const float rs = rsqrtf(stat[2 * co + 1] + 1e-3f);
-            const float m0 = (float)(sums[2 * co] / count), m1 = (float)(sums[2 * co + 1] / count);
-            d = gamma[co] * rs * (d - m0 - (zv[u] - stat[2 * co]) * rs * m1);
+            d = cf[co][0] * (d - cf[co][1] - (zv[u] - cf[co][3]) * cf[co][2]);
             g[((s * CO + co) * (size_t)H + y0 + yy) * W + x0 + xx] = d;
           }
         }
@@ -848,22 +940,25 @@ int ofx_fit_bw(hipStream_t st, int n, int ci, int co, int H, int W, const ofx_fi
                float *db, float *dgamma, float *dbeta) {
   const int TW = W >= 100 ? 100 : 50;
   if (W % TW) { ofx_set_error("ofx_dqn_fit: no weight-gradient tiling for %d x %d", H, W); return OFX_ERR_STATE; }
-  const long ntiles = (long)n * ((H + W_TR - 1) / W_TR) * (W / TW);
-  const int grid = grid_for(ntiles, OFX_FIT_MAX_BLOCKS / 2);
+  int grid = 0;
   const FitSrc S = dev_src(src);
   const double count = (double)n * H * W;
   bool done = false;
-#define BWK(CI_, CO_, SRC_, TW_, BN_) \
+  // NT threads and TR tile rows per workgroup (OFX_FIT_BW_NT / _TR for the layers with CI <= 4: 256-thread workgroups on
+  // 4-row tiles - four independent load / compute pipelines per CU instead of two - measured 4 % SLOWER, tools/ab_fit.sh)
+#define BWK(CI_, CO_, SRC_, TW_, BN_, NT_, TR_) \
   if (!done && ci == CI_ && co == CO_ && src.kind == SRC_ && TW == TW_ && (bn != 0) == BN_) { \
-    hipLaunchKernelGGL((f_bw<CI_, CO_, SRC_, TW_, BN_>), dim3(grid), dim3(512), 0, st, n, H, W, S, g, z, stat, gamma, sums, count, part); \
+    grid = grid_for((long)n * ((H + TR_ - 1) / TR_) * (W / TW), OFX_FIT_MAX_BLOCKS / 2); \
+    hipLaunchKernelGGL((f_bw<CI_, CO_, SRC_, TW_, BN_, NT_, TR_>), dim3(grid), dim3(NT_), 0, st, n, H, W, S, g, z, stat, gamma, sums, count, part); \
     done = true; }
-  BWK(2, 8, OFX_FIT_SRC_BITS, 100, true)
-  BWK(8, 8, OFX_FIT_SRC_POOL, 100, true)
-  BWK(8, 8, OFX_FIT_SRC_POOL, 50, true)
-  BWK(4, 8, OFX_FIT_SRC_UP, 100, true)
+  BWK(2, 8, OFX_FIT_SRC_BITS, 100, true, OFX_FIT_BW_NT, OFX_FIT_BW_TR)
+  BWK(8, 8, OFX_FIT_SRC_POOL, 100, true, 512, 8)
+  BWK(8, 8, OFX_FIT_SRC_POOL, 50, true, 512, 8)
+  BWK(4, 8, OFX_FIT_SRC_UP, 100, true, OFX_FIT_BW_NT, OFX_FIT_BW_TR)
 #undef BWK
 #define BWS(CI_, CO_, SRC_, TW_, BN_) \
   if (!done && ci == CI_ && co == CO_ && src.kind == SRC_ && TW == TW_ && (bn != 0) == BN_) { \
+    grid = grid_for((long)n * ((H + W_TR - 1) / W_TR) * (W / TW), OFX_FIT_MAX_BLOCKS / 2); \
     hipLaunchKernelGGL((f_bw_small<CI_, CO_, SRC_, TW_, BN_>), dim3(grid), dim3(256), 0, st, n, H, W, S, g, z, stat, gamma, sums, count, part); \
     done = true; }
   BWS(1, 2, OFX_FIT_SRC_UPRAW, 50, true)
