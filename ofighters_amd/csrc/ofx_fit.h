@@ -8,6 +8,7 @@
 #define OFX_FIT_SRC_POOL 1   /* pool2(relu(bn(z_prev)))          (trunk) */
 #define OFX_FIT_SRC_UP 2     /* up2(relu(bn(z_prev)))            (head 2) */
 #define OFX_FIT_SRC_UPRAW 3  /* up2(u0), u0 already behind its ReLU */
+#define OFX_FIT_SRC_ACTREP 4 /* relu(bn(z_prev)) at its own resolution, edge cells repeated outwards (phase form) */
 
 #define OFX_FIT_MAX_BLOCKS 2048 /* persistent grids: at most this many blocks, each with one row of partial sums */
 
@@ -38,3 +39,11 @@ int ofx_fit_b1_up(hipStream_t st, int n, int c, int con, int h, int w, int bn, c
 int ofx_fit_bw(hipStream_t st, int n, int ci, int co, int H, int W, const ofx_fit_src &src, int bn, float *g,
                const float *z, const float *stat, const float *gamma, const double *sums, double *part, float *dw,
                float *db, float *dgamma, float *dbeta);
+// the output convolution (8 -> 1 at 400 x 400 behind the last x2 up-sampling) in phase form: forward + frame correction;
+// weff: ofx_fit_out_floats() floats of scratch; the weight gradient needs part (ofx_fit_part_doubles) and fpart
+// (ofx_fit_out_doubles(n) doubles)
+size_t ofx_fit_out_floats(void);
+size_t ofx_fit_out_doubles(int n);
+int ofx_fit_out_fwd(hipStream_t st, int n, const ofx_fit_src &src, const float *w, const float *b, float *o2, float *weff);
+int ofx_fit_out_bw(hipStream_t st, int n, const ofx_fit_src &src, const float *d2, double *part, double *fpart, float *dw,
+                   float *db);

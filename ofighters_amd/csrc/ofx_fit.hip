@@ -43,6 +43,10 @@ struct FitSrc {
 // value of the convolution's input (channel c of sample s) at (y, x) of its H x W plane; zero outside
 template <int SRC, int C>
 __device__ __forceinline__ float src_value(const FitSrc &S, size_t s, int c, int y, int x, int H, int W) {
+  if constexpr (SRC == OFX_FIT_SRC_ACTREP) {   // relu(bn(z)) at the plane's own resolution, edge cells repeated outwards
+    const int yc = min(max(y, 0), H - 1), xc = min(max(x, 0), W - 1);
+    return bn_act(reinterpret_cast<const float *>(S.p)[((s * C + c) * (size_t)H + yc) * W + xc], S.act[2 * c], S.act[2 * c + 1]);
+  }
   if (y < 0 || y >= H || x < 0 || x >= W) return 0.f;
   if constexpr (SRC == OFX_FIT_SRC_BITS) {
     const uint32_t *b = reinterpret_cast<const uint32_t *>(S.p) + (s * C + c) * (size_t)((H * W) >> 5);
@@ -228,7 +232,9 @@ __device__ __forceinline__ void lds_vec(const float *p, float (&o)[K]) {
 // ---------------------------------------------------------------- forward
 constexpr int F_TR = 10;  // rows of a forward tile
 
-template <int CI, int CO, int SRC, int TW, bool STATS>
+// PHASE (the output convolution in phase form, see f_out_prep): the CO = 4 outputs of a cell (y, x) are the 2 x 2 block
+// (2 y + a, 2 x + b), channel 2 a + b, of ONE plane of 2 H x 2 W.
+template <int CI, int CO, int SRC, int TW, bool STATS, bool PHASE = false>
 __global__ __launch_bounds__(256, 3) void f_conv_fwd(int n, int H, int W, FitSrc S, const float *__restrict__ w,
                                                   const float *__restrict__ b, float *__restrict__ z,
                                                   double *__restrict__ part) {
@@ -281,6 +287,16 @@ __global__ __launch_bounds__(256, 3) void f_conv_fwd(int n, int H, int W, FitSrc
       }
     }
     const int y = y0 + r, x = x0 + 4 * q;
+    if constexpr (PHASE) {
+      static_assert(CO == 4 && TW % 4 == 0 && !STATS, "phase form");
+#pragma unroll
+      for (int a = 0; a < 2; a++) {
+        float *op = z + (s * 2 * H + 2 * y + a) * (size_t)(2 * W) + 2 * x;
+        *reinterpret_cast<float4 *>(op) = make_float4(acc[0][2 * a], acc[0][2 * a + 1], acc[1][2 * a], acc[1][2 * a + 1]);
+        *reinterpret_cast<float4 *>(op + 4) = make_float4(acc[2][2 * a], acc[2][2 * a + 1], acc[3][2 * a], acc[3][2 * a + 1]);
+      }
+      continue;
+    }
 #pragma unroll
     for (int co = 0; co < CO; co++) {
       float *zp = z + ((s * CO + co) * (size_t)H + y) * W + x;
@@ -615,7 +631,9 @@ constexpr int W_TR = 8, W_FLUSH = 16;
 #define OFX_FIT_BW_NT 512
 #define OFX_FIT_BW_TR 8
 #endif
-template <int CI, int CO, int SRC, int TW, bool BN, int NT, int TR>
+// PHASE: g is ONE plane of 2 H x 2 W per sample (d loss / d heat map) and output channel 2 a + b of cell (y, x) is its
+// element (2 y + a, 2 x + b) - the weight gradient of the output convolution in phase form (f_out_prep).
+template <int CI, int CO, int SRC, int TW, bool BN, int NT, int TR, bool PHASE = false>
 __global__ __launch_bounds__(NT) void f_bw(int n, int H, int W, FitSrc S, float *__restrict__ g,
                                             const float *__restrict__ z, const float *__restrict__ stat,
                                             const float *__restrict__ gamma, const double *__restrict__ sums, double count,
@@ -662,6 +680,22 @@ __global__ __launch_bounds__(NT) void f_bw(int n, int H, int W, FitSrc S, float 
     // V gradient values per step (16-byte loads where the rows allow): the index arithmetic is paid once per V values
     constexpr int V = TW % 4 == 0 ? 4 : 2, TWV = TW / V;
     static_assert(TW % V == 0, "tile width");
+    if constexpr (PHASE) {
+      static_assert(CO == 4 && V == 4 && !BN, "phase form");
+      for (int e = tid; e < 2 * TR * TWV; e += NT) {
+        const int a = e / (TR * TWV), rem = e - a * (TR * TWV), yy = rem / TWV, xv = rem - yy * TWV;
+        const int y = y0 + yy;
+        float4 lo4 = make_float4(0.f, 0.f, 0.f, 0.f), hi4 = lo4;
+        if (y < H) {
+          const float *gp = g + (s * 2 * H + 2 * y + a) * (size_t)(2 * W) + 2 * (x0 + 4 * xv);
+          lo4 = *reinterpret_cast<const float4 *>(gp);
+          hi4 = *reinterpret_cast<const float4 *>(gp + 4);
+        }
+        float *d0 = &dzt[2 * a][yy][4 * xv], *d1 = &dzt[2 * a + 1][yy][4 * xv];
+        d0[0] = lo4.x; d1[0] = lo4.y; d0[1] = lo4.z; d1[1] = lo4.w;
+        d0[2] = hi4.x; d1[2] = hi4.y; d0[3] = hi4.z; d1[3] = hi4.w;
+      }
+    } else
     for (int e = tid; e < CO * TR * TWV; e += NT) {
       const int co = e / (TR * TWV), rem = e - co * (TR * TWV), yy = rem / TWV, xv = rem - yy * TWV;
       const int y = y0 + yy;
@@ -860,6 +894,117 @@ __global__ __launch_bounds__(256) void f_bw_finish(int nv, int nw, int nblocks, 
   }
 }
 
+// ---------------------------------------------------------------- the output convolution (8 -> 1 at 400 x 400) in phase form
+// o2 = conv3x3(up2(a)), a = relu(bn(z)) of the last head layer.  Up-sampling 8 planes to 400 x 400 in every tile cost
+// more than the convolution itself (8x the useful instructions, rocprofv3 r03).  Along an axis
+//   up(2 k + t) for t = -1, 0, 1, 2  =  R[t + 1][0] a[k - 1] + R[t + 1][1] a[k] + R[t + 1][2] a[k + 1]
+// with a[] repeated outwards at the plane's edge, so the 2 x 2 outputs of low-res cell (k, m) are a 3 x 3 convolution
+// of `a` with 4 output channels (phase 2 a + b):  Weff[dy][dx][c][2 a + b] = sum_{ky, kx} w[ky][kx][c] R[a + ky][dy] R[b + kx][dx].
+// Forward, weight gradient (Q[dy][dx][c][phase] mapped back through R) run on f_conv_fwd / f_bw with the ACTREP source.
+// What the phase form gets wrong is the zero padding of the convolution at the plane's frame: it sees the up-sampled plane
+// REPEATED outwards (up(-1) = up(0), up(2 h) = up(2 h - 1)).  The two frame kernels take those terms out again.
+__device__ __forceinline__ float out_r(int t1, int d, int legacy) {   // R[t + 1][d]
+  const float wm0 = legacy ? 0.f : 0.25f, w00 = legacy ? 1.f : 0.75f, w01 = legacy ? 0.5f : 0.75f, wp1 = legacy ? 0.5f : 0.25f;
+  const float R[4][3] = {{w01, wp1, 0.f}, {wm0, w00, 0.f}, {0.f, w01, wp1}, {0.f, wm0, w00}};
+  return R[t1][d];
+}
+// weff[3][3][8][4] + bias4[4] from w[3][3][8][1], b[1]
+__global__ void f_out_prep(const float *w, const float *b, int legacy, float *weff) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < 288) {
+    const int p = e & 3, c = (e >> 2) & 7, dx = (e >> 5) % 3, dy = e / 96, a = p >> 1, bb = p & 1;
+    float acc = 0.f;
+    for (int ky = 0; ky < 3; ky++)
+      for (int kx = 0; kx < 3; kx++) acc += w[(ky * 3 + kx) * 8 + c] * out_r(a + ky, dy, legacy) * out_r(bb + kx, dx, legacy);
+    weff[e] = acc;
+  } else if (e < 292) {
+    weff[e] = b[0];
+  }
+}
+// frame pixel f of a 400 x 400 plane (1596 of them): rows 0 and 399, then columns 0 and 399 without their corners
+__device__ __forceinline__ void frame_px(int f, int &Y, int &X) {
+  if (f < 400) { Y = 0; X = f; }
+  else if (f < 800) { Y = 399; X = f - 400; }
+  else if (f < 1198) { Y = f - 799; X = 0; }
+  else { Y = f - 1197; X = 399; }
+}
+constexpr int kFrame = 1596;
+// forward: o2[Y][X] -= sum over the taps that fall outside the plane of w U[clamped tap]   (U = up2(a), SRC_UP)
+__global__ void f_out_frame_fwd(int n, FitSrc S, const float *w, float *o2) {
+  const size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (e >= (size_t)n * kFrame) return;
+  const size_t s = e / kFrame;
+  int Y, X;
+  frame_px((int)(e - s * kFrame), Y, X);
+  float acc = 0.f;
+  for (int ky = 0; ky < 3; ky++)
+    for (int kx = 0; kx < 3; kx++) {
+      const int y = Y + ky - 1, x = X + kx - 1;
+      if (y >= 0 && y < 400 && x >= 0 && x < 400) continue;
+      const int yc = min(max(y, 0), 399), xc = min(max(x, 0), 399);
+      for (int c = 0; c < 8; c++) acc += w[(ky * 3 + kx) * 8 + c] * src_value<OFX_FIT_SRC_UP, 8>(S, s, c, yc, xc, 400, 400);
+    }
+  o2[s * 160000 + (size_t)Y * 400 + X] -= acc;
+}
+// weight gradient: fpart[sample][72] = sum over the frame pixels and their outside taps of D U[clamped tap]; block = sample
+__global__ __launch_bounds__(256) void f_out_frame_bw(int n, FitSrc S, const float *d2, double *fpart) {
+  __shared__ double red[4][72];
+  const size_t s = blockIdx.x;
+  float acc[72];
+#pragma unroll
+  for (int k = 0; k < 72; k++) acc[k] = 0.f;
+  for (int f = threadIdx.x; f < kFrame; f += 256) {
+    int Y, X;
+    frame_px(f, Y, X);
+    const float d = d2[s * 160000 + (size_t)Y * 400 + X];
+#pragma unroll
+    for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+      for (int kx = 0; kx < 3; kx++) {
+        const int y = Y + ky - 1, x = X + kx - 1;
+        if (y >= 0 && y < 400 && x >= 0 && x < 400) continue;
+        const int yc = min(max(y, 0), 399), xc = min(max(x, 0), 399);
+#pragma unroll
+        for (int c = 0; c < 8; c++)
+          acc[(ky * 3 + kx) * 8 + c] = fmaf(d, src_value<OFX_FIT_SRC_UP, 8>(S, s, c, yc, xc, 400, 400), acc[(ky * 3 + kx) * 8 + c]);
+      }
+  }
+#pragma unroll
+  for (int k = 0; k < 72; k++) {
+    const float v = wave_sum(acc[k]);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = (double)v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 72) fpart[s * 72 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+// Q = ordered sum of part[nblocks][292] (f_bw<8, 4>: [dy][dx][c][phase], then the 4 phase sums of D);
+// dw[ky][kx][c] = sum R[a + ky][dy] R[b + kx][dx] Q[dy][dx][c][2 a + b] - sum over the samples of fpart;  db = sum of D
+__global__ __launch_bounds__(512) void f_out_bw_finish(int nblocks, const double *part, int n, const double *fpart, int legacy,
+                                                       float *dw, float *db) {
+  __shared__ double q[292];
+  const int k = threadIdx.x;
+  if (k < 292) {
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i = 0; i < nblocks; i++) acc[i & 3] += part[(size_t)i * 292 + k];
+    q[k] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  }
+  __syncthreads();
+  if (k < 72) {
+    const int c = k & 7, kx = (k >> 3) % 3, ky = k / 24;
+    double acc = 0.0;
+    for (int a = 0; a < 2; a++)
+      for (int b = 0; b < 2; b++)
+        for (int dy = 0; dy < 3; dy++)
+          for (int dx = 0; dx < 3; dx++)
+            acc += (double)(out_r(a + ky, dy, legacy) * out_r(b + kx, dx, legacy)) * q[((dy * 3 + dx) * 8 + c) * 4 + 2 * a + b];
+    double fr[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i = 0; i < n; i++) fr[i & 3] += fpart[(size_t)i * 72 + k];
+    dw[k] = (float)(acc - ((fr[0] + fr[1]) + (fr[2] + fr[3])));
+  } else if (k == 72) {
+    db[0] = (float)((q[288] + q[289]) + (q[290] + q[291]));
+  }
+}
+
 FitSrc dev_src(const ofx_fit_src &s) { return FitSrc{s.p, s.act, s.h, s.w, s.legacy}; }
 int grid_for(long ntiles, int cap) { return (int)(ntiles < cap ? ntiles : cap); }
 
@@ -973,6 +1118,39 @@ int ofx_fit_bw(hipStream_t st, int n, int ci, int co, int H, int W, const ofx_fi
   const int nw = 9 * ci * co, nv = nw + co;
   hipLaunchKernelGGL(f_bw_finish, dim3((nv + 15) / 16), dim3(256), 0, st, nv, nw, grid, part, dw, db, bn ? co : 0,
                      bn ? sums : nullptr, dgamma, dbeta);
+  OFX_HIP(hipGetLastError());
+  return OFX_OK;
+}
+
+size_t ofx_fit_out_floats(void) { return 292; }
+size_t ofx_fit_out_doubles(int n) { return (size_t)n * 72; }
+
+// o2[n][400][400] = conv3x3(up2(relu(bn(z)))) + b with z [n][8][200][200]: phase form + frame correction
+int ofx_fit_out_fwd(hipStream_t st, int n, const ofx_fit_src &src, const float *w, const float *b, float *o2, float *weff) {
+  if (src.kind != OFX_FIT_SRC_UP || src.h != 200 || src.w != 200) { ofx_set_error("ofx_dqn_fit: output convolution expects the 200 x 200 head layer"); return OFX_ERR_STATE; }
+  hipLaunchKernelGGL(f_out_prep, dim3(2), dim3(256), 0, st, w, b, src.legacy, weff);
+  const FitSrc S = dev_src(src);
+  FitSrc A = S;                                    // the same planes read at their own resolution
+  const long ntiles = (long)n * (200 / F_TR) * (200 / 100);
+  const int grid = grid_for(ntiles, OFX_FIT_MAX_BLOCKS);
+  hipLaunchKernelGGL((f_conv_fwd<8, 4, OFX_FIT_SRC_ACTREP, 100, false, true>), dim3(grid), dim3(256), 0, st, n, 200, 200, A,
+                     weff, weff + 288, o2, (double *)nullptr);
+  const size_t fr = (size_t)n * kFrame;
+  hipLaunchKernelGGL(f_out_frame_fwd, dim3((unsigned)((fr + 255) / 256)), dim3(256), 0, st, n, S, w, o2);
+  OFX_HIP(hipGetLastError());
+  return OFX_OK;
+}
+
+// dw[3][3][8][1], db[1] of the output convolution from d2 = d loss / d o2
+int ofx_fit_out_bw(hipStream_t st, int n, const ofx_fit_src &src, const float *d2, double *part, double *fpart, float *dw,
+                   float *db) {
+  const FitSrc S = dev_src(src);
+  const int grid = grid_for((long)n * ((200 + W_TR - 1) / W_TR) * 2, OFX_FIT_MAX_BLOCKS / 2);
+  hipLaunchKernelGGL((f_bw<8, 4, OFX_FIT_SRC_ACTREP, 100, false, 512, 8, true>), dim3(grid), dim3(512), 0, st, n, 200, 200, S,
+                     const_cast<float *>(d2), (const float *)nullptr, (const float *)nullptr, (const float *)nullptr,
+                     (const double *)nullptr, 1.0, part);
+  hipLaunchKernelGGL(f_out_frame_bw, dim3(n), dim3(256), 0, st, n, S, d2, fpart);
+  hipLaunchKernelGGL(f_out_bw_finish, dim3(1), dim3(512), 0, st, grid, part, n, fpart, src.legacy, dw, db);
   OFX_HIP(hipGetLastError());
   return OFX_OK;
 }

@@ -626,6 +626,7 @@ static int dqn_fit_lean(ofx_handle *h, float *weights, float *adam_m, float *ada
   sz(4 * N * 5000); sz(4 * N * 5008); sz(4 * N * 100); sz(4 * N * 50); sz(4 * N * 2); sz(4 * N * 625);      // p3 f d1 d2 o1 u0
   sz(4 * N * 625); sz(4 * N * 2); sz(4 * N * 100); sz(4 * N * 50); sz(4 * N * 5008); sz(4 * N * 5000);      // gu0 do1 dd1 dd2 df dp3
   sz(4 * (size_t)L.n_floats); sz(4 * 64); sz(4 * (2 * N + 4096)); sz(8 * ofx_fit_part_doubles()); sz(8 * 32);
+  sz(4 * ofx_fit_out_floats()); sz(8 * ofx_fit_out_doubles(n));
   for (int k = 0; k < 7; k++) { sz(4 * 16); sz(4 * 16); }
   if ((rc = keep_workspace(h, &h->fitws, &h->fitws_bytes, need))) return rc;
   Arena A{(char *)h->fitws, 0, need};
@@ -637,6 +638,8 @@ static int dqn_fit_lean(ofx_handle *h, float *weights, float *adam_m, float *ada
   OFX_HIP(hipMemsetAsync(loss, 0, 64 * sizeof(float), st));
   float *lpart = A.f(2 * N + 4096);
   double *part = A.d(ofx_fit_part_doubles()), *sums = A.d(32);
+  float *weff = A.f(ofx_fit_out_floats());
+  double *fpart = A.d(ofx_fit_out_doubles(n));
   float *tz[4], *tg[4], *tstat[4], *tact[4], *uz[3], *ug[3], *ustat[3], *uact[3];
   for (int i = 0; i < 4; i++) { tz[i] = A.f(N * 8 * tS[i] * tS[i]); tg[i] = A.f(N * 8 * tS[i] * tS[i]); tstat[i] = A.f(16); tact[i] = A.f(16); }
   for (int j = 0; j < 3; j++) { uz[j] = A.f(N * kUO[j] * uS[j] * uS[j]); ug[j] = A.f(N * kUO[j] * uS[j] * uS[j]); ustat[j] = A.f(16); uact[j] = A.f(16); }
@@ -671,7 +674,7 @@ static int dqn_fit_lean(ofx_handle *h, float *weights, float *adam_m, float *ada
     if ((rc = ofx_fit_conv_fwd(st, n, kUI[j], kUO[j], s, s, head_src(j), T(32 + 6 * j), T(33 + 6 * j), uz[j], part, &nb))) return rc;
     if ((rc = ofx_fit_finish(st, nb, kUO[j], (double)N * s * s, part, T(34 + 6 * j), T(35 + 6 * j), nullptr, ustat[j], uact[j]))) return rc;
   }
-  if ((rc = ofx_fit_conv_fwd(st, n, 8, 1, 400, 400, head_src(3), T(50), T(51), o2, nullptr, &nb))) return rc;
+  if ((rc = ofx_fit_out_fwd(st, n, head_src(3), T(50), T(51), o2, weff))) return rc;
 
   // ---- loss seeds ----
   OFX_HIP(hipMemsetAsync(do1, 0, N * 2 * 4, st));
@@ -689,7 +692,7 @@ static int dqn_fit_lean(ofx_handle *h, float *weights, float *adam_m, float *ada
   }
 
   // ---- backward: head 2 ----
-  if ((rc = ofx_fit_bw(st, n, 8, 1, 400, 400, head_src(3), 0, do2, nullptr, nullptr, nullptr, nullptr, part, G(50), G(51), nullptr, nullptr))) return rc;
+  if ((rc = ofx_fit_out_bw(st, n, head_src(3), do2, part, fpart, G(50), G(51)))) return rc;
   const float *dzn = do2;
   for (int j = 2; j >= 0; j--) {
     const int s = uS[j];
