@@ -977,18 +977,25 @@ __global__ __launch_bounds__(256) void f_out_frame_bw(int n, FitSrc S, const flo
   __syncthreads();
   if (threadIdx.x < 72) fpart[s * 72 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
-// Q = ordered sum of part[nblocks][292] (f_bw<8, 4>: [dy][dx][c][phase], then the 4 phase sums of D);
-// dw[ky][kx][c] = sum R[a + ky][dy] R[b + kx][dx] Q[dy][dx][c][2 a + b] - sum over the samples of fpart;  db = sum of D
-__global__ __launch_bounds__(512) void f_out_bw_finish(int nblocks, const double *part, int n, const double *fpart, int legacy,
-                                                       float *dw, float *db) {
-  __shared__ double q[292];
-  const int k = threadIdx.x;
-  if (k < 292) {
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int i = 0; i < nblocks; i++) acc[i & 3] += part[(size_t)i * 292 + k];
-    q[k] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-  }
+// out[k] = sum over the rows of part[nrows][nv], two levels in a fixed order (block = 16 values x 16 row shares)
+__global__ __launch_bounds__(256) void f_sum_rows(int nv, int nrows, const double *part, double *out) {
+  __shared__ double share[16][17];
+  const int k = blockIdx.x * 16 + (threadIdx.x & 15), j = threadIdx.x >> 4;
+  double acc = 0.0;
+  if (k < nv)
+    for (int i = j; i < nrows; i += 16) acc += part[(size_t)i * nv + k];
+  share[threadIdx.x & 15][j] = acc;
   __syncthreads();
+  if (threadIdx.x < 16 && blockIdx.x * 16 + threadIdx.x < nv) {
+    double t = 0.0;
+    for (int q = 0; q < 16; q++) t += share[threadIdx.x][q];
+    out[blockIdx.x * 16 + threadIdx.x] = t;
+  }
+}
+// q[292] = Q[dy][dx][c][phase] + the 4 phase sums of D, fr[72] = the frame terms:
+// dw[ky][kx][c] = sum R[a + ky][dy] R[b + kx][dx] Q[dy][dx][c][2 a + b] - fr;  db = sum of D
+__global__ void f_out_bw_finish(const double *q, const double *fr, int legacy, float *dw, float *db) {
+  const int k = threadIdx.x;
   if (k < 72) {
     const int c = k & 7, kx = (k >> 3) % 3, ky = k / 24;
     double acc = 0.0;
@@ -997,9 +1004,7 @@ __global__ __launch_bounds__(512) void f_out_bw_finish(int nblocks, const double
         for (int dy = 0; dy < 3; dy++)
           for (int dx = 0; dx < 3; dx++)
             acc += (double)(out_r(a + ky, dy, legacy) * out_r(b + kx, dx, legacy)) * q[((dy * 3 + dx) * 8 + c) * 4 + 2 * a + b];
-    double fr[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int i = 0; i < n; i++) fr[i & 3] += fpart[(size_t)i * 72 + k];
-    dw[k] = (float)(acc - ((fr[0] + fr[1]) + (fr[2] + fr[3])));
+    dw[k] = (float)(acc - fr[k]);
   } else if (k == 72) {
     db[0] = (float)((q[288] + q[289]) + (q[290] + q[291]));
   }
@@ -1123,7 +1128,7 @@ int ofx_fit_bw(hipStream_t st, int n, int ci, int co, int H, int W, const ofx_fi
 }
 
 size_t ofx_fit_out_floats(void) { return 292; }
-size_t ofx_fit_out_doubles(int n) { return (size_t)n * 72; }
+size_t ofx_fit_out_doubles(int n) { return (size_t)n * 72 + 292 + 72; }
 
 // o2[n][400][400] = conv3x3(up2(relu(bn(z)))) + b with z [n][8][200][200]: phase form + frame correction
 int ofx_fit_out_fwd(hipStream_t st, int n, const ofx_fit_src &src, const float *w, const float *b, float *o2, float *weff) {
@@ -1150,7 +1155,10 @@ int ofx_fit_out_bw(hipStream_t st, int n, const ofx_fit_src &src, const float *d
                      const_cast<float *>(d2), (const float *)nullptr, (const float *)nullptr, (const float *)nullptr,
                      (const double *)nullptr, 1.0, part);
   hipLaunchKernelGGL(f_out_frame_bw, dim3(n), dim3(256), 0, st, n, S, d2, fpart);
-  hipLaunchKernelGGL(f_out_bw_finish, dim3(1), dim3(512), 0, st, grid, part, n, fpart, src.legacy, dw, db);
+  double *q = fpart + (size_t)n * 72, *fr = q + 292;      // behind the per-sample frame terms
+  hipLaunchKernelGGL(f_sum_rows, dim3((292 + 15) / 16), dim3(256), 0, st, 292, grid, part, q);
+  hipLaunchKernelGGL(f_sum_rows, dim3((72 + 15) / 16), dim3(256), 0, st, 72, n, fpart, fr);
+  hipLaunchKernelGGL(f_out_bw_finish, dim3(1), dim3(128), 0, st, q, fr, src.legacy, dw, db);
   OFX_HIP(hipGetLastError());
   return OFX_OK;
 }
