@@ -202,14 +202,28 @@ def train_tick(N, M, device, base, w_host, fence):
         tr.replay()
     fence()
     rep_ms = (time.perf_counter() - t1) / 3 * 1e3
+    # the fit at the batch the rollout can feed it: 4096 rows of the sampled minibatch in ONE optimisation step
+    big_ms = None
+    try:
+        tr.fit_batch = 4096
+        tr.replay()
+        fence()
+        t2 = time.perf_counter()
+        for _ in range(2):
+            tr.replay()
+        fence()
+        big_ms = (time.perf_counter() - t2) / 2 * 1e3
+    except Exception as e:
+        big_ms = "failed: %s" % e
     rec = {"workload": "%d arenas x %d ships per GPU, TRAINING tick: one policy ship per arena (forward + epsilon-greedy + "
                        "transition capture) + step + obs + DeviceTrainer.replay on the reference's schedule "
                        "(every 50 steps and on lock-steps with a first-seen death), fit_batch 64" % (N, M),
            "value": N * steps / dt, "unit": "arena-steps/s", "steps": steps, "warmup": warm,
            "ms_per_step": dt / steps * 1e3, "replays_in_timed_region": n_rep, "ms_per_replay": rep_ms,
            "last_losses": [float(x) for x in roll.losses[-3:]],
-           "note": "sample + gather + two target forwards + one fit step per replay; the fit kernels are plain VALU "
-                   "kernels (ofx_train.hip), not the hot path"}
+           "ms_per_replay_fit_batch_4096": big_ms,
+           "note": "sample + gather + two target forwards + one fit step per replay; the fit is the lean form "
+                   "(ofx_fit.hip: only the pre-activations kept, fused fp32 VALU tiles), not the hot path"}
     b.close()
     return rec
 
