@@ -1,10 +1,13 @@
 // ofx_train.hip - one DQN fit step of the bi-head pointer_model: the model.fit call of
 // Trainer.replay (agents/qlearnIA_V2.py:284; model.compile(loss='mse', optimizer=Adam(lr)) :190).
 //
-// Plain fp32 VALU kernels with fixed-order reductions (no atomics: a fit is reproducible to the bit); the convolutions
-// keep all channels of a pixel in registers, the dense forwards run on the f32 MFMA GEMM of the forward.  This path runs
-// on the reference's replay schedule on a minibatch; it is not the hot path - correctness first (every gradient tensor
-// checked against torch autograd in float64, tests/test_train.py).  Keras semantics assumed (parity unpinned: no keras in the image):
+// Two forms of the same step.  The default is the LEAN form (dqn_fit_lean below + the kernels of ofx_fit.hip): only the
+// pre-activation tensor of every convolution is kept in HBM, the rest is recomputed inside fused tiles (17.8 MB of
+// workspace per minibatch row; 4096 rows in 118 ms).  The PLAIN form (OFX_OPT_FIT_PLAIN, dqn_fit_impl) is the layer-by-layer
+// original - one fp32 VALU kernel per layer and pass, every tensor of the graph in HBM (61 MB per row) - kept as the
+// reference of the lean form.  Both: fixed-order reductions (no atomics: a fit is reproducible to the bit), the dense
+// forwards on the f32 MFMA GEMM of the forward, every gradient tensor checked against torch autograd in float64 and the
+// two forms against each other (tests/test_train.py).  Keras semantics assumed (parity unpinned: no keras in the image):
 //   * fit runs the graph in training mode: BatchNorm normalises with the batch mean / biased variance (eps 1e-3) and
 //     moves the stored statistics: moving = 0.99 moving + 0.01 batch;
 //   * loss = mse(output1) + mse(output2), each the mean over the batch and the output elements;
