@@ -8,7 +8,7 @@ import os
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FILES = ("ofx_policy.hip", "ofx_head.hip", "ofx_raster.hip", "ofx_nn.hip")
+FILES = ("ofx_policy.hip", "ofx_head.hip", "ofx_raster.hip", "ofx_nn.hip", "ofx_fit.hip")
 
 # `for (int e = tid; e < N; e += THREADS) <body>` where <body> stores into arr[...]: group(1) = body
 FILL = re.compile(r"for\s*\(\s*int\s+(\w+)\s*=\s*(?:tid|threadIdx\.x|gt)\s*;[^;]*;\s*\1\s*\+=\s*[A-Za-z_0-9:.]+\s*\)\s*(\{(?:[^{}]|\{[^{}]*\})*\}|[^;]*;)")
