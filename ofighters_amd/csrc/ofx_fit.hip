@@ -24,6 +24,26 @@ namespace {
 
 __device__ __forceinline__ float bn_act(float z, float sc, float sh) { return fmaxf(fmaf(z, sc, sh), 0.f); }
 
+// (a0, a1) += v * (w0, w1) as ONE v_pk_fma_f32 (the splat of v is an op_sel of the instruction): twice the FMAs per
+// vector-issue slot of v_fmac_f32, the same roundings.  The inner loops below pair their accumulators over the channel
+// index.
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void fma2(float &a0, float &a1, float v, float w0, float w1) {
+  const f2v r = __builtin_elementwise_fma((f2v){v, v}, (f2v){w0, w1}, (f2v){a0, a1});
+  a0 = r.x;
+  a1 = r.y;
+}
+template <int N>
+__device__ __forceinline__ void fma_row(float (&acc)[N], float v, const float (&w)[N]) {   // acc[i] += v * w[i]
+  if constexpr (N % 2 == 0) {
+#pragma unroll
+    for (int i = 0; i < N; i += 2) fma2(acc[i], acc[i + 1], v, w[i], w[i + 1]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; i++) acc[i] = fmaf(v, w[i], acc[i]);
+  }
+}
+
 // x2 bilinear taps of up-res index u over n source cells: half-pixel centres, or (legacy) src = dst / 2 - the same
 // conventions as ofx_train.hip's up_taps / the forward's OFX_OPT_BILINEAR_LEGACY
 __device__ __forceinline__ void fit_up_taps(int u, int n, int &i0, int &i1, float &w1, int legacy) {
@@ -279,10 +299,7 @@ __global__ __launch_bounds__(256, 3) void f_conv_fwd(int n, int H, int W, FitSrc
           float wv[CO];
           lds_vec<CO>(&wl[((ky * 3 + kx) * CI + ci) * CO], wv);
 #pragma unroll
-          for (int co = 0; co < CO; co++) {
-#pragma unroll
-            for (int px = 0; px < 4; px++) acc[px][co] = fmaf(v[px + kx], wv[co], acc[px][co]);
-          }
+          for (int px = 0; px < 4; px++) fma_row<CO>(acc[px], v[px + kx], wv);
         }
       }
     }
@@ -441,11 +458,8 @@ __global__ __launch_bounds__(256, 3) void f_b1_pool(int n, int H, int W, const f
           for (int kx = 0; kx < 3; kx++) {
             float wv[C];
             lds_vec<C>(&wl[((ky * 3 + kx) * C + co) * C], wv);
-#pragma unroll
-            for (int ci = 0; ci < C; ci++) {
-              dp[0][ci] = fmaf(v[2 - kx], wv[ci], dp[0][ci]);
-              dp[1][ci] = fmaf(v[3 - kx], wv[ci], dp[1][ci]);
-            }
+            fma_row<C>(dp[0], v[2 - kx], wv);
+            fma_row<C>(dp[1], v[3 - kx], wv);
           }
         }
       }
@@ -573,8 +587,7 @@ __global__ __launch_bounds__(256, 2) void f_b1_up(int n, int h, int w, const flo
             const float v = dzt[co][i - ky + 2][j - kx + 2];
             float wv[C];
             lds_vec<C>(&wl[((ky * 3 + kx) * CON + co) * C], wv);
-#pragma unroll
-            for (int c = 0; c < C; c++) acc[c] = fmaf(v, wv[c], acc[c]);
+            fma_row<C>(acc, v, wv);
           }
 #pragma unroll
       for (int c = 0; c < C; c++) du[c][i][j] = acc[c];
@@ -739,8 +752,14 @@ __global__ __launch_bounds__(NT) void f_bw(int n, int H, int W, FitSrc S, float 
 #pragma unroll
         for (int kx = 0; kx < 3; kx++) {
           const float v = in[ci][yy + ky][xx + kx];
+          if constexpr (CO % 2 == 0) {
 #pragma unroll
-          for (int co = 0; co < CO; co++) acc[(ky * 3 + kx) * CO + co] = fmaf(v, dv[co], acc[(ky * 3 + kx) * CO + co]);
+            for (int co = 0; co < CO; co += 2)
+              fma2(acc[(ky * 3 + kx) * CO + co], acc[(ky * 3 + kx) * CO + co + 1], v, dv[co], dv[co + 1]);
+          } else {
+#pragma unroll
+            for (int co = 0; co < CO; co++) acc[(ky * 3 + kx) * CO + co] = fmaf(v, dv[co], acc[(ky * 3 + kx) * CO + co]);
+          }
         }
 #pragma unroll
       for (int co = 0; co < CO; co++) acc[9 * CO + co] += dv[co];
