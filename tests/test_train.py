@@ -247,25 +247,28 @@ def test_lean_fit_equals_plain_fit():
     zeros = np.zeros_like(w)
     w_d, m_d, v_d, g_d = (DeviceBuffer(w.nbytes) for _ in range(4))
     out = {}
-    for kind in ("textbook", "reference"):
+    # the whole minibatch in both forms of the targets, and its first 1 / 5 rows (one sample: the batch statistics of a
+    # single image; an odd count) in the textbook form
+    cases = [("textbook", n), ("reference", n), ("textbook", 1), ("textbook", 5)]
+    for kind, rows_n in cases:
         for form in ("lean", "plain"):
             b.set_option(nat.OPT_FIT_PLAIN, int(form == "plain"))
             w_d.upload(w); m_d.upload(zeros); v_d.upload(zeros)
             if kind == "textbook":
-                l = b.dqn_fit(w_d, m_d, v_d, 1, 1e-4, n, rows_d.ptr, bp_d.ptr, y.ptr, y2.ptr, g_d)
+                l = b.dqn_fit(w_d, m_d, v_d, 1, 1e-4, rows_n, rows_d.ptr, bp_d.ptr, y.ptr, y2.ptr, g_d)
             else:
-                l = b.dqn_fit_reference(w_d, m_d, v_d, 1, 1e-4, n, rows_d.ptr, bp_d.ptr, bn_d.ptr, 0.9, g_d)
-            out[kind, form] = (l, g_d.download(np.float32, w.shape).astype(np.float64), w_d.download(np.float32, w.shape))
-    for kind in ("textbook", "reference"):
-        (la, ga, wa), (lb, gb, wb) = out[kind, "lean"], out[kind, "plain"]
+                l = b.dqn_fit_reference(w_d, m_d, v_d, 1, 1e-4, rows_n, rows_d.ptr, bp_d.ptr, bn_d.ptr, 0.9, g_d)
+            out[kind, rows_n, form] = (l, g_d.download(np.float32, w.shape).astype(np.float64), w_d.download(np.float32, w.shape))
+    for kind, rows_n in cases:
+        (la, ga, wa), (lb, gb, wb) = out[kind, rows_n, "lean"], out[kind, rows_n, "plain"]
         assert np.isfinite(ga).all() and np.abs(ga).max() > 0
-        assert abs(la[0] - lb[0]) <= 1e-5 * max(1.0, abs(lb[0])) and abs(la[1] - lb[1]) <= 1e-5 * abs(lb[1]) + 1e-12, (kind, la, lb)
+        assert abs(la[0] - lb[0]) <= 1e-5 * max(1.0, abs(lb[0])) and abs(la[1] - lb[1]) <= 1e-5 * abs(lb[1]) + 1e-12, (kind, rows_n, la, lb)
         bad = []
         for name, (o, shp) in shapes.items():
             c = int(np.prod(shp))
             layer, what = name.split(".")
             if what in ("mean", "var"):      # moved by the batch statistics of the fit
-                np.testing.assert_allclose(wa[o:o + c], wb[o:o + c], rtol=1e-5, atol=1e-7, err_msg=kind + " " + name)
+                np.testing.assert_allclose(wa[o:o + c], wb[o:o + c], rtol=1e-5, atol=1e-7, err_msg="%s %d %s" % (kind, rows_n, name))
                 continue
             ko, kshp = shapes[layer + ".kernel"]
             kscale = float(np.abs(gb[ko:ko + int(np.prod(kshp))]).max())
@@ -274,7 +277,7 @@ def test_lean_fit_equals_plain_fit():
             # ReLU within rounding of zero may be gated differently - the same allowance as against float64
             if err > 1e-4 * scale + 5e-5 * kscale:
                 bad.append((name, scale, err))
-        assert not bad, (kind, bad)
+        assert not bad, (kind, rows_n, bad)
     b.close()
 
 
