@@ -554,6 +554,15 @@ __global__ __launch_bounds__(256, 2) void f_b1_up(int n, int h, int w, const flo
   const int tid = threadIdx.x, r = tid / U_TW, q = tid - r * U_TW;
   const int tx_n = (w + U_TW - 1) / U_TW, ty_n = (h + TRL - 1) / TRL, per_s = tx_n * ty_n;
   const long ntiles = (long)n * per_s;
+  // few weights (9 C CON <= 72): kept in registers for the whole kernel instead of re-read from LDS per position
+  constexpr bool WREG = 9 * C * CON <= 72;
+  float wreg[WREG ? 9 * CON : 1][C];
+  if constexpr (WREG) {
+#pragma unroll
+    for (int k = 0; k < 9 * CON; k++)
+#pragma unroll
+      for (int c = 0; c < C; c++) wreg[k][c] = wn[((k / CON) * C + c) * CON + k % CON];
+  }
   double s1[C], s2[C];
   float rsv[C];
 #pragma unroll
@@ -583,6 +592,12 @@ __global__ __launch_bounds__(256, 2) void f_b1_up(int n, int h, int w, const flo
       float acc[C];
 #pragma unroll
       for (int c = 0; c < C; c++) acc[c] = 0.f;
+      if constexpr (WREG) {
+#pragma unroll
+        for (int co = 0; co < CON; co++)
+#pragma unroll
+          for (int t = 0; t < 9; t++) fma_row<C>(acc, dzt[co][i - t / 3 + 2][j - t % 3 + 2], wreg[t * CON + co]);
+      } else
 #pragma unroll 1
       for (int co = 0; co < CON; co++)
 #pragma unroll
@@ -613,11 +628,12 @@ __global__ __launch_bounds__(256, 2) void f_b1_up(int n, int h, int w, const flo
 #pragma unroll
     for (int c = 0; c < C; c++) {
       float acc = 0.f;
+      // up-res row / column 2 y - 2 never has y among its taps (either convention): index 0 of the 5-window is skipped
 #pragma unroll
-      for (int ky = 0; ky < 5; ky++) {
+      for (int ky = 1; ky < 5; ky++) {
         float row = 0.f;
 #pragma unroll
-        for (int kx = 0; kx < 5; kx++) row = fmaf(cx[kx], du[c][2 * r + ky][2 * q + kx], row);
+        for (int kx = 1; kx < 5; kx++) row = fmaf(cx[kx], du[c][2 * r + ky][2 * q + kx], row);
         acc = fmaf(cy[ky], row, acc);
       }
       const size_t at = ((s * C + c) * (size_t)h + y) * w + x;
