@@ -103,6 +103,12 @@ __device__ __forceinline__ float src_value(const FitSrc &S, size_t s, int c, int
 // or three workgroups per CU nothing hides ~2 us of HBM latency per iteration (the first lean build spent 38 000 cycles
 // on a tile that holds 4 000 cycles of instructions).
 constexpr int FILL_U = 8;
+#ifndef OFX_FIT_SW
+#define OFX_FIT_SW 1
+#endif
+#ifndef OFX_FIT_ABLATE   /* diagnostic builds only: 1 = no tile fill, 2 = no tile compute in f_conv_fwd / f_bw (wrong results) */
+#define OFX_FIT_ABLATE 0
+#endif
 
 // The input tile of a convolution: in[CI][TR + 2][LP] <- source values of rows y0 - 1 .. y0 + TR, columns x0 - 1 ..
 // x0 + TW (zero outside the plane).  Up-sampling sources first stage the low-res activation they interpolate
@@ -115,7 +121,26 @@ template <int SRC, int CI, int TR, int TW> constexpr int lo_floats = src_is_up<S
 template <int SRC, int CI, int TR, int TW, int LP, int NT, int FU = 8, bool STAGE = true>
 __device__ __forceinline__ void fill_input(float (*in)[TR + 2][LP], float *lo, const FitSrc &S, size_t s, int y0, int x0,
                                            int H, int W, int tid) {
-  if constexpr (SRC == OFX_FIT_SRC_POOL) {
+  if constexpr (SRC == OFX_FIT_SRC_ACTREP) {
+    // rows of the plane itself: one element at either end of a tile row, TW / 4 aligned 16-byte loads between them
+    // (element-wise this fill was 79 % of the phase-form output convolution: tools/fit_ablate.sh)
+    static_assert(TW % 4 == 0, "tile width");
+    constexpr int ST = TW / 4 + 2;
+    const float *zp = reinterpret_cast<const float *>(S.p);
+    for (int e = tid; e < CI * (TR + 2) * ST; e += NT) {
+      const int c = e / ((TR + 2) * ST), rem = e - c * ((TR + 2) * ST), yy = rem / ST, st = rem - yy * ST;
+      const int yc = min(max(y0 - 1 + yy, 0), H - 1);
+      const float sc = S.act[2 * c], sh = S.act[2 * c + 1];
+      const float *zr = zp + ((s * CI + c) * (size_t)H + yc) * W;
+      if (st == 0) in[c][yy][0] = bn_act(zr[max(x0 - 1, 0)], sc, sh);
+      else if (st == ST - 1) in[c][yy][TW + 1] = bn_act(zr[min(x0 + TW, W - 1)], sc, sh);
+      else {
+        const float4 v = *reinterpret_cast<const float4 *>(zr + x0 + 4 * (st - 1));
+        float *o = &in[c][yy][1 + 4 * (st - 1)];
+        o[0] = bn_act(v.x, sc, sh); o[1] = bn_act(v.y, sc, sh); o[2] = bn_act(v.z, sc, sh); o[3] = bn_act(v.w, sc, sh);
+      }
+    }
+  } else if constexpr (SRC == OFX_FIT_SRC_POOL) {
     // two pooled pixels per step from two 16-byte loads (tile column 0 is an odd plane column: one single step at either
     // end of a row, TW / 2 pairs between them)
     static_assert(TW % 2 == 0, "tile width");
@@ -281,9 +306,17 @@ __global__ __launch_bounds__(256, 3) void f_conv_fwd(int n, int H, int W, FitSrc
     const size_t s = tile / per_s;
     const int t = (int)(tile - (long)s * per_s), y0 = (t / tx_n) * F_TR, x0 = (t % tx_n) * TW;
     __syncthreads();
-    fill_input<SRC, CI, F_TR, TW, LP, 256>(in, lo, S, s, y0, x0, H, W, tid);
+    if (OFX_FIT_ABLATE != 1) fill_input<SRC, CI, F_TR, TW, LP, 256>(in, lo, S, s, y0, x0, H, W, tid);
     __syncthreads();
-    if (!active) continue;
+    if (!active || OFX_FIT_ABLATE == 2) continue;
+#if OFX_FIT_SW
+    // weights through the scalar cache (s_load, an SGPR pair per v_pk_fma_f32): 18 broadcast ds_read_b128 per input channel
+    // kept the LDS return path busier than the vector ALU.  The offset the compiler cannot see through keeps the loads
+    // inside the tile loop (hoisted, all 9 CI CO of them would sit in vector registers).
+    int zoff;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(zoff));
+    const float *__restrict__ wt = w + zoff;
+#endif
     float acc[4][CO];
 #pragma unroll
     for (int co = 0; co < CO; co++) {
@@ -302,7 +335,12 @@ __global__ __launch_bounds__(256, 3) void f_conv_fwd(int n, int H, int W, FitSrc
 #pragma unroll
         for (int kx = 0; kx < 3; kx++) {
           float wv[CO];
+#if OFX_FIT_SW
+#pragma unroll
+          for (int co = 0; co < CO; co++) wv[co] = wt[((ky * 3 + kx) * CI + ci) * CO + co];
+#else
           lds_vec<CO>(&wl[((ky * 3 + kx) * CI + ci) * CO], wv);
+#endif
 #pragma unroll
           for (int px = 0; px < 4; px++) fma_row<CO>(acc[px], v[px + kx], wv);
         }
