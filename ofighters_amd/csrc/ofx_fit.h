@@ -8,12 +8,14 @@
 #define OFX_FIT_SRC_POOL 1   /* pool2(relu(bn(z_prev)))          (trunk) */
 #define OFX_FIT_SRC_UP 2     /* up2(relu(bn(z_prev)))            (head 2) */
 #define OFX_FIT_SRC_UPRAW 3  /* up2(u0), u0 already behind its ReLU */
+#define OFX_FIT_SRC_PLANE 5  /* a stored plane as it is, zero outside (the pooled activation kept by the forward) */
 #define OFX_FIT_SRC_ACTREP 4 /* relu(bn(z_prev)) at its own resolution, edge cells repeated outwards (phase form) */
 
 #define OFX_FIT_MAX_BLOCKS 2048 /* persistent grids: at most this many blocks, each with one row of partial sums */
 
 struct ofx_fit_src {
   int kind;
+  float *keep;        // POOL in ofx_fit_conv_fwd: also store the pooled activation [n][C][H][W] here (null: do not)
   const void *p;      // bits [n][C][5000] or the producing layer's z [n][C][h][w]
   const float *act;   // the producing layer's {scale, shift} per channel; null for bits / raw
   int h, w;           // dims of p's planes

@@ -59,6 +59,8 @@ __device__ __forceinline__ void fit_up_taps(int u, int n, int &i0, int &i1, floa
 }
 
 struct FitSrc {
+  float *keep;        // POOL in f_conv_fwd: where the pooled activation [n][C][H][W] is written (the weight gradient reads it
+                      // back through the PLANE source instead of pooling four times the bytes of z again); may be null
   const void *p;      // bits [n][C][5000] or the producing layer's z [n][C][h][w]
   const float *act;   // the producing layer's {scale, shift} per channel (relu(z * scale + shift)); unused for bits / raw
   int h, w;           // dims of p's planes
@@ -73,6 +75,7 @@ __device__ __forceinline__ float src_value(const FitSrc &S, size_t s, int c, int
     return bn_act(reinterpret_cast<const float *>(S.p)[((s * C + c) * (size_t)H + yc) * W + xc], S.act[2 * c], S.act[2 * c + 1]);
   }
   if (y < 0 || y >= H || x < 0 || x >= W) return 0.f;
+  if constexpr (SRC == OFX_FIT_SRC_PLANE) return reinterpret_cast<const float *>(S.p)[((s * C + c) * (size_t)H + y) * W + x];
   if constexpr (SRC == OFX_FIT_SRC_BITS) {
     const uint32_t *b = reinterpret_cast<const uint32_t *>(S.p) + (s * C + c) * (size_t)((H * W) >> 5);
     const int p = y * W + x;
@@ -138,6 +141,24 @@ __device__ __forceinline__ void fill_input(float (*in)[TR + 2][LP], float *lo, c
         const float4 v = *reinterpret_cast<const float4 *>(zr + x0 + 4 * (st - 1));
         float *o = &in[c][yy][1 + 4 * (st - 1)];
         o[0] = bn_act(v.x, sc, sh); o[1] = bn_act(v.y, sc, sh); o[2] = bn_act(v.z, sc, sh); o[3] = bn_act(v.w, sc, sh);
+      }
+    }
+  } else if constexpr (SRC == OFX_FIT_SRC_PLANE && TW % 4 == 0) {
+    // a stored plane as it is (zero outside): one element at either end of a tile row, 16-byte loads between them
+    constexpr int ST = TW / 4 + 2;
+    const float *zp = reinterpret_cast<const float *>(S.p);
+    for (int e = tid; e < CI * (TR + 2) * ST; e += NT) {
+      const int c = e / ((TR + 2) * ST), rem = e - c * ((TR + 2) * ST), yy = rem / ST, st = rem - yy * ST;
+      const int y = y0 - 1 + yy;
+      const bool row = y >= 0 && y < H;
+      const float *zr = zp + ((s * CI + c) * (size_t)H + (row ? y : 0)) * W;
+      if (st == 0) in[c][yy][0] = (row && x0 > 0) ? zr[x0 - 1] : 0.f;
+      else if (st == ST - 1) in[c][yy][TW + 1] = (row && x0 + TW < W) ? zr[x0 + TW] : 0.f;
+      else {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row) v = *reinterpret_cast<const float4 *>(zr + x0 + 4 * (st - 1));
+        float *o = &in[c][yy][1 + 4 * (st - 1)];
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
       }
     }
   } else if constexpr (SRC == OFX_FIT_SRC_POOL) {
@@ -308,6 +329,18 @@ __global__ __launch_bounds__(256, 3) void f_conv_fwd(int n, int H, int W, FitSrc
     __syncthreads();
     if (OFX_FIT_ABLATE != 1) fill_input<SRC, CI, F_TR, TW, LP, 256>(in, lo, S, s, y0, x0, H, W, tid);
     __syncthreads();
+    if constexpr (SRC == OFX_FIT_SRC_POOL) {
+      if (S.keep) {   // block-uniform: the tile's own pixels of the pooled activation, once
+        constexpr int V = TW % 4 == 0 ? 4 : 2, TWV = TW / V;
+        for (int e = tid; e < CI * F_TR * TWV; e += 256) {
+          const int c = e / (F_TR * TWV), rem = e - c * (F_TR * TWV), yy = rem / TWV, xv = rem - yy * TWV;
+          const float *q = &in[c][yy + 1][1 + V * xv];
+          float *o = S.keep + ((s * CI + c) * (size_t)H + y0 + yy) * W + x0 + V * xv;
+          if constexpr (V == 4) *reinterpret_cast<float4 *>(o) = make_float4(q[0], q[1], q[2], q[3]);
+          else *reinterpret_cast<float2 *>(o) = make_float2(q[0], q[1]);
+        }
+      }
+    }
     if (!active || OFX_FIT_ABLATE == 2) continue;
 #if OFX_FIT_SW
     // weights through the scalar cache (s_load, an SGPR pair per v_pk_fma_f32): 18 broadcast ds_read_b128 per input channel
@@ -1088,7 +1121,7 @@ __global__ void f_out_bw_finish(const double *q, const double *fr, int legacy, f
   }
 }
 
-FitSrc dev_src(const ofx_fit_src &s) { return FitSrc{s.p, s.act, s.h, s.w, s.legacy}; }
+FitSrc dev_src(const ofx_fit_src &s) { return FitSrc{s.keep, s.p, s.act, s.h, s.w, s.legacy}; }
 int grid_for(long ntiles, int cap) { return (int)(ntiles < cap ? ntiles : cap); }
 
 }  // namespace
@@ -1181,6 +1214,8 @@ int ofx_fit_bw(hipStream_t st, int n, int ci, int co, int H, int W, const ofx_fi
   BWK(2, 8, OFX_FIT_SRC_BITS, 100, true, OFX_FIT_BW_NT, OFX_FIT_BW_TR)
   BWK(8, 8, OFX_FIT_SRC_POOL, 100, true, 512, 8)
   BWK(8, 8, OFX_FIT_SRC_POOL, 50, true, 512, 8)
+  BWK(8, 8, OFX_FIT_SRC_PLANE, 100, true, 512, 8)
+  BWK(8, 8, OFX_FIT_SRC_PLANE, 50, true, 512, 8)
   BWK(4, 8, OFX_FIT_SRC_UP, 100, true, OFX_FIT_BW_NT, OFX_FIT_BW_TR)
 #undef BWK
 #define BWS(CI_, CO_, SRC_, TW_, BN_) \

@@ -624,6 +624,7 @@ static int dqn_fit_lean(ofx_handle *h, float *weights, float *adam_m, float *ada
   size_t need = 0;
   auto sz = [&](size_t bytes) { need += (bytes + 255) & ~(size_t)255; };
   for (int i = 0; i < 4; i++) { sz(4 * N * 8 * tS[i] * tS[i]); sz(4 * N * 8 * tS[i] * tS[i]); }        // z, g
+  for (int i = 0; i < 3; i++) sz(4 * N * 8 * tS[i + 1] * tS[i + 1]);                                       // pooled activation
   for (int j = 0; j < 3; j++) { sz(4 * N * kUO[j] * uS[j] * uS[j]); sz(4 * N * kUO[j] * uS[j] * uS[j]); }
   sz(4 * N * 160000); sz(4 * N * 160000);                                                                  // o2, do2
   sz(4 * N * 5000); sz(4 * N * 5008); sz(4 * N * 100); sz(4 * N * 50); sz(4 * N * 2); sz(4 * N * 625);      // p3 f d1 d2 o1 u0
@@ -643,7 +644,8 @@ static int dqn_fit_lean(ofx_handle *h, float *weights, float *adam_m, float *ada
   double *part = A.d(ofx_fit_part_doubles()), *sums = A.d(32);
   float *weff = A.f(ofx_fit_out_floats());
   double *fpart = A.d(ofx_fit_out_doubles(n));
-  float *tz[4], *tg[4], *tstat[4], *tact[4], *uz[3], *ug[3], *ustat[3], *uact[3];
+  float *tz[4], *tg[4], *tstat[4], *tact[4], *uz[3], *ug[3], *ustat[3], *uact[3], *tp[3];
+  for (int i = 0; i < 3; i++) tp[i] = A.f(N * 8 * tS[i + 1] * tS[i + 1]);
   for (int i = 0; i < 4; i++) { tz[i] = A.f(N * 8 * tS[i] * tS[i]); tg[i] = A.f(N * 8 * tS[i] * tS[i]); tstat[i] = A.f(16); tact[i] = A.f(16); }
   for (int j = 0; j < 3; j++) { uz[j] = A.f(N * kUO[j] * uS[j] * uS[j]); ug[j] = A.f(N * kUO[j] * uS[j] * uS[j]); ustat[j] = A.f(16); uact[j] = A.f(16); }
   float *o2 = A.f(N * 160000), *do2 = A.f(N * 160000);
@@ -651,19 +653,22 @@ static int dqn_fit_lean(ofx_handle *h, float *weights, float *adam_m, float *ada
   float *gu0 = A.f(N * 625), *do1 = A.f(N * 2), *dd1 = A.f(N * 100), *dd2 = A.f(N * 50), *df = A.f(N * 5008), *dp3 = A.f(N * 5000);
   if (A.over) { ofx_set_error("ofx_dqn_fit: internal workspace sized too small"); return OFX_ERR_STATE; }
   int nb = 0;
-  auto trunk_src = [&](int i) {  // input of trunk layer i
-    return i == 0 ? ofx_fit_src{OFX_FIT_SRC_BITS, bits_prev, nullptr, 400, 400, legacy}
-                  : ofx_fit_src{OFX_FIT_SRC_POOL, tz[i - 1], tact[i - 1], tS[i - 1], tS[i - 1], legacy};
+  // input of trunk layer i: the forward pools the previous layer's z on the fly and KEEPS the pooled activation (a quarter
+  // of z's bytes); the weight gradient reads that plane back instead of pooling z a second time
+  auto trunk_src = [&](int i, bool backward) {
+    if (i == 0) return ofx_fit_src{OFX_FIT_SRC_BITS, nullptr, bits_prev, nullptr, 400, 400, legacy};
+    if (backward) return ofx_fit_src{OFX_FIT_SRC_PLANE, nullptr, tp[i - 1], nullptr, tS[i], tS[i], legacy};
+    return ofx_fit_src{OFX_FIT_SRC_POOL, tp[i - 1], tz[i - 1], tact[i - 1], tS[i - 1], tS[i - 1], legacy};
   };
   auto head_src = [&](int j) {   // input of head-2 layer j (3 = the output convolution)
-    return j == 0 ? ofx_fit_src{OFX_FIT_SRC_UPRAW, u0, nullptr, 25, 25, legacy}
-                  : ofx_fit_src{OFX_FIT_SRC_UP, uz[j - 1], uact[j - 1], uS[j - 1], uS[j - 1], legacy};
+    return j == 0 ? ofx_fit_src{OFX_FIT_SRC_UPRAW, nullptr, u0, nullptr, 25, 25, legacy}
+                  : ofx_fit_src{OFX_FIT_SRC_UP, nullptr, uz[j - 1], uact[j - 1], uS[j - 1], uS[j - 1], legacy};
   };
 
   // ---- forward (training mode) ----
   for (int i = 0; i < 4; i++) {
     const int s = tS[i];
-    if ((rc = ofx_fit_conv_fwd(st, n, kTI[i], 8, s, s, trunk_src(i), T(6 * i), T(6 * i + 1), tz[i], part, &nb))) return rc;
+    if ((rc = ofx_fit_conv_fwd(st, n, kTI[i], 8, s, s, trunk_src(i, false), T(6 * i), T(6 * i + 1), tz[i], part, &nb))) return rc;
     if ((rc = ofx_fit_finish(st, nb, 8, (double)N * s * s, part, T(6 * i + 2), T(6 * i + 3), nullptr, tstat[i], tact[i]))) return rc;
   }
   if ((rc = ofx_fit_pool_act(st, n, 8, 50, 50, tz[3], tact[3], p3))) return rc;
@@ -725,7 +730,7 @@ static int dqn_fit_lean(ofx_handle *h, float *weights, float *adam_m, float *ada
     const int s = tS[i];
     if ((rc = ofx_fit_b1_pool(st, n, s, s, i < 3, dzn, i < 3 ? T(6 * (i + 1)) : nullptr, tz[i], tstat[i], tact[i], tg[i], part, &nb))) return rc;
     if ((rc = ofx_fit_finish(st, nb, 8, 1.0, part, nullptr, nullptr, sums, nullptr, nullptr))) return rc;
-    if ((rc = ofx_fit_bw(st, n, kTI[i], 8, s, s, trunk_src(i), 1, tg[i], tz[i], tstat[i], T(6 * i + 2), sums, part,
+    if ((rc = ofx_fit_bw(st, n, kTI[i], 8, s, s, trunk_src(i, true), 1, tg[i], tz[i], tstat[i], T(6 * i + 2), sums, part,
                          G(6 * i), G(6 * i + 1), G(6 * i + 2), G(6 * i + 3)))) return rc;
     dzn = tg[i];
   }
