@@ -32,8 +32,14 @@ int ofx_fit_finish(hipStream_t st, int nblocks, int c_n, double count, const dou
 int ofx_fit_pool_act(hipStream_t st, int n, int C, int H, int W, const float *z, const float *act, float *p);
 // g = d loss / d (BN output of the layer), ReLU-masked, through the pooling in front of the next convolution
 // (conv: dzn = that convolution's dz [n][8][H/2][W/2], wn its kernel; else dzn = d pooled output)
+// conv = 2 (the first layer): g is written compact - the one non-zero of every 2 x 2 window [n][8][H/2][W/2] - with the
+// window position of the maximum in kk (one byte per window), for ofx_fit_bw_first
 int ofx_fit_b1_pool(hipStream_t st, int n, int H, int W, int conv, const float *dzn, const float *wn, const float *z,
-                    const float *stat, const float *act, float *g, double *part, int *nblocks);
+                    const float *stat, const float *act, float *g, double *part, int *nblocks, unsigned char *kk = nullptr);
+size_t ofx_fit_first_doubles(int n);
+int ofx_fit_bw_first(hipStream_t st, int n, const void *bits, const float *gc, const unsigned char *kk, const float *w,
+                     const float *b, const float *stat, const float *gamma, const double *sums, double *part,
+                     double *cpart, float *dw, float *db, float *dgamma, float *dbeta);
 // the same through the x2 up-sampling in front of a convolution with `con` output channels at 2h x 2w
 int ofx_fit_b1_up(hipStream_t st, int n, int c, int con, int h, int w, int bn, const float *dzn, const float *wn,
                   const float *zp, const float *stat, const float *act, int legacy, float *g, double *part, int *nblocks);

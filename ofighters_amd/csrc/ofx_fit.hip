@@ -469,11 +469,14 @@ __global__ void f_pool_act(int n, int C, int H, int W, const float *z, const flo
 // dp given (the last trunk layer: the dense head's gradient); g = dp at the first maximum of each 2 x 2 window of
 // a = relu(bn(z)) where that maximum is positive, zero elsewhere; part[block] = {sum g, sum g xhat} per channel.
 constexpr int P_TR = 10, P_TW = 50;
-template <bool CONV>
+// COMPACT (the first layer): g has ONE non-zero per 2 x 2 window; it is stored as that value [n][8][H/2][W/2] (in g) plus the
+// window position 0..3 of the maximum (kk, one byte per window) - 1.6 MB per row instead of 5.12 MB, for f_bw_first.
+template <bool CONV, bool COMPACT = false>
 __global__ __launch_bounds__(256, 3) void f_b1_pool(int n, int H, int W, const float *__restrict__ dzn,
                                                  const float *__restrict__ wn, const float *__restrict__ z,
                                                  const float *__restrict__ stat, const float *__restrict__ act,
-                                                 float *__restrict__ g, double *__restrict__ part) {
+                                                 float *__restrict__ g, double *__restrict__ part,
+                                                 unsigned char *__restrict__ kk) {
   constexpr int C = 8, LP = P_TW + 4;
   __shared__ __align__(16) float dzt[CONV ? C : 1][P_TR + 2][LP];
   __shared__ __align__(16) float wl[CONV ? 9 * C * C : 4];   // [tap][co][ci]: the C input channels of one read contiguous
@@ -561,6 +564,8 @@ __global__ __launch_bounds__(256, 3) void f_b1_pool(int n, int H, int W, const f
         }
       }
       float o[2][4];
+      float gcv[2] = {0.f, 0.f};
+      int kcv[2] = {0, 0};
 #pragma unroll
       for (int j = 0; j < 2; j++) {
         const float zv[4] = {zr[0][2 * j], zr[0][2 * j + 1], zr[1][2 * j], zr[1][2 * j + 1]};
@@ -575,10 +580,20 @@ __global__ __launch_bounds__(256, 3) void f_b1_pool(int n, int H, int W, const f
         const float gv = (av[k] > 0.f && (j == 0 || both)) ? d : 0.f;
         o[0][2 * j] = k == 0 ? gv : 0.f; o[0][2 * j + 1] = k == 1 ? gv : 0.f;
         o[1][2 * j] = k == 2 ? gv : 0.f; o[1][2 * j + 1] = k == 3 ? gv : 0.f;
+        gcv[j] = gv; kcv[j] = k;
         s1[ci] += (double)gv;
         s2[ci] += (double)(gv * ((zv[k] - mean) * rs));
       }
-      if (vec) {
+      if constexpr (COMPACT) {
+        const size_t at = ((s * C + ci) * (size_t)Hp + yp) * Wp + xp;   // xp even, Wp even: 8-byte aligned
+        if (both) {
+          *reinterpret_cast<float2 *>(g + at) = make_float2(gcv[0], gcv[1]);
+          *reinterpret_cast<uchar2 *>(kk + at) = make_uchar2((unsigned char)kcv[0], (unsigned char)kcv[1]);
+        } else {
+          g[at] = gcv[0];
+          kk[at] = (unsigned char)kcv[0];
+        }
+      } else if (vec) {
         *reinterpret_cast<float4 *>(g + base) = make_float4(o[0][0], o[0][1], o[0][2], o[0][3]);
         *reinterpret_cast<float4 *>(g + base + W) = make_float4(o[1][0], o[1][1], o[1][2], o[1][3]);
       } else {
@@ -1121,6 +1136,130 @@ __global__ void f_out_bw_finish(const double *q, const double *fr, int legacy, f
   }
 }
 
+// ---------------------------------------------------------------- the first layer's weight gradient without z0 and without dz0
+// Layer 0 reads 1-bit maps, and BatchNorm's backward is affine in g and z:  dz = a (g - m0 - (z - mean) c)  gives
+//   dW[u][co] = sum_p in_u[p] dz[co][p] = a_co ( A[u][co] - m0_co B[u] - c_co ( T[u][co] - mean_co B[u] ) ),  u = (tap, ci),
+//   A = sum in_u g,   B[u] = sum in_u,   T[u][co] = sum in_u z[co] = b_co B[u] + sum_u' w[u'][co] Cc[u][u'],
+//   Cc[u][u'] = sum_p in_u[p] in_u'[p]  - the autocorrelation of the shifted bit maps (popcounts; B is its diagonal).
+// So the 5.12 MB per row of z0 are not read again, dz0 is never formed, and g0 arrives compact (f_b1_pool COMPACT): the
+// kernel that moved 27 GB per 2048 rows moves 3.  The bias gradient of a convolution in front of BatchNorm is exactly 0.
+constexpr int C0_ROWS = 40;   // rows of a correlation chunk
+// part[block][324]: Cc over the block's rows of one sample; block = 384 threads, thread q < 324 owns the pair (q / 18, q % 18)
+__global__ __launch_bounds__(384) void f_bits_corr(int n, const uint32_t *__restrict__ bits, double *__restrict__ part) {
+  __shared__ uint32_t ver[18][13];   // the 18 shifted versions of image row y: bit x of version u = in_u at pixel (y, x)
+  const int s = blockIdx.x / (400 / C0_ROWS), y0 = (blockIdx.x % (400 / C0_ROWS)) * C0_ROWS;
+  const int tid = threadIdx.x, ua = tid / 18, ub = tid - 18 * ua;
+  int acc = 0;
+  for (int y = y0; y < y0 + C0_ROWS; y++) {
+    __syncthreads();
+    for (int e = tid; e < 18 * 13; e += 384) {
+      const int u = e / 13, wd = e - 13 * u, tap = u >> 1, ci = u & 1, r = y + tap / 3 - 1, dx = tap % 3 - 1;
+      uint32_t v = 0;
+      if (r >= 0 && r < 400) {
+        const uint32_t *pl = bits + ((size_t)s * 2 + ci) * 5000;
+        const int x0 = 32 * wd + dx;                     // plane column of the version's bit 0 of this word
+        const long b0 = 400L * r + x0;                   // its bit position in the plane (may be -1 at x0 = -1)
+        const long bb = b0 < 0 ? 0 : b0;
+        const int wi = (int)(bb >> 5), sh = (int)(bb & 31);
+        const uint32_t lo = pl[wi], hi = wi + 1 < 5000 ? pl[wi + 1] : 0u;
+        v = sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
+        if (b0 < 0) v <<= 1;                             // column -1 does not exist: bit 0 of the word is pixel column 0's left
+        // keep the bits whose column x0 + b lies in [0, 400)
+        uint32_t m = 0xFFFFFFFFu;
+        if (x0 < 0) m &= ~1u;
+        const int over = x0 + 32 - 400;
+        if (over > 0) m &= over >= 32 ? 0u : (0xFFFFFFFFu >> over);
+        if (wd == 12) m &= 0xFFFFu;                      // ... and whose OUTPUT pixel 32 wd + b lies in the row (400 = 12.5 words)
+        v &= m;
+      }
+      ver[u][wd] = v;
+    }
+    __syncthreads();
+    if (tid < 324) {
+#pragma unroll
+      for (int wd = 0; wd < 13; wd++) acc += __popc(ver[ua][wd] & ver[ub][wd]);
+    }
+  }
+  if (tid < 324) part[(size_t)blockIdx.x * 324 + tid] = (double)acc;
+}
+
+// A[tap][ci][co] = sum in_u g and sum g per co from the compact g: a wave owns an output channel, a lane a pooled pixel
+constexpr int B0_TR = 40;   // image rows of a tile (20 pooled rows x 50 pooled columns = 1000 windows)
+__global__ __launch_bounds__(512) void f_bw_first(int n, const uint32_t *__restrict__ bits, const float *__restrict__ gc,
+                                                  const unsigned char *__restrict__ kk, double *__restrict__ part) {
+  constexpr int TW = 100, LP = TW + 2, NA = 19, NPX = (B0_TR / 2) * (TW / 2), NGRP = (NPX + 63) / 64;
+  __shared__ float in[2][B0_TR + 2][LP];
+  __shared__ double dacc[8][NA];
+  const int tid = threadIdx.x, co = tid >> 6, lane = tid & 63;
+  const int H = 400, W = 400, Hp = 200, Wp = 200, tx_n = W / TW, ty_n = H / B0_TR, per_s = tx_n * ty_n;
+  const long ntiles = (long)n * per_s;
+  FitSrc S{nullptr, bits, nullptr, 400, 400, 0};
+  float acc[NA];
+#pragma unroll
+  for (int k = 0; k < NA; k++) acc[k] = 0.f;
+  if (lane < NA) dacc[co][lane] = 0.0;
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const size_t s = tile / per_s;
+    const int t = (int)(tile - (long)s * per_s), y0 = (t / tx_n) * B0_TR, x0 = (t % tx_n) * TW;
+    __syncthreads();
+    for (int e = tid; e < 2 * (B0_TR + 2) * (TW + 2); e += 512) {
+      const int c = e / ((B0_TR + 2) * (TW + 2)), rem = e - c * ((B0_TR + 2) * (TW + 2));
+      const int yy = rem / (TW + 2), xx = rem - yy * (TW + 2);
+      in[c][yy][xx] = src_value<OFX_FIT_SRC_BITS, 2>(S, s, c, y0 - 1 + yy, x0 - 1 + xx, H, W);
+    }
+    __syncthreads();
+    for (int grp = 0; grp < NGRP; grp++) {
+      const int p = 64 * grp + lane;
+      if (p < NPX) {
+        const int pr = p / (TW / 2), pc = p - pr * (TW / 2);
+        const size_t at = ((s * 8 + co) * (size_t)Hp + y0 / 2 + pr) * Wp + x0 / 2 + pc;
+        const float gv = gc[at];
+        const int k = kk[at];
+        const int yy = 2 * pr + (k >> 1), xx = 2 * pc + (k & 1);   // the window's maximum, tile coordinates of the pixel
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+          acc[2 * tap] = fmaf(in[0][yy + tap / 3][xx + tap % 3], gv, acc[2 * tap]);
+          acc[2 * tap + 1] = fmaf(in[1][yy + tap / 3][xx + tap % 3], gv, acc[2 * tap + 1]);
+        }
+        acc[18] += gv;
+      }
+    }
+    // one flush per tile: 1000 windows = 16 terms per lane and sum
+#pragma unroll
+    for (int k = 0; k < NA; k++) {
+      const float v = wave_sum(acc[k]);
+      if (lane == 0) dacc[co][k] += (double)v;
+      acc[k] = 0.f;
+    }
+  }
+  __syncthreads();
+  // part[block] = A as [tap][ci][co] (144), then sum g [co] (8)
+  if (tid < 152) {
+    const int c = tid < 144 ? tid % 8 : tid - 144, u = tid < 144 ? tid / 8 : 18;
+    part[(size_t)blockIdx.x * 152 + tid] = dacc[c][u];
+  }
+}
+// q[152] = A, sum g; cc[324] = the autocorrelation:  dw, db, dgamma, dbeta of the first layer (see above)
+__global__ void f_bw_first_finish(const double *q, const double *cc, const float *w, const float *b, const float *stat,
+                                  const float *gamma, const double *sums, double count, float *dw, float *db, float *dgamma,
+                                  float *dbeta) {
+  const int k = threadIdx.x;
+  if (k < 144) {
+    const int co = k % 8, u = k / 8;
+    const double rs = 1.0 / sqrt((double)stat[2 * co + 1] + 1e-3), a = (double)gamma[co] * rs;
+    const double m0 = sums[2 * co] / count, c = rs * (sums[2 * co + 1] / count), mean = stat[2 * co];
+    const double Bu = cc[u * 18 + u];
+    double T = (double)b[co] * Bu;
+    for (int v = 0; v < 18; v++) T += (double)w[v * 8 + co] * cc[u * 18 + v];
+    dw[k] = (float)(a * (q[k] - m0 * Bu - c * (T - mean * Bu)));
+  } else if (k < 152) {
+    const int co = k - 144;
+    db[co] = 0.f;
+    dbeta[co] = (float)sums[2 * co];
+    dgamma[co] = (float)sums[2 * co + 1];
+  }
+}
+
 FitSrc dev_src(const ofx_fit_src &s) { return FitSrc{s.keep, s.p, s.act, s.h, s.w, s.legacy}; }
 int grid_for(long ntiles, int cap) { return (int)(ntiles < cap ? ntiles : cap); }
 
@@ -1166,13 +1305,14 @@ int ofx_fit_pool_act(hipStream_t st, int n, int C, int H, int W, const float *z,
 }
 
 int ofx_fit_b1_pool(hipStream_t st, int n, int H, int W, int conv, const float *dzn, const float *wn, const float *z,
-                    const float *stat, const float *act, float *g, double *part, int *nblocks) {
+                    const float *stat, const float *act, float *g, double *part, int *nblocks, unsigned char *kk) {
   const int Hp = H / 2, Wp = W / 2;
   const long ntiles = (long)n * ((Hp + P_TR - 1) / P_TR) * ((Wp + P_TW - 1) / P_TW);
   const int grid = grid_for(ntiles, OFX_FIT_MAX_BLOCKS);
   *nblocks = grid;
-  if (conv) hipLaunchKernelGGL(f_b1_pool<true>, dim3(grid), dim3(256), 0, st, n, H, W, dzn, wn, z, stat, act, g, part);
-  else hipLaunchKernelGGL(f_b1_pool<false>, dim3(grid), dim3(256), 0, st, n, H, W, dzn, wn, z, stat, act, g, part);
+  if (conv == 2) hipLaunchKernelGGL((f_b1_pool<true, true>), dim3(grid), dim3(256), 0, st, n, H, W, dzn, wn, z, stat, act, g, part, kk);
+  else if (conv) hipLaunchKernelGGL(f_b1_pool<true>, dim3(grid), dim3(256), 0, st, n, H, W, dzn, wn, z, stat, act, g, part, kk);
+  else hipLaunchKernelGGL(f_b1_pool<false>, dim3(grid), dim3(256), 0, st, n, H, W, dzn, wn, z, stat, act, g, part, kk);
   OFX_HIP(hipGetLastError());
   return OFX_OK;
 }
@@ -1270,6 +1410,25 @@ int ofx_fit_out_bw(hipStream_t st, int n, const ofx_fit_src &src, const float *d
   hipLaunchKernelGGL(f_sum_rows, dim3((292 + 15) / 16), dim3(256), 0, st, 292, grid, part, q);
   hipLaunchKernelGGL(f_sum_rows, dim3((72 + 15) / 16), dim3(256), 0, st, 72, n, fpart, fr);
   hipLaunchKernelGGL(f_out_bw_finish, dim3(1), dim3(128), 0, st, q, fr, src.legacy, dw, db);
+  OFX_HIP(hipGetLastError());
+  return OFX_OK;
+}
+
+size_t ofx_fit_first_doubles(int n) { return (size_t)n * (400 / C0_ROWS) * 324 + 324 + 152; }
+// dw / db / dgamma / dbeta of the first trunk layer from the compact g (gc, kk: ofx_fit_b1_pool with conv = 2), the 1-bit
+// maps and the layer's own weights; cpart: ofx_fit_first_doubles(n) doubles of scratch
+int ofx_fit_bw_first(hipStream_t st, int n, const void *bits, const float *gc, const unsigned char *kk, const float *w,
+                     const float *b, const float *stat, const float *gamma, const double *sums, double *part,
+                     double *cpart, float *dw, float *db, float *dgamma, float *dbeta) {
+  const int nc = n * (400 / C0_ROWS);
+  double *cc = cpart + (size_t)nc * 324, *q = cc + 324;
+  hipLaunchKernelGGL(f_bits_corr, dim3(nc), dim3(384), 0, st, n, (const uint32_t *)bits, cpart);
+  hipLaunchKernelGGL(f_sum_rows, dim3((324 + 15) / 16), dim3(256), 0, st, 324, nc, cpart, cc);
+  const int grid = grid_for((long)n * (400 / B0_TR) * 4, OFX_FIT_MAX_BLOCKS / 2);
+  hipLaunchKernelGGL(f_bw_first, dim3(grid), dim3(512), 0, st, n, (const uint32_t *)bits, gc, kk, part);
+  hipLaunchKernelGGL(f_sum_rows, dim3((152 + 15) / 16), dim3(256), 0, st, 152, grid, part, q);
+  hipLaunchKernelGGL(f_bw_first_finish, dim3(1), dim3(192), 0, st, q, cc, w, b, stat, gamma, sums, (double)n * 160000.0, dw, db,
+                     dgamma, dbeta);
   OFX_HIP(hipGetLastError());
   return OFX_OK;
 }

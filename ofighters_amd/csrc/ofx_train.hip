@@ -623,7 +623,8 @@ static int dqn_fit_lean(ofx_handle *h, float *weights, float *adam_m, float *ada
   static const int tS[4] = {400, 200, 100, 50}, uS[3] = {50, 100, 200};
   size_t need = 0;
   auto sz = [&](size_t bytes) { need += (bytes + 255) & ~(size_t)255; };
-  for (int i = 0; i < 4; i++) { sz(4 * N * 8 * tS[i] * tS[i]); sz(4 * N * 8 * tS[i] * tS[i]); }        // z, g
+  for (int i = 0; i < 4; i++) { sz(4 * N * 8 * tS[i] * tS[i]); sz(4 * N * 8 * tS[i] * tS[i] / (i ? 1 : 4)); }  // z, g (layer 0: compact)
+  sz(N * 8 * 40000); sz(8 * ofx_fit_first_doubles(n));                                                     // window positions, correlation
   for (int i = 0; i < 3; i++) sz(4 * N * 8 * tS[i + 1] * tS[i + 1]);                                       // pooled activation
   for (int j = 0; j < 3; j++) { sz(4 * N * kUO[j] * uS[j] * uS[j]); sz(4 * N * kUO[j] * uS[j] * uS[j]); }
   sz(4 * N * 160000); sz(4 * N * 160000);                                                                  // o2, do2
@@ -646,7 +647,9 @@ static int dqn_fit_lean(ofx_handle *h, float *weights, float *adam_m, float *ada
   double *fpart = A.d(ofx_fit_out_doubles(n));
   float *tz[4], *tg[4], *tstat[4], *tact[4], *uz[3], *ug[3], *ustat[3], *uact[3], *tp[3];
   for (int i = 0; i < 3; i++) tp[i] = A.f(N * 8 * tS[i + 1] * tS[i + 1]);
-  for (int i = 0; i < 4; i++) { tz[i] = A.f(N * 8 * tS[i] * tS[i]); tg[i] = A.f(N * 8 * tS[i] * tS[i]); tstat[i] = A.f(16); tact[i] = A.f(16); }
+  for (int i = 0; i < 4; i++) { tz[i] = A.f(N * 8 * tS[i] * tS[i]); tg[i] = A.f(N * 8 * tS[i] * tS[i] / (i ? 1 : 4)); tstat[i] = A.f(16); tact[i] = A.f(16); }
+  unsigned char *kk0 = (unsigned char *)A.take(N * 8 * 40000);
+  double *cpart = A.d(ofx_fit_first_doubles(n));
   for (int j = 0; j < 3; j++) { uz[j] = A.f(N * kUO[j] * uS[j] * uS[j]); ug[j] = A.f(N * kUO[j] * uS[j] * uS[j]); ustat[j] = A.f(16); uact[j] = A.f(16); }
   float *o2 = A.f(N * 160000), *do2 = A.f(N * 160000);
   float *p3 = A.f(N * 5000), *f = A.f(N * 5008), *d1 = A.f(N * 100), *d2 = A.f(N * 50), *o1 = A.f(N * 2), *u0 = A.f(N * 625);
@@ -728,8 +731,14 @@ static int dqn_fit_lean(ofx_handle *h, float *weights, float *adam_m, float *ada
   dzn = dp3;
   for (int i = 3; i >= 0; i--) {
     const int s = tS[i];
-    if ((rc = ofx_fit_b1_pool(st, n, s, s, i < 3, dzn, i < 3 ? T(6 * (i + 1)) : nullptr, tz[i], tstat[i], tact[i], tg[i], part, &nb))) return rc;
+    // the first layer's g is kept compact (one value + a window position per 2 x 2 window) and its weight gradient needs
+    // neither z0 nor dz0 (ofx_fit.hip, f_bw_first)
+    if ((rc = ofx_fit_b1_pool(st, n, s, s, i == 0 ? 2 : i < 3, dzn, i < 3 ? T(6 * (i + 1)) : nullptr, tz[i], tstat[i], tact[i], tg[i], part, &nb, kk0))) return rc;
     if ((rc = ofx_fit_finish(st, nb, 8, 1.0, part, nullptr, nullptr, sums, nullptr, nullptr))) return rc;
+    if (i == 0) {
+      if ((rc = ofx_fit_bw_first(st, n, bits_prev, tg[0], kk0, T(0), T(1), tstat[0], T(2), sums, part, cpart, G(0), G(1), G(2), G(3)))) return rc;
+      break;
+    }
     if ((rc = ofx_fit_bw(st, n, kTI[i], 8, s, s, trunk_src(i, true), 1, tg[i], tz[i], tstat[i], T(6 * i + 2), sums, part,
                          G(6 * i), G(6 * i + 1), G(6 * i + 2), G(6 * i + 3)))) return rc;
     dzn = tg[i];
