@@ -1147,9 +1147,10 @@ constexpr int C0_ROWS = 40;   // rows of a correlation chunk
 // part[block][324]: Cc over the block's rows of one sample; block = 384 threads, thread q < 324 owns the pair (q / 18, q % 18)
 __global__ __launch_bounds__(384) void f_bits_corr(int n, const uint32_t *__restrict__ bits, double *__restrict__ part) {
   __shared__ uint32_t ver[18][13];   // the 18 shifted versions of image row y: bit x of version u = in_u at pixel (y, x)
-  const int s = blockIdx.x / (400 / C0_ROWS), y0 = (blockIdx.x % (400 / C0_ROWS)) * C0_ROWS;
-  const int tid = threadIdx.x, ua = tid / 18, ub = tid - 18 * ua;
-  int acc = 0;
+  const int tid = threadIdx.x, ua = tid / 18, ub = tid - 18 * ua, nchunks = n * (400 / C0_ROWS);
+  int acc = 0;   // at most (chunks per block) x 40 x 400 < 2^31
+  for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+  const int s = chunk / (400 / C0_ROWS), y0 = (chunk % (400 / C0_ROWS)) * C0_ROWS;
   for (int y = y0; y < y0 + C0_ROWS; y++) {
     __syncthreads();
     for (int e = tid; e < 18 * 13; e += 384) {
@@ -1180,6 +1181,7 @@ __global__ __launch_bounds__(384) void f_bits_corr(int n, const uint32_t *__rest
       for (int wd = 0; wd < 13; wd++) acc += __popc(ver[ua][wd] & ver[ub][wd]);
     }
   }
+  }
   if (tid < 324) part[(size_t)blockIdx.x * 324 + tid] = (double)acc;
 }
 
@@ -1189,11 +1191,12 @@ __global__ __launch_bounds__(512) void f_bw_first(int n, const uint32_t *__restr
                                                   const unsigned char *__restrict__ kk, double *__restrict__ part) {
   constexpr int TW = 100, LP = TW + 2, NA = 19, NPX = (B0_TR / 2) * (TW / 2), NGRP = (NPX + 63) / 64;
   __shared__ float in[2][B0_TR + 2][LP];
+  __shared__ uint32_t wrow[2][B0_TR + 2][5];
   __shared__ double dacc[8][NA];
   const int tid = threadIdx.x, co = tid >> 6, lane = tid & 63;
+  int since = 0;
   const int H = 400, W = 400, Hp = 200, Wp = 200, tx_n = W / TW, ty_n = H / B0_TR, per_s = tx_n * ty_n;
   const long ntiles = (long)n * per_s;
-  FitSrc S{nullptr, bits, nullptr, 400, 400, 0};
   float acc[NA];
 #pragma unroll
   for (int k = 0; k < NA; k++) acc[k] = 0.f;
@@ -1202,10 +1205,30 @@ __global__ __launch_bounds__(512) void f_bw_first(int n, const uint32_t *__restr
     const size_t s = tile / per_s;
     const int t = (int)(tile - (long)s * per_s), y0 = (t / tx_n) * B0_TR, x0 = (t % tx_n) * TW;
     __syncthreads();
+    // the tile's bit rows as words first (102 pixels of a row lie in at most 5 words), then one LDS word per pixel
+    for (int e = tid; e < 2 * (B0_TR + 2) * 5; e += 512) {
+      const int c = e / ((B0_TR + 2) * 5), rem = e - c * ((B0_TR + 2) * 5), yy = rem / 5, j = rem - 5 * yy;
+      const int y = y0 - 1 + yy;
+      uint32_t v = 0;
+      if (y >= 0 && y < H) {
+        const long b0 = 400L * y + x0 - 1;                 // bit position of the row's first tile pixel (column x0 - 1)
+        const int wi = (int)((b0 < 0 ? 0 : b0) >> 5) + j;
+        if (wi < 5000) v = bits[((size_t)s * 2 + c) * 5000 + wi];
+      }
+      wrow[c][yy][j] = v;
+    }
+    __syncthreads();
     for (int e = tid; e < 2 * (B0_TR + 2) * (TW + 2); e += 512) {
       const int c = e / ((B0_TR + 2) * (TW + 2)), rem = e - c * ((B0_TR + 2) * (TW + 2));
       const int yy = rem / (TW + 2), xx = rem - yy * (TW + 2);
-      in[c][yy][xx] = src_value<OFX_FIT_SRC_BITS, 2>(S, s, c, y0 - 1 + yy, x0 - 1 + xx, H, W);
+      const int y = y0 - 1 + yy, x = x0 - 1 + xx;
+      float v = 0.f;
+      if (y >= 0 && y < H && x >= 0 && x < W) {
+        const long b0 = 400L * y + x0 - 1, bp = 400L * y + x;
+        const int j = (int)(bp >> 5) - (int)((b0 < 0 ? 0 : b0) >> 5);
+        v = (float)((wrow[c][yy][j] >> (bp & 31)) & 1u);
+      }
+      in[c][yy][xx] = v;
     }
     __syncthreads();
     for (int grp = 0; grp < NGRP; grp++) {
@@ -1224,13 +1247,21 @@ __global__ __launch_bounds__(512) void f_bw_first(int n, const uint32_t *__restr
         acc[18] += gv;
       }
     }
-    // one flush per tile: 1000 windows = 16 terms per lane and sum
+    // a flush every 4 tiles: 4000 windows = 64 fp32 terms per lane and sum
+    if (++since == 4) {
+      since = 0;
 #pragma unroll
-    for (int k = 0; k < NA; k++) {
-      const float v = wave_sum(acc[k]);
-      if (lane == 0) dacc[co][k] += (double)v;
-      acc[k] = 0.f;
+      for (int k = 0; k < NA; k++) {
+        const float v = wave_sum(acc[k]);
+        if (lane == 0) dacc[co][k] += (double)v;
+        acc[k] = 0.f;
+      }
     }
+  }
+#pragma unroll
+  for (int k = 0; k < NA; k++) {
+    const float v = wave_sum(acc[k]);
+    if (lane == 0) dacc[co][k] += (double)v;
   }
   __syncthreads();
   // part[block] = A as [tap][ci][co] (144), then sum g [co] (8)
@@ -1414,13 +1445,13 @@ int ofx_fit_out_bw(hipStream_t st, int n, const ofx_fit_src &src, const float *d
   return OFX_OK;
 }
 
-size_t ofx_fit_first_doubles(int n) { return (size_t)n * (400 / C0_ROWS) * 324 + 324 + 152; }
+size_t ofx_fit_first_doubles(int n) { return (size_t)1024 * 324 + 324 + 152 + 0 * (size_t)n; }
 // dw / db / dgamma / dbeta of the first trunk layer from the compact g (gc, kk: ofx_fit_b1_pool with conv = 2), the 1-bit
 // maps and the layer's own weights; cpart: ofx_fit_first_doubles(n) doubles of scratch
 int ofx_fit_bw_first(hipStream_t st, int n, const void *bits, const float *gc, const unsigned char *kk, const float *w,
                      const float *b, const float *stat, const float *gamma, const double *sums, double *part,
                      double *cpart, float *dw, float *db, float *dgamma, float *dbeta) {
-  const int nc = n * (400 / C0_ROWS);
+  const int nchunks = n * (400 / C0_ROWS), nc = nchunks < 1024 ? nchunks : 1024;   // persistent: <= 1024 rows of partial counts
   double *cc = cpart + (size_t)nc * 324, *q = cc + 324;
   hipLaunchKernelGGL(f_bits_corr, dim3(nc), dim3(384), 0, st, n, (const uint32_t *)bits, cpart);
   hipLaunchKernelGGL(f_sum_rows, dim3((324 + 15) / 16), dim3(256), 0, st, 324, nc, cpart, cc);
