@@ -397,7 +397,8 @@ int ofx_policy_forward_obs(ofx_handle *h, const float *weights, int32_t n_obs, c
  * i.e. the current values and the values written into target[iaction] / ptr_target[ipointer]; their squared
  * differences are the two MSE terms ofx_dqn_fit minimises.  The reference indexes ptr_target[x][y] on a [y][x] map
  * (:280) and fits on next_state's inputs (:282-283); here the pointer addresses the pixel it was chosen as
- * (ofx_dqn_fit_reference reproduces the reference as written).  Padding rows (ship < 0) give zeros.               */
+ * (ofx_dqn_fit_reference reproduces the reference as written).  Padding rows (ship < 0) give zeros.  q_sa and p_sp may
+ * both be NULL: the forward on `state` is then skipped (ofx_dqn_fit needs only y_act / y_ptr).                    */
 int ofx_dqn_targets(ofx_handle *h, const float *weights, int32_t n, const ofx_transition *rows, const void *bits_prev,
                     const void *bits_next, float gamma, float *q_sa, float *p_sp, float *y_act, float *y_ptr);
 

@@ -1641,10 +1641,16 @@ __global__ void k_dqn_targets(int n, const ofx_transition *rows, float gamma, co
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const ofx_transition r = rows[i];
-  if (r.ship < 0) { q_sa[i] = p_sp[i] = y_act[i] = y_ptr[i] = 0.f; return; }
+  if (r.ship < 0) {
+    if (q_sa) q_sa[i] = p_sp[i] = 0.f;
+    y_act[i] = y_ptr[i] = 0.f;
+    return;
+  }
   const float live = r.done ? 0.f : 1.f;  // int(not done)
-  q_sa[i] = act_prev[2 * i + (r.iaction ? 1 : 0)];
-  p_sp[i] = probe_prev[i];
+  if (q_sa) {   // the forward on `state` was run
+    q_sa[i] = act_prev[2 * i + (r.iaction ? 1 : 0)];
+    p_sp[i] = probe_prev[i];
+  }
   y_act[i] = (float)r.reward + gamma * fmaxf(act_next[2 * i], act_next[2 * i + 1]) * live;  // np.max(prediction)
   y_ptr[i] = (float)r.reward + gamma * max_next[i] * live;                                    // np.max(ptr_prediction)
 }
@@ -1666,7 +1672,7 @@ extern "C" int ofx_policy_forward_obs(ofx_handle *h, const float *weights, int32
 extern "C" int ofx_dqn_targets(ofx_handle *h, const float *weights, int32_t n, const ofx_transition *rows,
                                const void *bits_prev, const void *bits_next, float gamma, float *q_sa, float *p_sp,
                                float *y_act, float *y_ptr) {
-  if (!h || !weights || !rows || !bits_prev || !bits_next || !q_sa || !p_sp || !y_act || !y_ptr || n < 1) {
+  if (!h || !weights || !rows || !bits_prev || !bits_next || (!q_sa) != (!p_sp) || !y_act || !y_ptr || n < 1) {
     ofx_set_error("ofx_dqn_targets: bad argument");
     return OFX_ERR_INVALID;
   }
@@ -1684,7 +1690,9 @@ extern "C" int ofx_dqn_targets(ofx_handle *h, const float *weights, int32_t n, c
   float *max_next = (float *)b;
   hipLaunchKernelGGL(k_dqn_unpack, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, rows, vec_prev, vec_next, probe);
   OFX_HIP(hipGetLastError());
-  if ((rc = ofx_policy_forward_obs(h, weights, n, bits_prev, vec_prev, act_prev, nullptr, nullptr, nullptr, probe, probe_prev)))
+  // q_sa = p_sp = NULL: the caller only wants the targets (ofx_dqn_fit's own forward gives the current values) - the forward
+  // on `state` is skipped
+  if (q_sa && (rc = ofx_policy_forward_obs(h, weights, n, bits_prev, vec_prev, act_prev, nullptr, nullptr, nullptr, probe, probe_prev)))
     return rc;
   if ((rc = ofx_policy_forward_obs(h, weights, n, bits_next, vec_next, act_next, nullptr, nullptr, max_next, nullptr, nullptr)))
     return rc;

@@ -425,14 +425,15 @@ class ArenaBatch:
             out["ptr_probe"] = pp.download(np.float32, (n,))
         return out
 
-    def dqn_targets(self, weights_ptr, n, rows_ptr, bits_prev_ptr, bits_next_ptr, gamma=0.9):
-        """Trainer.replay's targets (qlearnIA_V2.py:251-270; gamma = 0.9, :51): host arrays q_sa, p_sp, y_act, y_ptr."""
+    def dqn_targets(self, weights_ptr, n, rows_ptr, bits_prev_ptr, bits_next_ptr, gamma=0.9, current=True):
+        """Trainer.replay's targets (qlearnIA_V2.py:251-270; gamma = 0.9, :51): host arrays q_sa, p_sp, y_act, y_ptr.
+        current=False: only y_act, y_ptr (the forward on `state` is skipped; q_sa / p_sp come back as None)."""
         n = int(n)
-        bufs = [DeviceBuffer(4 * n) for _ in range(4)]
+        bufs = [DeviceBuffer(4 * n) if (current or k >= 2) else None for k in range(4)]
         nat.check(nat.lib().ofx_dqn_targets(self._h, weights_ptr, n, rows_ptr, bits_prev_ptr, bits_next_ptr, float(gamma),
-                                             *[b.ptr for b in bufs]))
+                                             *[b.ptr if b else None for b in bufs]))
         self.sync()
-        return tuple(b.download(np.float32, (n,)) for b in bufs)
+        return tuple(b.download(np.float32, (n,)) if b else None for b in bufs)
 
     def dqn_fit(self, weights_buf, adam_m_buf, adam_v_buf, step, lr, n, rows_ptr, bits_prev_ptr, y_act_ptr, y_ptr_ptr,
                 grad_buf=None):

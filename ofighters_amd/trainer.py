@@ -84,12 +84,14 @@ class DeviceTrainer:
                                        rows_p, prev_p, next_p, self.gamma)
             self.losses.append(loss)
             return loss
-        outs = [DeviceBuffer(4 * n) for _ in range(4)]     # q_sa, p_sp, y_act, y_ptr
+        y_act, y_ptr = DeviceBuffer(4 * n), DeviceBuffer(4 * n)
         from . import _native as nat
+        # q_sa / p_sp (the current values at the chosen action / pointer) are not asked for: the fit's own training-mode
+        # forward produces them, so the targets need the forward on next_state only
         nat.check(nat.lib().ofx_dqn_targets(b.handle, self.weights.ptr, n, rows_p, prev_p, next_p, float(self.gamma),
-                                             *[o.ptr for o in outs]))
+                                             None, None, y_act.ptr, y_ptr.ptr))
         self.fit_steps += 1
         loss = b.dqn_fit(self.weights, self.adam_m, self.adam_v, self.fit_steps, self.learning_rate, n, rows_p, prev_p,
-                         outs[2].ptr, outs[3].ptr)
+                         y_act.ptr, y_ptr.ptr)
         self.losses.append(loss)
         return loss

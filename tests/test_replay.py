@@ -238,6 +238,9 @@ def test_dqn_targets_vs_oracle():
     rows_d, bp_d, bn_d = b.replay_gather_device(slot, batch)
     n = N * batch
     q_sa, p_sp, y_act, y_ptr = b.dqn_targets(dw.ptr, n, rows_d.ptr, bp_d.ptr, bn_d.ptr, gamma)
+    # the targets alone (q_sa = p_sp = NULL: no forward on `state`): the same bits
+    none_a, none_b, y_act2, y_ptr2 = b.dqn_targets(dw.ptr, n, rows_d.ptr, bp_d.ptr, bn_d.ptr, gamma, current=False)
+    assert none_a is None and none_b is None and np.array_equal(y_act, y_act2) and np.array_equal(y_ptr, y_ptr2)
     rows = rows_d.download(b.TRANSITION_DTYPE, (n,))
     bp = bp_d.download(np.uint32, (n, 2, 5000))
     bn = bn_d.download(np.uint32, (n, 2, 5000))
