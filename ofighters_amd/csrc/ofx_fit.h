@@ -37,6 +37,13 @@ int ofx_fit_pool_act(hipStream_t st, int n, int C, int H, int W, const float *z,
 int ofx_fit_b1_pool(hipStream_t st, int n, int H, int W, int conv, const float *dzn, const float *wn, const float *z,
                     const float *stat, const float *act, float *g, double *part, int *nblocks, unsigned char *kk = nullptr);
 size_t ofx_fit_first_doubles(int n);
+size_t ofx_fit_first_floats(void);
+struct ofx_handle;
+// the first trunk layer without its tensor z0 (see ofx_fit.hip "the first layer is never materialised")
+int ofx_fit_first_fwd(ofx_handle *h, int n, const void *bits, const float *w, const float *b, const float *gamma,
+                      const float *beta, double *cpart, float *stat, float *act, float *luts, float *p0);
+int ofx_fit_b1_first(hipStream_t st, int n, const void *bits, const float *dzn, const float *wn, const float *luts,
+                     const float *gamma, const float *beta, float *gc, unsigned char *kk, double *part, int *nblocks);
 int ofx_fit_bw_first(hipStream_t st, int n, const void *bits, const float *gc, const unsigned char *kk, const float *w,
                      const float *b, const float *stat, const float *gamma, const double *sums, double *part,
                      double *cpart, float *dw, float *db, float *dgamma, float *dbeta);

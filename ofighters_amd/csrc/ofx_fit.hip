@@ -1188,6 +1188,193 @@ __global__ __launch_bounds__(384) void f_bits_corr(int n, const uint32_t *__rest
   if (tid < 324) part[(size_t)blockIdx.x * 324 + tid] = (double)acc;
 }
 
+// ---- the first layer is never materialised -------------------------------------------------------------------------------
+// z0 = conv3x3(1-bit maps) takes one of 512 values per channel and input map, so (1) its batch statistics follow from the
+// autocorrelation Cc of the shifted bit maps: sum z = M b + sum_u w_u B_u, sum z^2 = M b^2 + 2 b sum_u w_u B_u + sum_uu'
+// w_u w_u' Cc[u][u'] (exact integers times weights, in doubles); (2) pool(relu(bn(z0))) - all the second layer reads - is the
+// forward's table kernel (k_conv1_lut, ofx_policy.hip) on a table that folds the BATCH statistics; (3) the backward
+// through the pooling looks x-hat up in a second table.  The 5.12 MB per row of z0 are neither written nor read.
+// lut_y[ci][pattern][co] = scale_co sum of the set taps' weights (+ scale b + shift for ci = 0): relu(bn(z0)) = max(y, 0)
+// lut_x: the same with rs instead of scale and rs (b - mean) for ci = 0: x-hat
+__global__ __launch_bounds__(256) void f_first_prepare(const double *cc, const float *w, const float *b, const float *gamma,
+                                                       const float *beta, double count, float *stat, float *act,
+                                                       float *lut_y, float *lut_x) {
+  __shared__ float sc[8], sh[8], rsv[8], mn[8];
+  const int tid = threadIdx.x;
+  if (tid < 8) {
+    const int co = tid;
+    double sw = 0.0, sww = 0.0;
+    for (int u = 0; u < 18; u++) {
+      sw += (double)w[u * 8 + co] * cc[u * 18 + u];
+      for (int v = 0; v < 18; v++) sww += (double)w[u * 8 + co] * (double)w[v * 8 + co] * cc[u * 18 + v];
+    }
+    const double bb = b[co], mean = bb + sw / count, ez2 = bb * bb + (2.0 * bb * sw + sww) / count, var = ez2 - mean * mean;
+    const float meanf = (float)mean, varf = (float)(var > 0.0 ? var : 0.0);
+    stat[2 * co] = meanf;
+    stat[2 * co + 1] = varf;
+    const float rs = rsqrtf(varf + 1e-3f), s_ = gamma[co] * rs;
+    act[2 * co] = s_;
+    act[2 * co + 1] = beta[co] - meanf * s_;
+    sc[co] = s_; sh[co] = beta[co] - meanf * s_; rsv[co] = rs; mn[co] = meanf;
+  }
+  __syncthreads();
+  for (int e = tid; e < 2 * 512 * 8; e += 256) {
+    const int co = e & 7, pat = (e >> 3) & 511, ci = e >> 12;
+    float acc = 0.f;
+    for (int tap = 0; tap < 9; tap++)
+      if ((pat >> tap) & 1) acc += w[(tap * 2 + ci) * 8 + co];
+    lut_y[e] = acc * sc[co] + (ci == 0 ? b[co] * sc[co] + sh[co] : 0.f);
+    lut_x[e] = acc * rsv[co] + (ci == 0 ? (b[co] - mn[co]) * rsv[co] : 0.f);
+  }
+}
+
+// f_b1_pool<true, COMPACT> for the first layer without z0: the windows' x-hat from lut_x (LDS) and the bit rows of the tile
+__global__ __launch_bounds__(256, 2) void f_b1_first(int n, const uint32_t *__restrict__ bits, const float *__restrict__ dzn,
+                                                     const float *__restrict__ wn, const float *__restrict__ lut_x,
+                                                     const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                     float *__restrict__ g, unsigned char *__restrict__ kk,
+                                                     double *__restrict__ part) {
+  constexpr int C = 8, LP = P_TW + 4, H = 400, W = 400, Hp = 200, Wp = 200, NR = 2 * P_TR + 2;
+  __shared__ __align__(16) float dzt[C][P_TR + 2][LP];
+  __shared__ __align__(16) float wl[9 * C * C];
+  __shared__ __align__(16) float slut[2 * 512 * 8];
+  __shared__ uint32_t rows[2][NR][5];   // bit i of a staged row <-> image column 2 x0 - 1 + i (0 outside the plane)
+  __shared__ double red[4][2 * C];
+  const int tid = threadIdx.x, r = tid / (P_TW / 2), q = tid - r * (P_TW / 2);
+  for (int e = tid; e < 9 * C * C; e += 256) {
+    const int ci = e % C, co = (e / C) % C, tap = e / (C * C);
+    wl[e] = wn[(tap * C + ci) * C + co];
+  }
+  for (int e = tid; e < 2 * 512 * 8 / 4; e += 256) reinterpret_cast<float4 *>(slut)[e] = reinterpret_cast<const float4 *>(lut_x)[e];
+  const int tx_n = Wp / P_TW, ty_n = Hp / P_TR, per_s = tx_n * ty_n;
+  const long ntiles = (long)n * per_s;
+  double s1[C], s2[C];
+#pragma unroll
+  for (int c = 0; c < C; c++) { s1[c] = 0.0; s2[c] = 0.0; }
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const size_t s = tile / per_s;
+    const int t = (int)(tile - (long)s * per_s), y0 = (t / tx_n) * P_TR, x0 = (t % tx_n) * P_TW;
+    __syncthreads();
+    {
+      constexpr int NE = C * (P_TR + 2) * (P_TW + 2);
+      for (int e0 = tid; e0 < NE; e0 += 256 * FILL_U) {
+        float v[FILL_U];
+#pragma unroll
+        for (int u = 0; u < FILL_U; u++) {
+          const int e = e0 + u * 256;
+          const int co = e / ((P_TR + 2) * (P_TW + 2)), rem = e - co * ((P_TR + 2) * (P_TW + 2));
+          const int yy = rem / (P_TW + 2), xx = rem - yy * (P_TW + 2);
+          const int y = y0 - 1 + yy, x = x0 - 1 + xx;
+          v[u] = (e < NE && y >= 0 && y < Hp && x >= 0 && x < Wp) ? dzn[((s * C + co) * (size_t)Hp + y) * Wp + x] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < FILL_U; u++) {
+          const int e = e0 + u * 256;
+          if (e < NE) (&dzt[0][0][0])[(e / (P_TW + 2)) * LP + e % (P_TW + 2)] = v[u];
+        }
+      }
+    }
+    // image rows 2 y0 - 1 .. 2 y0 + 2 P_TR, columns 2 x0 - 1 .. 2 x0 + 2 P_TW (102 bits -> 4 words + one spare)
+    for (int e = tid; e < 2 * NR * 5; e += 256) {
+      const int wd = e % 5, rr = (e / 5) % NR, ci = e / (5 * NR);
+      const int gy = 2 * y0 - 1 + rr;
+      uint32_t out = 0u;
+      if (gy >= 0 && gy < H && wd < 4) {
+        const int c0 = 2 * x0 - 1 + 32 * wd;                          // image column of the word's bit 0
+        const long s0 = (long)gy * W + c0;                            // its cell (-1 only at gy = 0, c0 = -1)
+        const uint32_t *pl = bits + ((size_t)s * 2 + ci) * 5000;
+        const long sw = s0 >> 5;
+        const uint32_t lo = (sw >= 0 && sw < 5000) ? pl[sw] : 0u, hi = (sw + 1 >= 0 && sw + 1 < 5000) ? pl[sw + 1] : 0u;
+        out = __funnelshift_r(lo, hi, (unsigned)(s0 & 31));
+        if (c0 < 0) out &= ~1u;                                       // column -1
+        const int over = c0 + 32 - W;                                 // bits past the last column of THIS row
+        if (over > 0) out = over >= 32 ? 0u : (out & (0xFFFFFFFFu >> over));
+      }
+      rows[ci][rr][wd] = out;
+    }
+    __syncthreads();
+    const int yp = y0 + r, xp = x0 + 2 * q;
+    if (r >= P_TR) continue;
+    float dp[2][C];
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int ci = 0; ci < C; ci++) dp[j][ci] = 0.f;
+#pragma unroll 1
+    for (int co = 0; co < C; co++) {
+#pragma unroll
+      for (int ky = 0; ky < 3; ky++) {
+        const float2 a = *reinterpret_cast<const float2 *>(&dzt[co][r - ky + 2][2 * q]);
+        const float2 c2 = *reinterpret_cast<const float2 *>(&dzt[co][r - ky + 2][2 * q + 2]);
+        const float v[4] = {a.x, a.y, c2.x, c2.y};
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) {
+          float wv[C];
+          lds_vec<C>(&wl[((ky * 3 + kx) * C + co) * C], wv);
+          fma_row<C>(dp[0], v[2 - kx], wv);
+          fma_row<C>(dp[1], v[3 - kx], wv);
+        }
+      }
+    }
+    // the 2 x 4 block of first-layer pixels under the thread's two windows: rows 2 r, 2 r + 1 of the tile, columns 4 q ..
+    // 4 q + 3; staged row 2 r + dy + ky <-> image row (2 y0 + 2 r + dy) + ky - 1, staged bit 4 q + dx + kx <-> column + kx - 1
+    uint32_t f[2][4];
+#pragma unroll
+    for (int ci = 0; ci < 2; ci++)
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++) {
+        const uint32_t *rw = &rows[ci][2 * r + rr][(4 * q) >> 5];
+        f[ci][rr] = __funnelshift_r(rw[0], rw[1], (unsigned)((4 * q) & 31)) & 63u;
+      }
+    float xh[2][4][C];   // [row][column][channel]
+#pragma unroll
+    for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+      for (int dx = 0; dx < 4; dx++) {
+        float4 lo4, hi4;
+#pragma unroll
+        for (int ci = 0; ci < 2; ci++) {
+          const uint32_t pat = ((f[ci][dy] >> dx) & 7u) | (((f[ci][dy + 1] >> dx) & 7u) << 3) | (((f[ci][dy + 2] >> dx) & 7u) << 6);
+          const float4 *e = reinterpret_cast<const float4 *>(&slut[(ci * 512 + pat) * 8]);
+          if (ci == 0) { lo4 = e[0]; hi4 = e[1]; }
+          else { lo4.x += e[0].x; lo4.y += e[0].y; lo4.z += e[0].z; lo4.w += e[0].w; hi4.x += e[1].x; hi4.y += e[1].y; hi4.z += e[1].z; hi4.w += e[1].w; }
+        }
+        xh[dy][dx][0] = lo4.x; xh[dy][dx][1] = lo4.y; xh[dy][dx][2] = lo4.z; xh[dy][dx][3] = lo4.w;
+        xh[dy][dx][4] = hi4.x; xh[dy][dx][5] = hi4.y; xh[dy][dx][6] = hi4.z; xh[dy][dx][7] = hi4.w;
+      }
+#pragma unroll
+    for (int ci = 0; ci < C; ci++) {
+      const float gm = gamma[ci], bt = beta[ci];
+      float gcv[2];
+      int kcv[2];
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const float xv[4] = {xh[0][2 * j][ci], xh[0][2 * j + 1][ci], xh[1][2 * j][ci], xh[1][2 * j + 1][ci]};
+        float av[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) av[i] = fmaxf(fmaf(gm, xv[i], bt), 0.f);
+        int k = 0;
+#pragma unroll
+        for (int i = 1; i < 4; i++) if (av[i] > av[k]) k = i;
+        const float gv = av[k] > 0.f ? dp[j][ci] : 0.f;
+        gcv[j] = gv; kcv[j] = k;
+        s1[ci] += (double)gv;
+        s2[ci] += (double)(gv * xv[k]);
+      }
+      const size_t at = ((s * C + ci) * (size_t)Hp + yp) * Wp + xp;
+      *reinterpret_cast<float2 *>(g + at) = make_float2(gcv[0], gcv[1]);
+      *reinterpret_cast<uchar2 *>(kk + at) = make_uchar2((unsigned char)kcv[0], (unsigned char)kcv[1]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < C; c++) {
+    const double a = wave_sum(s1[c]), b2 = wave_sum(s2[c]);
+    if ((tid & 63) == 0) { red[tid >> 6][2 * c] = a; red[tid >> 6][2 * c + 1] = b2; }
+  }
+  __syncthreads();
+  if (tid < 2 * C) part[(size_t)blockIdx.x * 2 * C + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
 // A[tap][ci][co] = sum in_u g and sum g per co from the compact g: a wave owns an output channel, a lane a pooled pixel
 constexpr int B0_TR = 40;   // image rows of a tile (20 pooled rows x 50 pooled columns = 1000 windows)
 __global__ __launch_bounds__(512) void f_bw_first(int n, const uint32_t *__restrict__ bits, const float *__restrict__ gc,
@@ -1315,6 +1502,7 @@ int ofx_fit_conv_fwd(hipStream_t st, int n, int ci, int co, int H, int W, const 
     OFX_HIP(hipGetLastError()); return OFX_OK; }
   FWD(2, 8, OFX_FIT_SRC_BITS, 100, true)
   FWD(8, 8, OFX_FIT_SRC_POOL, 100, true)
+  FWD(8, 8, OFX_FIT_SRC_PLANE, 100, true)
   FWD(8, 8, OFX_FIT_SRC_POOL, 50, true)
   FWD(1, 2, OFX_FIT_SRC_UPRAW, 50, true)
   FWD(2, 4, OFX_FIT_SRC_UP, 100, true)
@@ -1449,15 +1637,37 @@ int ofx_fit_out_bw(hipStream_t st, int n, const ofx_fit_src &src, const float *d
 }
 
 size_t ofx_fit_first_doubles(int n) { return (size_t)1024 * 324 + 324 + 152 + 0 * (size_t)n; }
-// dw / db / dgamma / dbeta of the first trunk layer from the compact g (gc, kk: ofx_fit_b1_pool with conv = 2), the 1-bit
-// maps and the layer's own weights; cpart: ofx_fit_first_doubles(n) doubles of scratch
+size_t ofx_fit_first_floats(void) { return 2 * 8192; }
+// The first trunk layer's forward without its tensor: autocorrelation of the bit maps (cpart, kept for the backward) ->
+// batch statistics (stat, act) and the two tables (luts: ofx_fit_first_floats() floats) -> p0 = pool(relu(bn(conv1)))
+// [n][8][200][200] through the forward's table kernel
+int ofx_fit_first_fwd(ofx_handle *h, int n, const void *bits, const float *w, const float *b, const float *gamma,
+                      const float *beta, double *cpart, float *stat, float *act, float *luts, float *p0) {
+  hipStream_t st = h->stream;
+  const int nchunks = n * (400 / C0_ROWS), nc = nchunks < 1024 ? nchunks : 1024;   // persistent: <= 1024 rows of partial counts
+  double *cc = cpart + (size_t)1024 * 324;
+  hipLaunchKernelGGL(f_bits_corr, dim3(nc), dim3(384), 0, st, n, (const uint32_t *)bits, cpart);
+  hipLaunchKernelGGL(f_sum_rows, dim3((324 + 15) / 16), dim3(256), 0, st, 324, nc, cpart, cc);
+  hipLaunchKernelGGL(f_first_prepare, dim3(1), dim3(256), 0, st, cc, w, b, gamma, beta, (double)n * 160000.0, stat, act, luts,
+                     luts + 8192);
+  OFX_HIP(hipGetLastError());
+  return ofx_launch_conv1_lut(h, bits, n, luts, p0);
+}
+// g0 compact (gc, kk) + the BatchNorm-backward sums of the first layer from the second layer's dz (dzn, kernel wn)
+int ofx_fit_b1_first(hipStream_t st, int n, const void *bits, const float *dzn, const float *wn, const float *luts,
+                     const float *gamma, const float *beta, float *gc, unsigned char *kk, double *part, int *nblocks) {
+  const int grid = grid_for((long)n * (200 / P_TR) * (200 / P_TW), OFX_FIT_MAX_BLOCKS);
+  *nblocks = grid;
+  hipLaunchKernelGGL(f_b1_first, dim3(grid), dim3(256), 0, st, n, (const uint32_t *)bits, dzn, wn, luts + 8192, gamma, beta, gc, kk, part);
+  OFX_HIP(hipGetLastError());
+  return OFX_OK;
+}
+// dw / db / dgamma / dbeta of the first trunk layer from the compact g (gc, kk), the 1-bit maps, the autocorrelation in
+// cpart (ofx_fit_first_fwd) and the layer's own weights
 int ofx_fit_bw_first(hipStream_t st, int n, const void *bits, const float *gc, const unsigned char *kk, const float *w,
                      const float *b, const float *stat, const float *gamma, const double *sums, double *part,
                      double *cpart, float *dw, float *db, float *dgamma, float *dbeta) {
-  const int nchunks = n * (400 / C0_ROWS), nc = nchunks < 1024 ? nchunks : 1024;   // persistent: <= 1024 rows of partial counts
-  double *cc = cpart + (size_t)nc * 324, *q = cc + 324;
-  hipLaunchKernelGGL(f_bits_corr, dim3(nc), dim3(384), 0, st, n, (const uint32_t *)bits, cpart);
-  hipLaunchKernelGGL(f_sum_rows, dim3((324 + 15) / 16), dim3(256), 0, st, 324, nc, cpart, cc);
+  double *cc = cpart + (size_t)1024 * 324, *q = cc + 324;
   const int grid = grid_for((long)n * (400 / B0_TR) * 4, OFX_FIT_MAX_BLOCKS / 2);
   hipLaunchKernelGGL(f_bw_first, dim3(grid), dim3(512), 0, st, n, (const uint32_t *)bits, gc, kk, part);
   hipLaunchKernelGGL(f_sum_rows, dim3((152 + 15) / 16), dim3(256), 0, st, 152, grid, part, q);

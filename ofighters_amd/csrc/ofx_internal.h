@@ -85,6 +85,7 @@ int ofx_replay_episode_reset(ofx_handle *h, const uint8_t *arena_mask);
 // C[M][N] = act(A[M][K] (lda) x B[K][N] (ldb) + bias[N]) on the f32 MFMA (k_gemm_f32, ofx_policy.hip)
 int ofx_launch_gemm(ofx_handle *h, const float *A, int lda, const float *B, int ldb, const float *bias, float *C, int ldc,
                     int M, int N, int K, int relu, const int32_t *live = nullptr);
+int ofx_launch_conv1_lut(ofx_handle *h, const void *bits, int n, const float *lut, float *out);  // k_conv1_lut, caller's table
 int ofx_policy_weights_updated(ofx_handle *h, const float *weights);  // the blob was changed in place (ofx_dqn_fit)
 // model.predict on n stored observations: act_values [n][2], heatmap [n][H][W], ptr_max [n] (any may be null)
 int ofx_policy_predict_obs(ofx_handle *h, const float *weights, int32_t n_obs, const void *bits, const float *vec8,

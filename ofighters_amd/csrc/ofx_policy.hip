@@ -1375,6 +1375,20 @@ static int launch_conv(ofx_handle *h, ConvParams p, int images, int H) {
   return OFX_OK;
 }
 
+// conv1 + BatchNorm + ReLU + pool of n stored observations (bits [n][2][5000]) through a caller-built table
+// [2][512][8] (channel 0 carries the bias): out [n][8][200][200].  The fit's first layer (ofx_fit.hip): its table folds
+// the BATCH statistics.
+int ofx_launch_conv1_lut(ofx_handle *h, const void *bits, int n, const float *lut, float *out) {
+  ConvParams cp{};
+  cp.bits[0] = reinterpret_cast<const unsigned *>(bits);
+  cp.bits[1] = cp.bits[0] + (PS * PS) / 32;
+  cp.bits_stride = 2 * (size_t)((PS * PS) / 32);
+  cp.out = out; cp.H = PS; cp.W = PS; cp.images = n;
+  hipLaunchKernelGGL(k_conv1_lut<40>, dim3((unsigned)(n * (PS / 40))), dim3(256), 0, h->stream, cp, lut);
+  OFX_HIP(hipGetLastError());
+  return OFX_OK;
+}
+
 // (also the dense layers of the fit's forward, ofx_train.hip)
 int ofx_launch_gemm(ofx_handle *h, const float *A, int lda, const float *B, int ldb, const float *bias, float *C, int ldc,
                     int M, int N, int K, int relu, const int32_t *live) {

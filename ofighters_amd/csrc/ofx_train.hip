@@ -623,7 +623,8 @@ static int dqn_fit_lean(ofx_handle *h, float *weights, float *adam_m, float *ada
   static const int tS[4] = {400, 200, 100, 50}, uS[3] = {50, 100, 200};
   size_t need = 0;
   auto sz = [&](size_t bytes) { need += (bytes + 255) & ~(size_t)255; };
-  for (int i = 0; i < 4; i++) { sz(4 * N * 8 * tS[i] * tS[i]); sz(4 * N * 8 * tS[i] * tS[i] / (i ? 1 : 4)); }  // z, g (layer 0: compact)
+  for (int i = 0; i < 4; i++) { if (i) sz(4 * N * 8 * tS[i] * tS[i]); sz(4 * N * 8 * tS[i] * tS[i] / (i ? 1 : 4)); }  // z (not layer 0's), g (layer 0: compact)
+  sz(4 * ofx_fit_first_floats());
   sz(N * 8 * 40000); sz(8 * ofx_fit_first_doubles(n));                                                     // window positions, correlation
   for (int i = 0; i < 3; i++) sz(4 * N * 8 * tS[i + 1] * tS[i + 1]);                                       // pooled activation
   for (int j = 0; j < 3; j++) { sz(4 * N * kUO[j] * uS[j] * uS[j]); sz(4 * N * kUO[j] * uS[j] * uS[j]); }
@@ -647,7 +648,8 @@ static int dqn_fit_lean(ofx_handle *h, float *weights, float *adam_m, float *ada
   double *fpart = A.d(ofx_fit_out_doubles(n));
   float *tz[4], *tg[4], *tstat[4], *tact[4], *uz[3], *ug[3], *ustat[3], *uact[3], *tp[3];
   for (int i = 0; i < 3; i++) tp[i] = A.f(N * 8 * tS[i + 1] * tS[i + 1]);
-  for (int i = 0; i < 4; i++) { tz[i] = A.f(N * 8 * tS[i] * tS[i]); tg[i] = A.f(N * 8 * tS[i] * tS[i] / (i ? 1 : 4)); tstat[i] = A.f(16); tact[i] = A.f(16); }
+  for (int i = 0; i < 4; i++) { tz[i] = i ? A.f(N * 8 * tS[i] * tS[i]) : nullptr; tg[i] = A.f(N * 8 * tS[i] * tS[i] / (i ? 1 : 4)); tstat[i] = A.f(16); tact[i] = A.f(16); }
+  float *luts = A.f(ofx_fit_first_floats());
   unsigned char *kk0 = (unsigned char *)A.take(N * 8 * 40000);
   double *cpart = A.d(ofx_fit_first_doubles(n));
   for (int j = 0; j < 3; j++) { uz[j] = A.f(N * kUO[j] * uS[j] * uS[j]); ug[j] = A.f(N * kUO[j] * uS[j] * uS[j]); ustat[j] = A.f(16); uact[j] = A.f(16); }
@@ -660,7 +662,7 @@ static int dqn_fit_lean(ofx_handle *h, float *weights, float *adam_m, float *ada
   // of z's bytes); the weight gradient reads that plane back instead of pooling z a second time
   auto trunk_src = [&](int i, bool backward) {
     if (i == 0) return ofx_fit_src{OFX_FIT_SRC_BITS, nullptr, bits_prev, nullptr, 400, 400, legacy};
-    if (backward) return ofx_fit_src{OFX_FIT_SRC_PLANE, nullptr, tp[i - 1], nullptr, tS[i], tS[i], legacy};
+    if (backward || i == 1) return ofx_fit_src{OFX_FIT_SRC_PLANE, nullptr, tp[i - 1], nullptr, tS[i], tS[i], legacy};
     return ofx_fit_src{OFX_FIT_SRC_POOL, tp[i - 1], tz[i - 1], tact[i - 1], tS[i - 1], tS[i - 1], legacy};
   };
   auto head_src = [&](int j) {   // input of head-2 layer j (3 = the output convolution)
@@ -669,7 +671,9 @@ static int dqn_fit_lean(ofx_handle *h, float *weights, float *adam_m, float *ada
   };
 
   // ---- forward (training mode) ----
-  for (int i = 0; i < 4; i++) {
+  // the first layer is never materialised: statistics from the autocorrelation of the bit maps, p0 through the table kernel
+  if ((rc = ofx_fit_first_fwd(h, n, bits_prev, T(0), T(1), T(2), T(3), cpart, tstat[0], tact[0], luts, tp[0]))) return rc;
+  for (int i = 1; i < 4; i++) {
     const int s = tS[i];
     if ((rc = ofx_fit_conv_fwd(st, n, kTI[i], 8, s, s, trunk_src(i, false), T(6 * i), T(6 * i + 1), tz[i], part, &nb))) return rc;
     if ((rc = ofx_fit_finish(st, nb, 8, (double)N * s * s, part, T(6 * i + 2), T(6 * i + 3), nullptr, tstat[i], tact[i]))) return rc;
@@ -733,7 +737,9 @@ static int dqn_fit_lean(ofx_handle *h, float *weights, float *adam_m, float *ada
     const int s = tS[i];
     // the first layer's g is kept compact (one value + a window position per 2 x 2 window) and its weight gradient needs
     // neither z0 nor dz0 (ofx_fit.hip, f_bw_first)
-    if ((rc = ofx_fit_b1_pool(st, n, s, s, i == 0 ? 2 : i < 3, dzn, i < 3 ? T(6 * (i + 1)) : nullptr, tz[i], tstat[i], tact[i], tg[i], part, &nb, kk0))) return rc;
+    if (i == 0) rc = ofx_fit_b1_first(st, n, bits_prev, dzn, T(6), luts, T(2), T(3), tg[0], kk0, part, &nb);
+    else rc = ofx_fit_b1_pool(st, n, s, s, i < 3, dzn, i < 3 ? T(6 * (i + 1)) : nullptr, tz[i], tstat[i], tact[i], tg[i], part, &nb);
+    if (rc) return rc;
     if ((rc = ofx_fit_finish(st, nb, 8, 1.0, part, nullptr, nullptr, sums, nullptr, nullptr))) return rc;
     if (i == 0) {
       if ((rc = ofx_fit_bw_first(st, n, bits_prev, tg[0], kk0, T(0), T(1), tstat[0], T(2), sums, part, cpart, G(0), G(1), G(2), G(3)))) return rc;
