@@ -295,7 +295,7 @@ int ofx_policy_pin_weights(ofx_handle *h, const float *weights);
 #define OFX_OPT_POLICY_BF16 5
 /* Diagnostic: ofx_dqn_fit / ofx_dqn_fit_reference in their PLAIN form (value 1): one kernel per layer and pass, every
  * activation, pooled / up-sampled input and gradient of the graph in HBM (61 MB per row of the minibatch).  The default
- * (0) is the lean form: only the pre-activation tensor of every convolution and the trunk's pooled activations are kept (16 MB per row), everything else
+ * (0) is the lean form: only the pre-activation tensor of every convolution and the trunk's pooled activations are kept (11 MB per row; the first layer is never materialised), everything else
  * is recomputed inside fused tiles.  Same function; the results agree up to fp32 summation order (tests/test_train.py).*/
 #define OFX_OPT_FIT_PLAIN 6
 int ofx_set_option(ofx_handle *h, int32_t option, int32_t value);
@@ -411,9 +411,9 @@ int ofx_dqn_targets(ofx_handle *h, const float *weights, int32_t n, const ofx_tr
  * transitions' `state` observations and the pointer addresses heat[y][x] (the reference fits on next_state's inputs
  * and indexes [x][y], :280-283: that form is ofx_dqn_fit_reference).  Every row must be a real transition (ship >= 0; use
  * ofx_replay_gather_valid): a padding row would enter the BatchNorm batch statistics and the loss scale, so the call
- * fails with OFX_ERR_INVALID before anything is updated.  The handle keeps a workspace of 16 MB per row between calls
+ * fails with OFX_ERR_INVALID before anything is updated.  The handle keeps a workspace of 11 MB per row between calls
  * (OFX_OPT_FIT_PLAIN: 61 MB); every reduction has a fixed order, so the same call on the same state gives the same bits.
- * fp32 on the vector ALU (not the hot path): 5.3 ms for 64 rows, 96 ms for 4096 with the target forward; synchronises. */
+ * fp32 on the vector ALU (not the hot path): 5.0 ms for 64 rows, 84 ms for 4096 with the target forward; synchronises. */
 int ofx_dqn_fit(ofx_handle *h, float *weights, float *adam_m, float *adam_v, int32_t step, float lr, int32_t n,
                 const ofx_transition *rows, const void *bits_prev, const float *y_act, const float *y_ptr,
                 float *grad_out, float *loss_host);

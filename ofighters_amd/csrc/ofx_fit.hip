@@ -14,9 +14,9 @@
 //                dW[tap][ci][co] = sum in[ci][p + tap] dz[co][p] with the input tile rebuilt by the same source functor:
 //                a wave owns an input channel, a lane a pixel, 9 x CO accumulators per lane, flushed into doubles.
 //                (f_bw_small: the layers with CI x CO <= 8, a thread owns 4 pixels and all sums.)
-//   f_bw_first / the first layer (1-bit inputs): g kept compact (one value + a window position per 2 x 2 window) and the
-//   f_bits_corr  weight gradient with BatchNorm's backward folded in analytically through the autocorrelation of the shifted
-//                bit maps (popcounts) - neither z0 nor dz0 is read or formed there.
+//   f_first_* /  the first layer (1-bit inputs) is never materialised: batch statistics and the weight gradient (BatchNorm's
+//   f_bits_corr  backward folded in analytically) from the autocorrelation of the shifted bit maps (popcounts), its pooled
+//   f_b1_first   activation through the forward's table kernel, the pooling backward from an x-hat table; g kept compact.
 //   f_out_*      the output convolution (8 -> 1 at 400 x 400 behind the last up-sampling) in PHASE form: a 3 x 3
 //                convolution of the 200 x 200 activation with 4 phase channels on f_conv_fwd / f_bw, plus two small
 //                kernels that correct the plane's frame (zero padding against the phase form's repeated edge) exactly.
@@ -24,7 +24,7 @@
 // Every reduction has a fixed order (tile -> block assignment by index, ordered combines): two fits from the same state
 // give the same bits.  fp32 on the vector ALU (accumulators paired over the channel index: v_pk_fma_f32) with FMA
 // contraction; checked against torch autograd in float64 and against the plain form (tests/test_train.py).  Per row of
-// the minibatch 16 MB of workspace instead of 61 MB; 4096 rows in ~0.1 s, HBM-bound.
+// the minibatch 11 MB of workspace instead of 61 MB; 4096 rows in 84 ms.
 #include "ofx_internal.h"
 #include "ofx_fit.h"
 
