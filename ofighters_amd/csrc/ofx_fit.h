@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 
+#include "../../include/ofx.h"
+
 // how a convolution's input is produced from what is kept in HBM
 #define OFX_FIT_SRC_BITS 0   /* 1-bit maps -> 0.f / 1.f */
 #define OFX_FIT_SRC_POOL 1   /* pool2(relu(bn(z_prev)))          (trunk) */
@@ -62,3 +64,8 @@ size_t ofx_fit_out_doubles(int n);
 int ofx_fit_out_fwd(hipStream_t st, int n, const ofx_fit_src &src, const float *w, const float *b, float *o2, float *weff);
 int ofx_fit_out_bw(hipStream_t st, int n, const ofx_fit_src &src, const float *d2, double *part, double *fpart, float *dw,
                    float *db);
+// the top of head 2 when d o2 has one non-zero per sample (ofx_dqn_fit's targets): see ofx_fit.hip
+size_t ofx_fit_point_doubles(int n);
+int ofx_fit_top_point(hipStream_t st, int n, const ofx_transition *rows, const ofx_fit_src &src, const float *w, const float *b,
+                      const float *o1, const float *y_act, const float *y_ptr, const float *stat, float *o2p, float *do1,
+                      float *d2p, float *lpart, float *g, double *scratch, double *sums, float *dw, float *db);

@@ -1481,6 +1481,93 @@ __global__ void f_bw_first_finish(const double *q, const double *cc, const float
   }
 }
 
+// ---------------------------------------------------------------- the top of head 2 for the textbook targets (ofx_dqn_fit)
+// One error per sample on the heat map: the loss reads o2 at ONE pixel (px, py) of a row and d o2 is non-zero there only.
+// So the output convolution is evaluated at that pixel (72 taps of the up-sampled activation), its weight gradient is one
+// outer product per sample, and the gradient that reaches the last head layer lives in the 4 x 4 low-res cells around the
+// pointer: a few hundred operations per sample instead of four passes over 400 x 400 planes.  (The reference's dense
+// targets - ofx_dqn_fit_reference - keep the dense kernels above.)
+// o2p[s] = b + sum w[ky][kx][c] U_c[py + ky - 1][px + kx - 1]   (U = up2(relu(bn(z))), zero outside the plane)
+__global__ void f_top_point_fwd(int n, const ofx_transition *rows, FitSrc S, const float *w, const float *b, float *o2p) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  const ofx_transition r = rows[s];
+  const int px = min(max(r.px, 0), 399), py = min(max(r.py, 0), 399);
+  float acc = b[0];
+  for (int ky = 0; ky < 3; ky++)
+    for (int kx = 0; kx < 3; kx++)
+      for (int c = 0; c < 8; c++)
+        acc = fmaf(w[(ky * 3 + kx) * 8 + c], src_value<OFX_FIT_SRC_UP, 8>(S, (size_t)s, c, py + ky - 1, px + kx - 1, 400, 400), acc);
+  o2p[s] = acc;
+}
+// seeds of both heads (t_loss_seed of ofx_train.hip with o2 at the pointer only): do1, d2p[s] = d loss / d o2 at the pointer
+__global__ void f_top_point_seed(int n, const ofx_transition *rows, const float *o1, const float *o2p, const float *y_act,
+                                 const float *y_ptr, float *do1, float *d2p, float *lpart) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  const ofx_transition r = rows[s];
+  const int a = r.iaction ? 1 : 0;
+  const float e1 = o1[2 * s + a] - y_act[s], e2 = o2p[s] - y_ptr[s];
+  do1[2 * s + a] = 2.f * e1 / (2.f * n);
+  d2p[s] = 2.f * e2 / (160000.f * n);
+  lpart[2 * s] = e1 * e1 / (2.f * n);
+  lpart[2 * s + 1] = e2 * e2 / (160000.f * n);
+}
+// block = sample: pw[s][73] = d U (the output convolution's weight-gradient share, then d for the bias); the 4 x 4 x 8 patch
+// of g (already zeroed elsewhere) and the sample's {sum g, sum g xhat} per channel in part[s][16]
+__global__ __launch_bounds__(128) void f_top_point_bwd(int n, const ofx_transition *rows, FitSrc S, const float *w,
+                                                       const float *d2p, const float *stat, float *g, double *pw,
+                                                       double *part) {
+  __shared__ float gv_[8][16], gx_[8][16];
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const ofx_transition r = rows[s];
+  const int px = min(max(r.px, 0), 399), py = min(max(r.py, 0), 399);
+  const float d = d2p[s];
+  if (tid < 72) {
+    const int c = tid & 7, tap = tid >> 3;
+    pw[(size_t)s * 73 + tid] = (double)(d * src_value<OFX_FIT_SRC_UP, 8>(S, (size_t)s, c, py + tap / 3 - 1, px + tap % 3 - 1, 400, 400));
+  } else if (tid == 72) {
+    pw[(size_t)s * 73 + 72] = (double)d;
+  }
+  // item = (channel c, cell i of the 4 x 4 window whose first cell is (k0, m0))
+  const int c = tid & 7, cell = tid >> 3, k = (((py - 1) >> 1) - 1) + (cell >> 2), m = (((px - 1) >> 1) - 1) + (cell & 3);
+  float gv = 0.f, gx = 0.f;
+  if (k >= 0 && k < 200 && m >= 0 && m < 200) {
+    float da = 0.f;
+    for (int ky = 0; ky < 3; ky++) {
+      const int Y = py + ky - 1;
+      if (Y < 0 || Y >= 400) continue;
+      int a0, a1;
+      float wt;
+      fit_up_taps(Y, 200, a0, a1, wt, S.legacy);
+      const float cy = (a0 == k ? 1.f - wt : 0.f) + (a1 == k ? wt : 0.f);
+      if (cy == 0.f) continue;
+      for (int kx = 0; kx < 3; kx++) {
+        const int X = px + kx - 1;
+        if (X < 0 || X >= 400) continue;
+        fit_up_taps(X, 200, a0, a1, wt, S.legacy);
+        const float cx = (a0 == m ? 1.f - wt : 0.f) + (a1 == m ? wt : 0.f);
+        // d o2[py][px] / d U[Y][X] = w[tap of (Y, X) as seen from (py, px)] = w[ky][kx]
+        da = fmaf(cy * cx, d * w[(ky * 3 + kx) * 8 + c], da);
+      }
+    }
+    const size_t at = (((size_t)s * 8 + c) * 200 + k) * 200 + m;
+    const float zv = reinterpret_cast<const float *>(S.p)[at];
+    gv = bn_act(zv, S.act[2 * c], S.act[2 * c + 1]) > 0.f ? da : 0.f;
+    gx = gv * ((zv - stat[2 * c]) * rsqrtf(stat[2 * c + 1] + 1e-3f));
+    g[at] = gv;
+  }
+  gv_[c][cell] = gv;
+  gx_[c][cell] = gx;
+  __syncthreads();
+  if (tid < 8) {
+    double a = 0.0, b2 = 0.0;
+    for (int i = 0; i < 16; i++) { a += (double)gv_[tid][i]; b2 += (double)gx_[tid][i]; }
+    part[(size_t)s * 16 + 2 * tid] = a;
+    part[(size_t)s * 16 + 2 * tid + 1] = b2;
+  }
+}
+
 FitSrc dev_src(const ofx_fit_src &s) { return FitSrc{s.keep, s.p, s.act, s.h, s.w, s.legacy}; }
 int grid_for(long ntiles, int cap) { return (int)(ntiles < cap ? ntiles : cap); }
 
@@ -1673,6 +1760,27 @@ int ofx_fit_bw_first(hipStream_t st, int n, const void *bits, const float *gc, c
   hipLaunchKernelGGL(f_sum_rows, dim3((152 + 15) / 16), dim3(256), 0, st, 152, grid, part, q);
   hipLaunchKernelGGL(f_bw_first_finish, dim3(1), dim3(192), 0, st, q, cc, w, b, stat, gamma, sums, (double)n * 160000.0, dw, db,
                      dgamma, dbeta);
+  OFX_HIP(hipGetLastError());
+  return OFX_OK;
+}
+
+size_t ofx_fit_point_doubles(int n) { return (size_t)n * (73 + 16); }
+// The top of head 2 for one error per sample (ofx_dqn_fit): o2 at the pointer (o2p [n]), the seeds of both heads (do1, d2p [n],
+// lpart [2 n]), the output convolution's dw / db, g of the last head layer (g, zeroed here, + its BatchNorm sums in `sums`);
+// scratch: ofx_fit_point_doubles(n) doubles
+int ofx_fit_top_point(hipStream_t st, int n, const ofx_transition *rows, const ofx_fit_src &src, const float *w, const float *b,
+                      const float *o1, const float *y_act, const float *y_ptr, const float *stat, float *o2p, float *do1,
+                      float *d2p, float *lpart, float *g, double *scratch, double *sums, float *dw, float *db) {
+  const FitSrc S = dev_src(src);
+  double *pw = scratch, *part = scratch + (size_t)n * 73;
+  OFX_HIP(hipMemsetAsync(g, 0, sizeof(float) * (size_t)n * 8 * 40000, st));
+  hipLaunchKernelGGL(f_top_point_fwd, dim3((n + 63) / 64), dim3(64), 0, st, n, rows, S, w, b, o2p);
+  hipLaunchKernelGGL(f_top_point_seed, dim3((n + 255) / 256), dim3(256), 0, st, n, rows, o1, o2p, y_act, y_ptr, do1, d2p, lpart);
+  hipLaunchKernelGGL(f_top_point_bwd, dim3(n), dim3(128), 0, st, n, rows, S, w, d2p, stat, g, pw, part);
+  hipLaunchKernelGGL(f_bw_finish, dim3((73 + 15) / 16), dim3(256), 0, st, 73, 72, n, pw, dw, db, 0, (const double *)nullptr,
+                     (float *)nullptr, (float *)nullptr);
+  hipLaunchKernelGGL(f_finish, dim3(1), dim3(256), 0, st, n, 8, 1.0, part, (const float *)nullptr, (const float *)nullptr, sums,
+                     (float *)nullptr, (float *)nullptr);
   OFX_HIP(hipGetLastError());
   return OFX_OK;
 }

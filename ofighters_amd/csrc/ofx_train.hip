@@ -632,7 +632,7 @@ static int dqn_fit_lean(ofx_handle *h, float *weights, float *adam_m, float *ada
   sz(4 * N * 5000); sz(4 * N * 5008); sz(4 * N * 100); sz(4 * N * 50); sz(4 * N * 2); sz(4 * N * 625);      // p3 f d1 d2 o1 u0
   sz(4 * N * 625); sz(4 * N * 2); sz(4 * N * 100); sz(4 * N * 50); sz(4 * N * 5008); sz(4 * N * 5000);      // gu0 do1 dd1 dd2 df dp3
   sz(4 * (size_t)L.n_floats); sz(4 * 64); sz(4 * (2 * N + 4096)); sz(8 * ofx_fit_part_doubles()); sz(8 * 32);
-  sz(4 * ofx_fit_out_floats()); sz(8 * ofx_fit_out_doubles(n));
+  sz(4 * ofx_fit_out_floats()); sz(8 * ofx_fit_out_doubles(n)); sz(8 * ofx_fit_point_doubles(n));
   for (int k = 0; k < 7; k++) { sz(4 * 16); sz(4 * 16); }
   if ((rc = keep_workspace(h, &h->fitws, &h->fitws_bytes, need))) return rc;
   Arena A{(char *)h->fitws, 0, need};
@@ -645,7 +645,7 @@ static int dqn_fit_lean(ofx_handle *h, float *weights, float *adam_m, float *ada
   float *lpart = A.f(2 * N + 4096);
   double *part = A.d(ofx_fit_part_doubles()), *sums = A.d(32);
   float *weff = A.f(ofx_fit_out_floats());
-  double *fpart = A.d(ofx_fit_out_doubles(n));
+  double *fpart = A.d(ofx_fit_out_doubles(n)), *pscratch = A.d(ofx_fit_point_doubles(n));
   float *tz[4], *tg[4], *tstat[4], *tact[4], *uz[3], *ug[3], *ustat[3], *uact[3], *tp[3];
   for (int i = 0; i < 3; i++) tp[i] = A.f(N * 8 * tS[i + 1] * tS[i + 1]);
   for (int i = 0; i < 4; i++) { tz[i] = i ? A.f(N * 8 * tS[i] * tS[i]) : nullptr; tg[i] = A.f(N * 8 * tS[i] * tS[i] / (i ? 1 : 4)); tstat[i] = A.f(16); tact[i] = A.f(16); }
@@ -689,30 +689,36 @@ static int dqn_fit_lean(ofx_handle *h, float *weights, float *adam_m, float *ada
     if ((rc = ofx_fit_conv_fwd(st, n, kUI[j], kUO[j], s, s, head_src(j), T(32 + 6 * j), T(33 + 6 * j), uz[j], part, &nb))) return rc;
     if ((rc = ofx_fit_finish(st, nb, kUO[j], (double)N * s * s, part, T(34 + 6 * j), T(35 + 6 * j), nullptr, ustat[j], uact[j]))) return rc;
   }
-  if ((rc = ofx_fit_out_fwd(st, n, head_src(3), T(50), T(51), o2, weff))) return rc;
+  if (dense && (rc = ofx_fit_out_fwd(st, n, head_src(3), T(50), T(51), o2, weff))) return rc;
 
   // ---- loss seeds ----
   OFX_HIP(hipMemsetAsync(do1, 0, N * 2 * 4, st));
-  if (dense) {
+  if (!dense) {
+    // one error per sample on the heat map: the output convolution at the pointer only, its gradients and the last head
+    // layer's g from that one pixel (ofx_fit.hip, "the top of head 2 for the textbook targets")
+    float *o2p = o2, *d2p = o2 + N;                          // [n] each: the dense planes are not used on this path
+    if ((rc = ofx_fit_top_point(st, n, rows, head_src(3), T(50), T(51), o1, y_act, y_ptr, ustat[2], o2p, do1, d2p, lpart, ug[2],
+                                pscratch, sums, G(50), G(51)))) return rc;
+    hipLaunchKernelGGL(t_sum_ordered, dim3(1), dim3(64), 0, st, n, 2, lpart, loss);
+    OFX_HIP(hipGetLastError());
+  } else if (dense) {
     const int nb1 = (int)((N * 2 + 255) / 256), nb2 = (int)(N * 160000 / 256 > 2048 ? 2048 : (N * 160000 + 255) / 256);
     hipLaunchKernelGGL(t_loss_dense, dim3(nb1), dim3(256), 0, st, N * 2, 1.f / (2.f * n), o1, t1, do1, lpart);
     hipLaunchKernelGGL(t_sum_ordered, dim3(1), dim3(64), 0, st, nb1, 1, lpart, loss);
     hipLaunchKernelGGL(t_loss_dense, dim3(nb2), dim3(256), 0, st, N * 160000, 1.f / (160000.f * n), o2, t2, do2, lpart + 2048);
     hipLaunchKernelGGL(t_sum_ordered, dim3(1), dim3(64), 0, st, nb2, 1, lpart + 2048, loss + 1);
     OFX_HIP(hipGetLastError());
-  } else {
-    OFX_HIP(hipMemsetAsync(do2, 0, N * 160000 * 4, st));
-    K(t_loss_seed, N, n, rows, o1, o2, y_act, y_ptr, do1, do2, lpart);
-    hipLaunchKernelGGL(t_sum_ordered, dim3(1), dim3(64), 0, st, n, 2, lpart, loss);
   }
 
   // ---- backward: head 2 ----
-  if ((rc = ofx_fit_out_bw(st, n, head_src(3), do2, part, fpart, G(50), G(51)))) return rc;
+  if (dense && (rc = ofx_fit_out_bw(st, n, head_src(3), do2, part, fpart, G(50), G(51)))) return rc;
   const float *dzn = do2;
   for (int j = 2; j >= 0; j--) {
     const int s = uS[j];
-    if ((rc = ofx_fit_b1_up(st, n, kUO[j], kUO[j + 1], s, s, 1, dzn, T(32 + 6 * (j + 1)), uz[j], ustat[j], uact[j], legacy, ug[j], part, &nb))) return rc;
-    if ((rc = ofx_fit_finish(st, nb, kUO[j], 1.0, part, nullptr, nullptr, sums, nullptr, nullptr))) return rc;
+    if (j < 2 || dense) {   // (the textbook path has the last layer's g and its sums already)
+      if ((rc = ofx_fit_b1_up(st, n, kUO[j], kUO[j + 1], s, s, 1, dzn, T(32 + 6 * (j + 1)), uz[j], ustat[j], uact[j], legacy, ug[j], part, &nb))) return rc;
+      if ((rc = ofx_fit_finish(st, nb, kUO[j], 1.0, part, nullptr, nullptr, sums, nullptr, nullptr))) return rc;
+    }
     if ((rc = ofx_fit_bw(st, n, kUI[j], kUO[j], s, s, head_src(j), 1, ug[j], uz[j], ustat[j], T(34 + 6 * j), sums, part,
                          G(32 + 6 * j), G(33 + 6 * j), G(34 + 6 * j), G(35 + 6 * j)))) return rc;
     dzn = ug[j];
