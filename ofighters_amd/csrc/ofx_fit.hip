@@ -17,14 +17,16 @@
 //   f_first_* /  the first layer (1-bit inputs) is never materialised: batch statistics and the weight gradient (BatchNorm's
 //   f_bits_corr  backward folded in analytically) from the autocorrelation of the shifted bit maps (popcounts), its pooled
 //   f_b1_first   activation through the forward's table kernel, the pooling backward from an x-hat table; g kept compact.
-//   f_out_*      the output convolution (8 -> 1 at 400 x 400 behind the last up-sampling) in PHASE form: a 3 x 3
+//   f_top_point_* the textbook targets (one error per sample): the output convolution, its gradients and the last head layer's g
+//                from the ONE heat-map pixel that carries an error.
+//   f_out_*      (dense targets) the output convolution (8 -> 1 at 400 x 400 behind the last up-sampling) in PHASE form: a 3 x 3
 //                convolution of the 200 x 200 activation with 4 phase channels on f_conv_fwd / f_bw, plus two small
 //                kernels that correct the plane's frame (zero padding against the phase form's repeated edge) exactly.
 //
 // Every reduction has a fixed order (tile -> block assignment by index, ordered combines): two fits from the same state
 // give the same bits.  fp32 on the vector ALU (accumulators paired over the channel index: v_pk_fma_f32) with FMA
 // contraction; checked against torch autograd in float64 and against the plain form (tests/test_train.py).  Per row of
-// the minibatch 11 MB of workspace instead of 61 MB; 4096 rows in 84 ms.
+// the minibatch 11 MB of workspace instead of 61 MB; 4096 rows in 68 ms.
 #include "ofx_internal.h"
 #include "ofx_fit.h"
 
