@@ -409,6 +409,17 @@ __global__ __launch_bounds__(256) void t_dense_bwd_x(int n, int in_n, int out_n,
     }
 }
 
+// out[c][r] = in[r][c] (a weight matrix or a batch of activations for the MFMA GEMM's row-major operands)
+__global__ void t_transpose(int rows, int cols, const float *in, float *out) {
+  __shared__ float tile[32][33];
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8)
+    if (r0 + i < rows && c0 + tx < cols) tile[i][tx] = in[(size_t)(r0 + i) * cols + c0 + tx];
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8)
+    if (c0 + i < cols && r0 + tx < rows) out[(size_t)(c0 + i) * rows + r0 + tx] = tile[tx][i];
+}
+
 // f[n][5008] = concat(vec8, flatten_hwc(x4 [n][8][25][25])) and its transpose for the gradient
 __global__ void t_concat_fwd(int n, const ofx_transition *rows, const float *x4, float *f, int next_head) {
   const size_t total = (size_t)n * 5008;
@@ -624,7 +635,7 @@ static int dqn_fit_lean(ofx_handle *h, float *weights, float *adam_m, float *ada
   size_t need = 0;
   auto sz = [&](size_t bytes) { need += (bytes + 255) & ~(size_t)255; };
   for (int i = 0; i < 4; i++) { if (i) sz(4 * N * 8 * tS[i] * tS[i]); sz(4 * N * 8 * tS[i] * tS[i] / (i ? 1 : 4)); }  // z (not layer 0's), g (layer 0: compact)
-  sz(4 * ofx_fit_first_floats());
+  sz(4 * ofx_fit_first_floats()); sz(4 * 5008 * 100);
   sz(N * 8 * 40000); sz(8 * ofx_fit_first_doubles(n));                                                     // window positions, correlation
   for (int i = 0; i < 3; i++) sz(4 * N * 8 * tS[i + 1] * tS[i + 1]);                                       // pooled activation
   for (int j = 0; j < 3; j++) { sz(4 * N * kUO[j] * uS[j] * uS[j]); sz(4 * N * kUO[j] * uS[j] * uS[j]); }
@@ -649,7 +660,7 @@ static int dqn_fit_lean(ofx_handle *h, float *weights, float *adam_m, float *ada
   float *tz[4], *tg[4], *tstat[4], *tact[4], *uz[3], *ug[3], *ustat[3], *uact[3], *tp[3];
   for (int i = 0; i < 3; i++) tp[i] = A.f(N * 8 * tS[i + 1] * tS[i + 1]);
   for (int i = 0; i < 4; i++) { tz[i] = i ? A.f(N * 8 * tS[i] * tS[i]) : nullptr; tg[i] = A.f(N * 8 * tS[i] * tS[i] / (i ? 1 : 4)); tstat[i] = A.f(16); tact[i] = A.f(16); }
-  float *luts = A.f(ofx_fit_first_floats());
+  float *luts = A.f(ofx_fit_first_floats()), *w1t = A.f(5008 * 100);
   unsigned char *kk0 = (unsigned char *)A.take(N * 8 * 40000);
   double *cpart = A.d(ofx_fit_first_doubles(n));
   for (int j = 0; j < 3; j++) { uz[j] = A.f(N * kUO[j] * uS[j] * uS[j]); ug[j] = A.f(N * kUO[j] * uS[j] * uS[j]); ustat[j] = A.f(16); uact[j] = A.f(16); }
@@ -736,7 +747,10 @@ static int dqn_fit_lean(ofx_handle *h, float *weights, float *adam_m, float *ada
   // ---- dense1 + trunk ----
   K(t_relu_mask, N * 100, N * 100, d1, dd1);
   K(t_dense_bwd_w, (size_t)1253 * 25 * 8, n, 5008, 100, f, dd1, G(24), G(25));
-  K(t_dense_bwd_x, ((N + 3) / 4) * 1252, n, 5008, 100, dd1, T(24), df, 0);
+  // d f = dd1 x W1^T on the f32 MFMA GEMM (the 5008 x 100 kernel transposed first): 2 x 5008 x 100 FLOP per row
+  hipLaunchKernelGGL(t_transpose, dim3((100 + 31) / 32, (5008 + 31) / 32), dim3(256), 0, st, 5008, 100, T(24), w1t);
+  OFX_HIP(hipGetLastError());
+  if ((rc = ofx_launch_gemm(h, dd1, 100, w1t, 5008, nullptr, df, 5008, n, 5008, 100, 0))) return rc;
   K(t_concat_bwd, N * 5000, n, df, dp3);
   dzn = dp3;
   for (int i = 3; i >= 0; i--) {
