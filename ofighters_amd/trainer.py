@@ -26,7 +26,7 @@ class DeviceTrainer:
         self.batch_size = batch_size                        # 8 (:307)
         self.seed = seed
         self.fit_batch = fit_batch                          # rows per optimisation step (the reference fits on 8; one
-                                                            # replay takes 4.4 ms at 64 rows, 68 ms at 4096)
+                                                            # replay takes 4.5 ms at 64 rows, 66 ms at 4096)
         self.reference_quirks = bool(reference_quirks)      # Trainer.replay as written instead of the textbook DQN step
         self.fit_steps = 0
         self.draws = 0
