@@ -356,6 +356,24 @@ class Workload:
         return s
 
 
+def launch_ranks(n, argv):
+    """Start n ranks of this script on this node (one process per GPU, rendezvous on 127.0.0.1, a free port) and wait
+    for them.  Runs in a parent that has not imported torch: nothing here initialises the GPU.  Returns the exit code."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # the host driver only supports dmabuf IPC (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -383,11 +401,31 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary configurations at N=1")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: THIS process becomes the launcher - it has imported neither
+        # torch nor the library and never touches the GPU - and starts the N ranks as child processes through
+        # torch.distributed.run (the line the driver itself uses for N > 1); rank 0's JSON line goes to the inherited
+        # stdout, the exit code is the workers'.  No exec: the ranks are children, the parent waits.
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        # a line that says n_gpus = world while the caller asked for --gpus N would be read as an N-GPU number
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE is %d (RANK %s): refusing to print a line for another "
+                         "world size; launch %d ranks (python bench.py --gpus %d, or torch.distributed.run "
+                         "--nproc-per-node %d bench.py --gpus %d)\n"
+                         % (args.gpus, world, os.environ.get("RANK", "unset"), args.gpus, args.gpus, args.gpus, args.gpus))
+        sys.exit(2)
     import numpy as np
     import torch
+    n_dev = torch.cuda.device_count()
+    if world > 1 and os.environ.get("OFX_DIST_BACKEND", "nccl") == "nccl" and n_dev < world:
+        sys.stderr.write("bench.py: --gpus %d but this node shows %d GPU(s): RCCL needs one device per rank\n" % (world, n_dev))
+        sys.exit(2)
 
     dist = None
     local_rank %= max(1, torch.cuda.device_count())
