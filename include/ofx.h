@@ -214,6 +214,34 @@ int ofx_rollout(ofx_handle *h, const int32_t *behaviours_host, uint64_t seed, ui
 int ofx_get_host(ofx_handle *h, int field, void *dst_host, size_t bytes);
 void *ofx_device_ptr(ofx_handle *h, int field);
 size_t ofx_field_bytes(const ofx_handle *h, int field);
+/* ---- zero-copy views of the handle's arrays -----------------------------
+ * The reference's plugin seam is "any object with .play(obs)" (agents/agent.py:34-37); its learning agent reads
+ * obs.ship_map / obs.laser_map / obs.vector[:8] and answers an Action (agents/qlearnIA_V2.py:206-220,447-454).  For a
+ * batch the same seam is an EXTERNAL POLICY that reads the maps and the state of all N x M ships where they lie in HBM
+ * and writes its [N][M] ofx_action array there: ofx_field_desc / ofx_map_desc describe a handle-owned array (pointer,
+ * element type, shape, strides in elements, device) so that a host framework can wrap it WITHOUT a copy - a DLPack
+ * capsule, __cuda_array_interface__, torch.as_tensor (ofighters_amd/engine.py: ArenaBatch.tensor / maps_tensor).
+ * Ownership: the memory belongs to the handle and lives until ofx_destroy; the CONTENTS of a state field are
+ * those of the last ofx_step / ofx_restart* / ofx_spawn*, of a map those of the last ofx_rasterise of that type, and the
+ * next such call overwrites them in place.  Everything runs on ofx_stream(h): read and write the views on that stream
+ * (or order yours against it), never concurrently with an entry point that writes them.                            */
+enum { OFX_DT_U8 = 0, OFX_DT_I16 = 1, OFX_DT_I32 = 2, OFX_DT_I64 = 3, OFX_DT_F32 = 4, OFX_DT_F64 = 5 };
+typedef struct ofx_tensor_desc {
+  void *data;          /* device pointer                                    */
+  int32_t dtype;       /* OFX_DT_*                                          */
+  int32_t itemsize;    /* bytes per element                                 */
+  int32_t ndim;        /* 1..4                                              */
+  int32_t device;      /* HIP device ordinal of the handle                  */
+  int64_t shape[4];
+  int64_t stride[4];   /* in elements; dense row-major                      */
+} ofx_tensor_desc;
+/* state field `field` (OFX_F_*): [N][M], [N][L] or [N]                      */
+int ofx_field_desc(ofx_handle *h, int field, ofx_tensor_desc *out);
+/* map `which` (0 ship, 1 laser) of `map_type`: [N][W rows = y][H cols = x] of uint8 / float32 / float64, or
+ * [N][W*H/8] uint8 for OFX_MAP_BITS; the handle's internal buffer (allocated at the first ofx_rasterise of that type
+ * with NULL outputs, or here)                                               */
+int ofx_map_desc(ofx_handle *h, int map_type, int which, ofx_tensor_desc *out);
+
 /* number of lasers dropped because an arena's list was full since the last
  * call (never silent truncation); resets the counter.                        */
 int ofx_overflow_count(ofx_handle *h, int64_t *count_host);

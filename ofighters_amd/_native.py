@@ -58,6 +58,16 @@ class OfxTransition(C.Structure):
                 ("head_prev", C.c_float * 8), ("head_next", C.c_float * 8)]
 
 
+class OfxTensorDesc(C.Structure):
+    """include/ofx.h: struct ofx_tensor_desc - a handle-owned HBM array described for a zero-copy view."""
+    _fields_ = [("data", C.c_void_p), ("dtype", C.c_int32), ("itemsize", C.c_int32), ("ndim", C.c_int32),
+                ("device", C.c_int32), ("shape", C.c_int64 * 4), ("stride", C.c_int64 * 4)]
+
+
+DT_U8, DT_I16, DT_I32, DT_I64, DT_F32, DT_F64 = range(6)
+DT_TYPESTR = {DT_U8: "|u1", DT_I16: "<i2", DT_I32: "<i4", DT_I64: "<i8", DT_F32: "<f4", DT_F64: "<f8"}
+
+
 class OfxPolicyDesc(C.Structure):
     _fields_ = [("n_floats", C.c_int32), ("offset", C.c_int32 * 64), ("count", C.c_int32 * 64),
                 ("n_tensors", C.c_int32)]
@@ -93,6 +103,8 @@ SIGNATURES = {
     "ofx_get_host": (_i, [_vp, _i, _vp, _sz]),
     "ofx_device_ptr": (_vp, [_vp, _i]),
     "ofx_field_bytes": (_sz, [_vp, _i]),
+    "ofx_field_desc": (_i, [_vp, _i, C.POINTER(OfxTensorDesc)]),
+    "ofx_map_desc": (_i, [_vp, _i, _i, C.POINTER(OfxTensorDesc)]),
     "ofx_overflow_count": (_i, [_vp, C.POINTER(C.c_int64)]),
     "ofx_episode_scores": (_i, [_vp, _vp]),
     "ofx_scores_allreduce": (_i, [_vp, _vp, _vp]),

@@ -538,6 +538,73 @@ extern "C" void *ofx_device_ptr(ofx_handle *h, int field) {
   return h ? field_ptr(h, field, &b) : nullptr;
 }
 
+// ---- zero-copy views (ofx_field_desc / ofx_map_desc)
+static void desc_fill(ofx_tensor_desc *d, void *data, int dtype, int device, int ndim, int64_t s0, int64_t s1, int64_t s2) {
+  static const int isz[] = {1, 2, 4, 8, 4, 8};
+  d->data = data;
+  d->dtype = dtype;
+  d->itemsize = isz[dtype];
+  d->ndim = ndim;
+  d->device = device;
+  const int64_t sh[4] = {s0, s1, s2, 1};
+  int64_t st = 1;
+  for (int i = 3; i >= 0; i--) {
+    d->shape[i] = i < ndim ? sh[i] : 1;
+    d->stride[i] = i < ndim ? st : 0;
+    if (i < ndim) st *= sh[i];
+  }
+}
+
+extern "C" int ofx_field_desc(ofx_handle *h, int field, ofx_tensor_desc *out) {
+  if (!h || !out) { ofx_set_error("ofx_field_desc: null argument"); return OFX_ERR_INVALID; }
+  size_t b;
+  void *ptr = field_ptr(h, field, &b);
+  if (!ptr) { ofx_set_error("ofx_field_desc: unknown field %d", field); return OFX_ERR_INVALID; }
+  const int64_t N = h->cfg.n_arenas, M = h->cfg.n_ships, L = h->cfg.laser_cap;
+  switch (field) {
+    case OFX_F_SHIP_ALIVE: desc_fill(out, ptr, OFX_DT_U8, h->cfg.device, 2, N, M, 1); break;
+    case OFX_F_KILLER: desc_fill(out, ptr, OFX_DT_I16, h->cfg.device, 2, N, M, 1); break;
+    case OFX_F_N_LASERS:
+    case OFX_F_TIME: desc_fill(out, ptr, OFX_DT_I32, h->cfg.device, 1, N, 1, 1); break;
+    case OFX_F_LASER_X:
+    case OFX_F_LASER_Y:
+    case OFX_F_LASER_DX:
+    case OFX_F_LASER_DY: desc_fill(out, ptr, OFX_DT_F64, h->cfg.device, 2, N, L, 1); break;
+    case OFX_F_LASER_OWNER:
+    case OFX_F_LASER_DEAD: desc_fill(out, ptr, OFX_DT_U8, h->cfg.device, 2, N, L, 1); break;
+    default: desc_fill(out, ptr, OFX_DT_I32, h->cfg.device, 2, N, M, 1); break;   // the [N][M] int32 ship / agent fields
+  }
+  if ((size_t)(out->shape[0] * (out->ndim > 1 ? out->shape[1] : 1)) * (size_t)out->itemsize != b) {
+    ofx_set_error("ofx_field_desc: field %d: description and size disagree", field);
+    return OFX_ERR_STATE;
+  }
+  return OFX_OK;
+}
+
+extern "C" int ofx_map_desc(ofx_handle *h, int map_type, int which, ofx_tensor_desc *out) {
+  if (!h || !out) { ofx_set_error("ofx_map_desc: null argument"); return OFX_ERR_INVALID; }
+  if (map_type < OFX_MAP_U8 || map_type > OFX_MAP_BITS || which < 0 || which > 1) {
+    ofx_set_error("ofx_map_desc: map type %d / map %d", map_type, which);
+    return OFX_ERR_INVALID;
+  }
+  OFX_HIP(hipSetDevice(h->cfg.device));
+  const size_t per_map = ofx_map_bytes(h, map_type);
+  for (int w = 0; w < 2; w++)
+    if (!h->maps[map_type][w]) {   // the buffer ofx_rasterise(h, map_type, NULL, NULL) fills: the same lazy allocation
+      OFX_HIP(hipMalloc(&h->maps[map_type][w], per_map * (size_t)h->cfg.n_arenas));
+      OFX_HIP(hipMemsetAsync(h->maps[map_type][w], 0, per_map * (size_t)h->cfg.n_arenas, h->stream));
+    }
+  const int64_t N = h->cfg.n_arenas, W = h->cfg.width, H = h->cfg.height;
+  void *ptr = h->maps[map_type][which];
+  switch (map_type) {
+    case OFX_MAP_U8: desc_fill(out, ptr, OFX_DT_U8, h->cfg.device, 3, N, W, H); break;
+    case OFX_MAP_F32: desc_fill(out, ptr, OFX_DT_F32, h->cfg.device, 3, N, W, H); break;
+    case OFX_MAP_F64: desc_fill(out, ptr, OFX_DT_F64, h->cfg.device, 3, N, W, H); break;
+    default: desc_fill(out, ptr, OFX_DT_U8, h->cfg.device, 2, N, (int64_t)per_map, 1); break;
+  }
+  return OFX_OK;
+}
+
 extern "C" int ofx_get_host(ofx_handle *h, int field, void *dst_host, size_t bytes) {
   if (!h || !dst_host) { ofx_set_error("ofx_get_host: null argument"); return OFX_ERR_INVALID; }
   size_t b;

@@ -13,7 +13,9 @@
 #define OFX_FIT_SRC_PLANE 5  /* a stored plane as it is, zero outside (the pooled activation kept by the forward) */
 #define OFX_FIT_SRC_ACTREP 4 /* relu(bn(z_prev)) at its own resolution, edge cells repeated outwards (phase form) */
 
+#ifndef OFX_FIT_MAX_BLOCKS
 #define OFX_FIT_MAX_BLOCKS 2048 /* persistent grids: at most this many blocks, each with one row of partial sums */
+#endif
 
 struct ofx_fit_src {
   int kind;

@@ -449,6 +449,7 @@ __global__ __launch_bounds__(256) void f_finish(int nblocks, int c_n, double cou
     const float mean = (float)m, var = (float)(v > 0.0 ? v : 0.0);
     stat[2 * k] = mean;
     stat[2 * k + 1] = var;
+    stat[16 + k] = (float)(m - (double)mean);   // what the rounding of the mean dropped (f_bw: BatchNorm's backward)
     const float sc = gamma[k] * rsqrtf(var + 1e-3f);
     act[2 * k] = sc;
     act[2 * k + 1] = beta[k] - mean * sc;
@@ -770,15 +771,23 @@ __global__ __launch_bounds__(NT) void f_bw(int n, int H, int W, FitSrc S, float 
   __shared__ double dacc[NT / 64][NA];
   // BatchNorm's backward per channel: dz = a (g - m0 - (z - mean) c).  Computed once: written out per element, the two
   // double divisions by `count` alone were ~100 instructions for every one of a tile's 6 400 gradient values.
-  __shared__ float cf[BN ? CO : 1][4];
+  // m0, c and the batch mean are carried as two floats each (value + what its rounding dropped; stat[16 + c] for the
+  // mean): their rounding error is the SAME at every pixel of the batch, so it does not average out in the weight
+  // gradient sum in * dz - at 1024 rows fp32 coefficients left conv2's kernel gradient 7e-4 of its scale away from the
+  // float64 graph, 1e-3 for conv1's gamma (r04, tools/fit_check64.py; the plain form computes them per element in doubles).
+  __shared__ float cf[BN ? CO : 1][7];
   if constexpr (BN)
     if (threadIdx.x < CO) {
       const int co = threadIdx.x;
       const float rs = rsqrtf(stat[2 * co + 1] + 1e-3f);
+      const double m0 = sums[2 * co] / count, c = (double)rs * (sums[2 * co + 1] / count);
       cf[co][0] = gamma[co] * rs;
-      cf[co][1] = (float)(sums[2 * co] / count);
-      cf[co][2] = rs * (float)(sums[2 * co + 1] / count);
+      cf[co][1] = (float)m0;
+      cf[co][2] = (float)c;
       cf[co][3] = stat[2 * co];
+      cf[co][4] = (float)(m0 - (double)cf[co][1]);
+      cf[co][5] = (float)(c - (double)cf[co][2]);
+      cf[co][6] = stat[16 + co];
     }
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const int ci = wv % CI, sub = wv / CI;
@@ -841,7 +850,10 @@ __global__ __launch_bounds__(NT) void f_bw(int n, int H, int W, FitSrc S, float 
         }
         if constexpr (BN) {
 #pragma unroll
-          for (int k = 0; k < V; k++) d[k] = cf[co][0] * (d[k] - cf[co][1] - (zz[k] - cf[co][3]) * cf[co][2]);
+          for (int k = 0; k < V; k++) {
+            const float zm = (zz[k] - cf[co][3]) - cf[co][6];
+            d[k] = cf[co][0] * (((d[k] - cf[co][1]) - zm * cf[co][2]) - (zm * cf[co][5] + cf[co][4]));
+          }
           if constexpr (SRC != OFX_FIT_SRC_BITS) {   // nothing reads the first layer's dz
             if constexpr (V == 4) *reinterpret_cast<float4 *>(g + at) = make_float4(d[0], d[1], d[2], d[3]);
             else *reinterpret_cast<float2 *>(g + at) = make_float2(d[0], d[1]);
@@ -908,15 +920,19 @@ __global__ __launch_bounds__(256) void f_bw_small(int n, int H, int W, FitSrc S,
   __shared__ float lo[lo_floats<SRC, CI, W_TR, TW>];
   __shared__ __align__(16) float dzt[CO][W_TR][DP];
   __shared__ double dacc[4][NA];
-  __shared__ float cf[BN ? CO : 1][4];   // see f_bw
+  __shared__ float cf[BN ? CO : 1][7];   // see f_bw
   if constexpr (BN)
     if (threadIdx.x < CO) {
       const int co = threadIdx.x;
       const float rs = rsqrtf(stat[2 * co + 1] + 1e-3f);
+      const double m0 = sums[2 * co] / count, c = (double)rs * (sums[2 * co + 1] / count);
       cf[co][0] = gamma[co] * rs;
-      cf[co][1] = (float)(sums[2 * co] / count);
-      cf[co][2] = rs * (float)(sums[2 * co + 1] / count);
+      cf[co][1] = (float)m0;
+      cf[co][2] = (float)c;
       cf[co][3] = stat[2 * co];
+      cf[co][4] = (float)(m0 - (double)cf[co][1]);
+      cf[co][5] = (float)(c - (double)cf[co][2]);
+      cf[co][6] = stat[16 + co];
     }
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, r = tid / TPR, q = tid - r * TPR;
   const bool active = r < W_TR;
@@ -959,7 +975,8 @@ __global__ __launch_bounds__(256) void f_bw_small(int n, int H, int W, FitSrc S,
         float d = gv[u];
         if constexpr (BN) {
           if (y0 + yy < H && xx < TW) {
-            d = cf[co][0] * (d - cf[co][1] - (zv[u] - cf[co][3]) * cf[co][2]);
+            const float zm = (zv[u] - cf[co][3]) - cf[co][6];
+            d = cf[co][0] * (((d - cf[co][1]) - zm * cf[co][2]) - (zm * cf[co][5] + cf[co][4]));
             g[((s * CO + co) * (size_t)H + y0 + yy) * W + x0 + xx] = d;
           }
         }
@@ -1214,6 +1231,7 @@ __global__ __launch_bounds__(256) void f_first_prepare(const double *cc, const f
     const float meanf = (float)mean, varf = (float)(var > 0.0 ? var : 0.0);
     stat[2 * co] = meanf;
     stat[2 * co + 1] = varf;
+    stat[16 + co] = (float)(mean - (double)meanf);
     const float rs = rsqrtf(varf + 1e-3f), s_ = gamma[co] * rs;
     act[2 * co] = s_;
     act[2 * co + 1] = beta[co] - meanf * s_;

@@ -15,7 +15,7 @@ struct HeadParams2 {
   const float *w2fr, *w3fr;     // frame-line variants of the phase weights (PrepLayout::w2fr, w3fr)
   const float *efr;             // frame phase weights of upconv4 [line h|v][side][parity 2][3][8] (PrepLayout::efr)
   float *u2fr;                  // [S][4][100][4] exact frame lines of uprelu2: row 0, row 99, col 0, col 99
-  float *u3fr;                  // [S][4][200][8] exact frame lines of uprelu3
+  float *vfr;                   // [S][4][200][9] exact frame lines of the tap planes V_t = sum_c w4[t][c] uprelu3_c (top, bottom, left, right)
   float *c4;                    // [S][4][400]   zero-padding corrections of the heat-map frame pixels
   const uint8_t *mask;          // [S] or null
   int32_t *live;                // with a mask: scratch [1 + S], filled here with the count and the ordered list of the
@@ -35,7 +35,7 @@ struct HeadParams2 {
 };
 
 // bytes of the three frame buffers for S samples
-size_t ofx_head_frame_bytes(size_t S, size_t *u2fr, size_t *u3fr, size_t *c4);
+size_t ofx_head_frame_bytes(size_t S, size_t *u2fr, size_t *vfr, size_t *c4);
 // mask [S] -> live[0] = count, live[1 + i] = i-th selected ship (one workgroup, a scan)
 int ofx_head_compact(ofx_handle *h, int S, const uint8_t *mask, int32_t *live);
 // k_head_frames + k_head_stream on the handle's stream

@@ -6,14 +6,22 @@
 // low-resolution grid with pre-combined weights (k_policy_prepare), so no upsampled tensor is ever formed:
 //   stage A  uprelu2 (100x100x4) from uprelu1: GEMM  [pixel][phase*4+co] , K = 9 taps x 2 ci      v_mfma_f32_16x16x4
 //   stage B  uprelu3 (200x200x8) from uprelu2: GEMM  [quad][phase*4+co] x 2 channel halves, K = 36  v_mfma_f32_16x16x4
-//   stage C  heat map (400x400)  from uprelu3: per pixel out[phase] = sum_k W[k][phase] in[k], K = 72: v_mfma_f32_4x4x1
-//            (16 blocks, the A block broadcast with CBSZ / ABID: M = 4 phases, N = 64 pixels, no padded dimension)
+//   stage C  heat map (400x400)  from uprelu3, in TAP-PLANE form (r04).  The up-sampling and the 3x3 taps are linear and
+//            the layer has ONE output channel, so the channel sum goes first, on the low-resolution grid:
+//              V_t[y][x] = sum_c w4[t][c] uprelu3_c[y][x]            t = (ky, kx), 9 tap planes    (1x1 convolution, 72 MACs)
+//              heat[2y+a][2x+b] = b4 + sum_t up2(V_t)[2y+a+ky-1][2x+b+kx-1]                         (separable stencil, 60 MACs)
+//            against 288 MACs per low-resolution pixel for the pre-combined phase weights (r01 - r03: 144 v_mfma_f32_4x4x1
+//            per pixel pair).  The 1x1 runs on the matrix cores in the PRODUCER, straight from stage B's accumulators:
+//            stage B is issued with the weights as the A operand, so a lane ends up with all 8 channels of ONE uprelu3
+//            pixel, which is the B operand of 24 v_mfma_f32_4x4x1 (16 blocks, the weight block broadcast with CBSZ /
+//            ABID: M = 4 taps, N = 64 pixels).  uprelu3 itself is never stored; the 9 tap planes are.  The stencil runs
+//            on the vector ALU in the consumers (v_pk_fma_f32 over a pixel pair).
 //
-// k_head_stream: one 512-thread workgroup streams a 100-column half of one ship's plane top to bottom.  uprelu3 and
-// uprelu2 live only as ROLLING WINDOWS of rows in LDS (16-row rings); waves 0-3 produce (stage A + B), waves 4-7
-// consume (stage C + arg-max) two sub-steps behind, ONE barrier per sub-step of 5 uprelu3 rows.  Nothing of the
-// 42 GB uprelu3 tensor or the 5 GB uprelu2 tensor (32768 ships) touches HBM.  The schedule (lags, ring sizes) is
-// checked by tools/head_schedule.py.
+// k_head_stream: one 512-thread workgroup streams a 100-column half of one ship's plane top to bottom.  The tap planes
+// and uprelu2 live only as ROLLING WINDOWS of rows in LDS (16-row rings); waves 0-3 produce (stage B + the 1x1), waves
+// 4-7 consume (stage A for the producers' next rows, the stencil + arg-max) two sub-steps behind, ONE barrier per
+// sub-step of 5 rows.  Nothing of the 42 GB uprelu3 tensor or the 5 GB uprelu2 tensor (32768 ships) touches HBM.  The
+// schedule (lags, ring sizes) is checked by tools/head_schedule.py.
 //
 // Zero padding: the phase form sees the clamp-extended low-resolution plane, which differs from Keras' zero padding
 // only on the 1-pixel frame of each layer's output.  k_head_frames computes those thin lines exactly (frame lines of
@@ -23,12 +31,6 @@
 #include "ofx_lowp.h"
 #include <stdlib.h>
 
-#ifndef HS_A_FIRST
-#define HS_A_FIRST 1      // consumers: stage A in front of the stage-C pass (0: behind it, the r02 order)
-#endif
-#ifndef HS_C_PRIO
-#define HS_C_PRIO 0       // s_setprio of the consumer waves (r02: 1; with stage A in front 0 is the faster one)
-#endif
 #ifndef OFX_HEAD_HOOKS
 #define OFX_HEAD_HOOKS 0  // 1: the OFX_HEAD_ABLATE timing switches are compiled into k_head_stream (results are wrong)
 #endif
@@ -240,7 +242,13 @@ __global__ __launch_bounds__(HF_THREADS) void k_head_frames_ref(HeadParams2 p) {
     u3l[(cl * 200 + y) * 8 + co] = u3l[(rl * 200 + x) * 8 + co];
   }
   __syncthreads();
-  for (int e = tid; e < 6400; e += HF_THREADS) p.u3fr[(size_t)s * 6400 + e] = u3l[e];
+  // the tap planes along the four lines: V_t = sum_c w4[t][c] uprelu3_c (what k_head_stream's ring holds)
+  for (int e = tid; e < 4 * 200 * 9; e += HF_THREADS) {
+    const int tp = e % 9, cell = e / 9;
+    float acc = 0.f;
+    for (int ci = 0; ci < 8; ci++) acc = fmaf(p.w4raw[tp * 8 + ci], u3l[cell * 8 + ci], acc);
+    p.vfr[(size_t)s * 7200 + e] = acc;
+  }
 
   // ---- corrections of the heat-map frame pixels: the taps of upconv4 that fall into the zero padding, evaluated
   // on the clamp-extended up-sampled plane the phase form sees there ----
@@ -460,8 +468,15 @@ __global__ __launch_bounds__(HG_THREADS) void k_head_frames(HeadParams2 p) {
     u3l[(((c & 2) ? 3 : 2) * 200 + y) * 8 + co] = val;
   }
   __syncthreads();
-  for (int e = tid; e < 1600; e += HG_THREADS)
-    reinterpret_cast<f32x4 *>(p.u3fr + (size_t)s * 6400)[e] = reinterpret_cast<const f32x4 *>(u3l)[e];
+  // the tap planes along the four lines: V_t = sum_c w4[t][c] uprelu3_c (what k_head_stream's ring holds; the same
+  // sequential sum over c as the 1x1's MFMA chain)
+  for (int e = tid; e < 4 * 200 * 9; e += HG_THREADS) {
+    const int tp = e % 9, cell = e / 9;
+    float acc = 0.f;
+#pragma unroll
+    for (int ci = 0; ci < 8; ci++) acc = fmaf(p.w4raw[tp * 8 + ci], u3l[cell * 8 + ci], acc);
+    p.vfr[(size_t)s * 7200 + e] = acc;
+  }
 
   // ---- corrections of the heat-map frame pixels (PrepLayout::efr: the conv taps of the row / column outside the
   // image in phase form along the line): pixel 2 j + b of a line gets sum_o E[b][o] L[j + o - 1] ----
@@ -503,13 +518,20 @@ __global__ __launch_bounds__(HG_THREADS) void k_head_frames(HeadParams2 p) {
 constexpr int HS_GPR = 13;               // groups of 4 quads per quad row: 50 quads + 1 halo + 1 pad
 constexpr int HS_NTILES = 325;           // 16-quad M-tiles of a strip (100 quad rows x 13 groups / 4)
 constexpr int HS_NS = 42;                // sub-steps
-constexpr int HS_NR3 = 16, HS_P3 = 106;  // uprelu3 ring: rows, row pitch (column x at index x - c0 + 1 + 4 side)
-constexpr int HS_PL3 = HS_NR3 * HS_P3 + 4;   // channel plane stride (floats)
+constexpr int HS_NR3 = 16, HS_P3 = 106;  // tap-plane ring (one row per uprelu3 row): rows, row pitch (column x at index x - c0 + 1 + 4 side)
+constexpr int HS_PL3 = HS_NR3 * HS_P3 + 4;   // plane stride (floats)
+constexpr int HS_NV = 9;                 // tap planes V_t, t = 3 ky + kx
 // uprelu2 ring (column c at index c - (side ? 46 : -1)): 16 row slots + 2 mirror slots (16, 17 repeat 0, 1), so the
-// three rows of a window are always contiguous and the A gather of stage B is one base address + immediates
+// three rows of a window are always contiguous and the gather of stage B is one base address + immediates
 constexpr int HS_NR2 = 16, HS_P2 = 56;
-constexpr int HS_PL2 = (HS_NR2 + 2) * HS_P2;  // 1008 = 16 mod 32: the channel planes of the MFMA A-gather land on different banks
+constexpr int HS_PL2 = (HS_NR2 + 2) * HS_P2;  // 1008 = 16 mod 32: the channel planes of the MFMA gather land on different banks
 static_assert(HS_PL2 % 32 == 16, "uprelu2 plane stride");
+// group (flat over quad rows) -> its offsets in the two rings: both repeat every 16 quad rows = 208 groups, and the four
+// groups of M-tile T are entries 4 (T mod 52) .. + 3
+constexpr int HS_TABP = 16 * HS_GPR;
+static_assert(HS_TABP == 4 * 52, "table period in tiles");
+// LDS of a workgroup: two of them per CU (160 KB)
+static_assert(4 * (HS_NV * HS_PL3 + 4 * HS_PL2 + HS_TABP) <= 80 * 1024, "two workgroups per CU");
 // uprelu2 row pairs finished by the end of sub-step s - 1 (0 = by the prologue): the table of tools/head_schedule.py,
 // 2, 3, 5, 6, 7, 8, 10, ...: min(50, s + 2 + ((s + 2) >> 2)) (hs_pairs_done_c below)
 // Stage-A tile of consumer wave cw in sub-step st (uprelu2 rows for the M-tiles of st + 1): tile id 2 pair + half belongs
@@ -533,7 +555,7 @@ __device__ __forceinline__ int hs_tiles_done(int s) {  // tiles finished by the 
   return s < 0 ? 0 : min(HS_NTILES, 8 * (s + 1) + ((s + 1) >> 3));
 }
 
-// LDS reads of stage C: two 8-byte reads of one row.  volatile keeps them apart (merged into one ds_read2_b64 they
+// LDS reads of the stencil: two 8-byte reads of one row.  volatile keeps them apart (merged into one ds_read2_b64 they
 // take 8 LDS cycles instead of 2 + 2, MI355X_MICROARCH.md) and in program order (the pipeline below is explicit)
 typedef const volatile __attribute__((address_space(3))) f32x2 hs_lds_v2;
 
@@ -545,25 +567,36 @@ __device__ __forceinline__ void hs_u2_store(float *u2r, int ch, int row, int col
   if (slot < 2) q[HS_NR2 * HS_P2] = v;
 }
 
+// x2 bilinear: output row 2 i + a, tap k in {0, 1, 2} = up-res row 2 i + a + k - 1, weight of low-res row i + t - 1
+// (k_policy_prepare's up_coef).  The set of non-zero (k, t) is the half-pixel one under both conventions.
+constexpr bool HS_NZ[2][3][3] = {{{1, 1, 0}, {1, 1, 0}, {0, 1, 1}}, {{1, 1, 0}, {0, 1, 1}, {0, 1, 1}}};
+constexpr float HS_CH[2][3][3] = {{{0.75f, 0.25f, 0.f}, {0.25f, 0.75f, 0.f}, {0.f, 0.75f, 0.25f}},
+                                  {{0.25f, 0.75f, 0.f}, {0.f, 0.75f, 0.25f}, {0.f, 0.25f, 0.75f}}};
+constexpr float HS_CL[2][3][3] = {{{0.5f, 0.5f, 0.f}, {0.f, 1.f, 0.f}, {0.f, 0.5f, 0.5f}},
+                                  {{0.f, 1.f, 0.f}, {0.f, 0.5f, 0.5f}, {0.f, 0.f, 1.f}}};
+// the (k, t) pairs either output parity needs, in read order: 7 of the 9
+constexpr int HS_NKT = 7;
+constexpr int HS_KT[HS_NKT][2] = {{0, 0}, {0, 1}, {1, 0}, {1, 1}, {1, 2}, {2, 1}, {2, 2}};
+__device__ __forceinline__ f32x2 hs_fma2(float c, f32x2 v, f32x2 z) { return __builtin_elementwise_fma((f32x2){c, c}, v, z); }
+
 constexpr int HS_NB = 4;                 // producer waves (two M-tiles per sub-step each); 4 consumer waves behind them
 constexpr int HS_THREADS = 64 * (HS_NB + 4);
 
 // EXTRA: the launch wants the heat map and / or a probed value written out (ofx_policy_forward with a heatmap pointer,
 // ofx_policy_forward_obs with a probe: the DQN targets); the rollout's forward does not, and its instantiation carries
 // neither the tests nor the branches of those paths in the consumers' loop
-// LP != 0 (OFX_OPT_POLICY_BF16, opt-in; 1 = bf16, 2 = fp16 operands): stage B on v_mfma_f32_16x16x16_bf16 / _f16 (K = 36 -> 3 MFMAs of K = 16 per channel half
-// instead of 9 of K = 4) and stage C on v_mfma_f32_4x4x4_16B_bf16 (one MFMA per (channel, row) takes the four columns a
-// lane has read for its pixel pair, the fourth with a zero weight: 48 instead of 144 per pass); the operands - uprelu2 /
-// uprelu3 values read from the fp32 rings and the phase weights - are rounded to bf16 on the way into the matrix
-// instruction, the sums stay fp32.  Rings, schedule, frame lines (exact fp32) and stage A are the fp32 kernel's.
+// LP != 0 (OFX_OPT_POLICY_BF16, opt-in; 1 = bf16, 2 = fp16 operands): stage B on v_mfma_f32_16x16x16_bf16 / _f16 (K = 36 ->
+// 3 MFMAs of K = 16 per channel half instead of 9 of K = 4): the operands - uprelu2 values read from the fp32 ring and
+// the phase weights - are rounded on the way into the matrix instruction, the sums stay fp32.  The 1x1, the stencil,
+// rings, schedule, frame lines (exact fp32) and stage A are the fp32 kernel's.
 template <bool EXTRA, int LP>
 __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
   constexpr bool BF16 = LP != 0;  // reduced-precision operands (1 = bf16, 2 = fp16), fp32 sums
-  __shared__ __align__(16) float u3r[8 * HS_PL3];
+  __shared__ __align__(16) float vr[HS_NV * HS_PL3];
   __shared__ __align__(16) float u2r[4 * HS_PL2];
-  // group (flat over quad rows) -> float offset of its first quad in the uprelu2 ring (row slot of quad row - 1) and
-  // in the uprelu3 ring (row slot of uprelu3 row 2 * quad row): two table reads replace the index arithmetic of a tile
-  __shared__ unsigned short tabA[4 * HS_NTILES], tabD[4 * HS_NTILES];
+  // lo 16 bits: float offset of the group's first quad in the uprelu2 ring (row slot of quad row - 1); hi: in a tap
+  // plane (row slot of uprelu3 row 2 * quad row), bit 31: the group holds the strip's frame column
+  __shared__ unsigned tabG[HS_TABP];
   // blocks b and b + 8 (same XCD under round-robin placement) are the two halves of one ship; the ship of a block
   // rotates with the group of 16 blocks, so that a regular ship mask (say the first ship of every arena: the
   // reference's own line-up has one policy ship) does not put all the live workgroups on one XCD
@@ -572,14 +605,13 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
   if (s < 0) return;  // block-uniform
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int g = tid; g < 4 * HS_NTILES; g += HS_THREADS) {
+  for (int g = tid; g < HS_TABP; g += HS_THREADS) {
     const int q = g / HS_GPR, gg = g - HS_GPR * q;
-    tabA[g] = (unsigned short)((q & (HS_NR2 - 1)) * HS_P2 + 4 * gg);
-    // bit 15: the group holds the strip's frame column; bit 14: the group lies in the first / last quad row
-    tabD[g] = (unsigned short)((((2 * q) & (HS_NR3 - 1)) * HS_P3 + 8 * gg) | ((gg == (side ? 12 : 0)) ? 0x8000 : 0) |
-                               ((q == 0 || q == 99) ? 0x4000 : 0));
+    const unsigned lo = (unsigned)((q & (HS_NR2 - 1)) * HS_P2 + 4 * gg);
+    const unsigned hi = (unsigned)(((2 * q) & (HS_NR3 - 1)) * HS_P3 + 8 * gg) | ((gg == (side ? 12 : 0)) ? 0x8000u : 0u);
+    tabG[g] = lo | (hi << 16);
   }
-  __syncthreads();  // the producers read the tables in front of their first barrier
+  __syncthreads();  // the producers read the table in front of their first barrier
 
 #if OFX_HEAD_HOOKS
   unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0}, stamp_last = __builtin_amdgcn_s_memtime();
@@ -592,20 +624,31 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
   // Both roles run the same number of barriers (1 + HS_NS); each has its own loop so that the register allocator
   // sees only one role's long-lived state at a time.
   if (wv < HS_NB) {
-    // ================================================================ producer waves (stage B)
+    // ================================================================ producer waves (stage B + the 1x1)
+    // lane = (quad n16 of the M-tile, output parity kq = (pa, pb)): ONE uprelu3 pixel, all 8 channels
     const int n16 = lane & 15, kq = lane >> 4;
-    const int ph = n16 >> 2, cl = n16 & 3, pa = ph >> 1, pb = ph & 1;
-    float bw[2][9];          // B operands, constant over the strip
-    f32x4 binit3[2];         // the folded bias as the C operand of a tile's first MFMA
+    const int qd = n16 & 3, lg = n16 >> 2, pa = kq >> 1, pb = kq & 1;
+    float bw[2][9];          // A operands W[half][k = 4 j + kq][m = n16 = phase * 4 + channel], constant over the strip
+    f32x4 binit3[2];         // the folded bias as the C operand of a tile's first MFMA (row m = 4 kq + i: channel 4 half + i)
 #pragma unroll
     for (int hf = 0; hf < 2; hf++) {
 #pragma unroll
       for (int j = 0; j < 9; j++) bw[hf][j] = p.w3mf[(hf * 36 + 4 * j + kq) * 16 + n16];
-      const float b = p.b3[4 * hf + cl];
-      binit3[hf] = (f32x4){b, b, b, b};
+      binit3[hf] = (f32x4){p.b3[4 * hf], p.b3[4 * hf + 1], p.b3[4 * hf + 2], p.b3[4 * hf + 3]};
     }
-    const float *fr3 = p.u3fr + (size_t)s * 6400;
-    // BF16: B operand of MFMA J of half hf = W[k = 16 J + 4 kq + i][n16], i = 0..3 (k >= 36: zero); the A operand is the
+    // the 1x1: lane L holds w4[tap 4 g + (L & 3)][channel c] for (g, c) = L >> 2 = 8 g + c (taps 0 - 7); the MFMA for (g, c)
+    // picks its 4-lane block with ABID and broadcasts it (CBSZ = 4)
+    float wq[1];
+    {
+      const int idx = lane >> 2, tap = 4 * (idx >> 3) + (lane & 3);
+      wq[0] = p.w4raw[tap * 8 + (idx & 7)];
+    }
+    // the ninth tap would fill one row of a third group of four: 8 scalar-weight FMAs on the vector ALU instead of 8 MFMAs
+    float w8[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) w8[c] = p.w4raw[64 + c];
+    const float *vf = p.vfr + (size_t)s * 7200;
+    // BF16: A operand of MFMA J of half hf = W[k = 16 J + 4 kq + i][n16], i = 0..3 (k >= 36: zero); the B operand is the
     // four channels of tap 4 J + kq at the lane's quad: one address per J (lane-constant tap offset), channel planes
     // by immediate
     lp_x4 bwb[2][3];
@@ -628,56 +671,92 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
       }
     }
 
-    // ---- stage B: M-tile T = groups 4 T .. 4 T + 3 (flat over quad rows), both channel halves from one A gather ----
+    // ---- M-tile T = groups 4 T .. 4 T + 3 (flat over quad rows), 16 quads x 4 parities = 64 uprelu3 pixels ----
     struct TileB {
-      const float *a;   // A: cell (row qi - 1, column of the lane's quad - 1) of channel kq; rows + P2, columns + 1
-      float *w;         // D: first of the 4 cells of the lane group's quads (channel cl of half 0, phase row / column)
-      int gd;           // flat group of the lane group (D side)
-      float fv;         // exact frame-column cell of this lane (requested a sub-step ahead)
-      bool fcol;        // the lane group's group holds the strip's frame column
-      bool hasf;        // wave-uniform: the tile touches the frame of the plane
+      const float *a;   // gather: cell (row qi - 1, column of the lane's quad - 1) of channel kq; rows + P2, columns + 1
+      float *w;         // the lane's pixel in tap plane 0
+      bool fcol;        // wave-uniform: one of the tile's groups holds the strip's frame column
+      bool frow;        // wave-uniform: the tile has groups in the first / last quad row
+      int fq;           // wave-uniform: the quad row of the frame-column group
+      float fv;         // lanes 0-17: exact frame-column value (row parity lane / 9, tap plane lane % 9), requested a sub-step ahead
+      unsigned e;       // the lane group's own table entry
+      int T;
     };
-    const float *const a_lane = &u2r[kq * HS_PL2 + (n16 & 3) + side];
-    float *const w_lane = &u3r[cl * HS_PL3 + pa * HS_P3 + pb + 1];
-    const unsigned short *const ta_lane = &tabA[n16 >> 2], *const td_lane = &tabD[kq];
+    const float *const a_lane = &u2r[kq * HS_PL2 + qd + side];
+    float *const w_lane = &vr[pa * HS_P3 + 2 * qd + pb + 1];
+    const unsigned *const tab_lane = &tabG[lg];
     auto tile_setup = [&](int T, TileB &t) {  // T < HS_NTILES
-      t.a = a_lane + ta_lane[4 * T];
-      const unsigned td = td_lane[4 * T];
-      t.w = w_lane + (td & 0x3FFFu);
-      t.gd = 4 * T + kq;
-      t.fcol = (td & 0x8000u) != 0;
-      t.hasf = __builtin_amdgcn_ballot_w64((td & 0xC000u) != 0) != 0;  // the tile touches the frame of the plane
-      // exact frame-column cell of this lane: loaded by every lane (a valid address either way), used where fcol
-      const int qi = (t.gd * 5042) >> 16;
-      t.fv = fr3[((side ? 3 : 2) * 200 + 2 * qi + (n16 >> 3)) * 8 + (n16 & 7)];
-    };
-    auto tile_epilogue = [&](const TileB &t, const f32x4 d0, const f32x4 d1) {
-#pragma unroll
-      for (int i = 0; i < 4; i++) t.w[2 * i] = hd_max_raw(d0[i], 0.f);
-#pragma unroll
-      for (int i = 0; i < 4; i++) t.w[4 * HS_PL3 + 2 * i] = hd_max_raw(d1[i], 0.f);
-    };
-    // exact frame cells of uprelu3 (and the clamp copies around the plane) for a tile that touches the frame
-    auto tile_frames = [&](const TileB &t) {
-      const int qi_d = (t.gd * 5042) >> 16, g_d = t.gd - HS_GPR * qi_d;
-      if (t.fcol) {  // lane group: 2 rows x 8 channels of the frame column + the clamp column
-        const int yp = n16 >> 3, ch = n16 & 7, y = 2 * qi_d + yp;
-        const float v = t.fv;
-        const int cf = side ? 104 : 1, cc = side ? 105 : 0;
-        float *q = &u3r[ch * HS_PL3 + (y & (HS_NR3 - 1)) * HS_P3];
-        q[cf] = v; q[cc] = v;
-        if (y == 0) { float *q2 = &u3r[ch * HS_PL3 + (HS_NR3 - 1) * HS_P3]; q2[cf] = v; q2[cc] = v; }             // row -1
-        if (y == 199) { float *q2 = &u3r[ch * HS_PL3 + (200 & (HS_NR3 - 1)) * HS_P3]; q2[cf] = v; q2[cc] = v; }  // row 200
+      const int Tm = T - 52 * ((T * 1261) >> 16);   // T mod 52 (wave-uniform)
+      const unsigned e = tab_lane[4 * Tm];
+      t.e = e;
+      t.T = T;
+      t.a = a_lane + (e & 0xFFFFu);
+      t.w = w_lane + ((e >> 16) & 0x3FFFu);
+      t.frow = 4 * T < HS_GPR || 4 * T + 3 >= 99 * HS_GPR;
+      const unsigned long long fm = __builtin_amdgcn_ballot_w64((e >> 31) != 0);
+      t.fcol = fm != 0;
+      t.fq = 0;
+      t.fv = 0.f;
+      if (fm != 0) {
+        // the zero padding differs from the clamp-extended phase form on the plane's frame: those cells take the exact
+        // values of k_head_frames' lines.  The strip's frame column crosses the tile in ONE group: 2 rows x 9 planes
+        const int fl = (int)__builtin_ctzll(fm);                      // a lane of that group (n16 = 4 lg + ..: lanes 4 lg .. 4 lg + 3)
+        const int g = 4 * T + ((fl & 15) >> 2);
+        t.fq = (g * 5042) >> 16;
+        const int ln = min(lane, 17), y = 2 * t.fq + ln / 9;
+        t.fv = vf[((side ? 3 : 2) * 200 + y) * 9 + ln % 9];
       }
-      if (qi_d == 0 || qi_d == 99) {  // frame row over the group's 8 columns: lane = (column, channel half)
-        const int c = n16 >> 1, chh = n16 & 1;
-        const int ci3 = 8 * g_d + 1 + c, x = ci3 - 1 - 4 * side + 100 * side;
-        const int y = qi_d ? 199 : 0, yc = qi_d ? 200 : -1;
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(fr3 + ((qi_d ? 1 : 0) * 200 + x) * 8 + 4 * chh);
+    };
+    // ReLU -> the 9 tap values of the lane's pixel -> the ring
+    auto tile_tail = [&](const TileB &t, const f32x4 d0, const f32x4 d1) {
+      float u[8];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          u3r[(4 * chh + k) * HS_PL3 + (y & (HS_NR3 - 1)) * HS_P3 + ci3] = v[k];
-          u3r[(4 * chh + k) * HS_PL3 + (yc & (HS_NR3 - 1)) * HS_P3 + ci3] = v[k];
+      for (int i = 0; i < 4; i++) { u[i] = hd_max_raw(d0[i], 0.f); u[4 + i] = hd_max_raw(d1[i], 0.f); }
+      f32x4 v[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      float v8 = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+          const int idx = 8 * g + c;
+          switch (idx) {
+#define HS_CASE(B) case B: v[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(wq[0], u[c], v[g], 4, B, 0); break;
+            HS_CASE(0) HS_CASE(1) HS_CASE(2) HS_CASE(3) HS_CASE(4) HS_CASE(5) HS_CASE(6) HS_CASE(7)
+            HS_CASE(8) HS_CASE(9) HS_CASE(10) HS_CASE(11) HS_CASE(12) HS_CASE(13) HS_CASE(14) HS_CASE(15)
+#undef HS_CASE
+          }
+        }
+        v8 = fmaf(w8[c], u[c], v8);
+      }
+#pragma unroll
+      for (int tp = 0; tp < 8; tp++) t.w[tp * HS_PL3] = v[tp >> 2][tp & 3];
+      t.w[8 * HS_PL3] = v8;
+    };
+    // exact frame cells of the tap planes (and the clamp copies around the plane) behind a tile that touches the frame:
+    // same wave, so the LDS writes land behind the tile's own
+    auto tile_frames = [&](const TileB &t) {
+      if (t.fcol) {  // the strip's frame column, 2 rows x 9 planes on lanes 0-17, + the clamp column
+        if (lane < 18) {
+          const int yp = lane / 9, tp = lane - 9 * yp, y = 2 * t.fq + yp;
+          const float v = t.fv;
+          const int cf = side ? 104 : 1, cc = side ? 105 : 0;
+          float *q = &vr[tp * HS_PL3 + (y & (HS_NR3 - 1)) * HS_P3];
+          q[cf] = v; q[cc] = v;
+          if (y == 0) { float *q2 = &vr[tp * HS_PL3 + (HS_NR3 - 1) * HS_P3]; q2[cf] = v; q2[cc] = v; }             // row -1
+          if (y == 199) { float *q2 = &vr[tp * HS_PL3 + (200 & (HS_NR3 - 1)) * HS_P3]; q2[cf] = v; q2[cc] = v; }  // row 200
+        }
+      }
+      // frame row of the plane over the lane group's 8 columns x 9 planes (and its clamp copy): the 16 lanes of the group
+      if (!t.frow) return;
+      const int g = 4 * t.T + lg, qi = (g * 5042) >> 16, gg = g - HS_GPR * qi;
+      if (qi == 0 || qi == 99) {
+        const int y = qi ? 199 : 0, yc = qi ? 200 : -1;
+        for (int i = 4 * qd + kq; i < 72; i += 16) {
+          const int c = i / 9, tp = i - 9 * c;
+          const int ci3 = 8 * gg + 1 + c, x = ci3 - 1 - 4 * side + 100 * side;
+          const float v = vf[((qi ? 1 : 0) * 200 + min(x, 199)) * 9 + tp];
+          vr[tp * HS_PL3 + (y & (HS_NR3 - 1)) * HS_P3 + ci3] = v;
+          vr[tp * HS_PL3 + (yc & (HS_NR3 - 1)) * HS_P3 + ci3] = v;
         }
       }
     };
@@ -691,35 +770,34 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
       f32x4 d0 = binit3[0], d1 = binit3[1];
 #pragma unroll
       for (int J = 0; J < 3; J++) {
-        d0 = lp_mfma16<LP ? LP : 1>(A[J], bwb[0][J], d0);
-        d1 = lp_mfma16<LP ? LP : 1>(A[J], bwb[1][J], d1);
+        d0 = lp_mfma16<LP ? LP : 1>(bwb[0][J], A[J], d0);
+        d1 = lp_mfma16<LP ? LP : 1>(bwb[1][J], A[J], d1);
       }
-      tile_epilogue(t, d0, d1);
-      if (t.hasf) tile_frames(t);
+      tile_tail(t, d0, d1);
+      if (t.fcol || t.frow) tile_frames(t);
     };
     auto run_pair = [&](const TileB &t0, const TileB &t1) {
       if constexpr (BF16) { tile_bf16(t0); tile_bf16(t1); return; }
-      // The two tiles run one after the other (two accumulator chains each: 64 cycles between dependent MFMAs, the
-      // 16x16x4 latency is 40) so that the ReLU + LDS writes of the first hide behind the MFMAs of the second; all 18
-      // A operands are requested up front.
+      // all 18 gathers requested up front; two accumulator chains per tile (64 cycles between dependent MFMAs, the
+      // 16x16x4 latency is 40); the 1x1 of the first tile follows the second tile's MFMAs
       float a0[9], a1[9];
 #pragma unroll
       for (int j = 0; j < 9; j++) { a0[j] = t0.a[(j / 3) * HS_P2 + j % 3]; a1[j] = t1.a[(j / 3) * HS_P2 + j % 3]; }
       f32x4 d00, d01, d10, d11;
 #pragma unroll
       for (int j = 0; j < 9; j++) {
-        d00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], bw[0][j], j ? d00 : binit3[0], 0, 0, 0);
-        d01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], bw[1][j], j ? d01 : binit3[1], 0, 0, 0);
+        d00 = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[0][j], a0[j], j ? d00 : binit3[0], 0, 0, 0);
+        d01 = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[1][j], a0[j], j ? d01 : binit3[1], 0, 0, 0);
       }
 #pragma unroll
       for (int j = 0; j < 9; j++) {
-        d10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], bw[0][j], j ? d10 : binit3[0], 0, 0, 0);
-        d11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], bw[1][j], j ? d11 : binit3[1], 0, 0, 0);
-        if (j == 1) tile_epilogue(t0, d00, d01);
+        d10 = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[0][j], a1[j], j ? d10 : binit3[0], 0, 0, 0);
+        d11 = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[1][j], a1[j], j ? d11 : binit3[1], 0, 0, 0);
       }
-      tile_epilogue(t1, d10, d11);
-      if (t0.hasf) tile_frames(t0);
-      if (t1.hasf) tile_frames(t1);
+      tile_tail(t0, d00, d01);
+      tile_tail(t1, d10, d11);
+      if (t0.fcol || t0.frow) tile_frames(t0);
+      if (t1.fcol || t1.frow) tile_frames(t1);
     };
     auto run_single = [&](const TileB &t0) {
       if constexpr (BF16) { tile_bf16(t0); return; }
@@ -727,18 +805,18 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
 #pragma unroll
       for (int j = 0; j < 9; j++) {
         const float a0 = t0.a[(j / 3) * HS_P2 + j % 3];
-        d00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bw[0][j], j ? d00 : binit3[0], 0, 0, 0);
-        d01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bw[1][j], j ? d01 : binit3[1], 0, 0, 0);
+        d00 = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[0][j], a0, j ? d00 : binit3[0], 0, 0, 0);
+        d01 = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[1][j], a0, j ? d01 : binit3[1], 0, 0, 0);
       }
-      tile_epilogue(t0, d00, d01);
-      if (t0.hasf) tile_frames(t0);
+      tile_tail(t0, d00, d01);
+      if (t0.fcol || t0.frow) tile_frames(t0);
     };
 
     // every global load so far (the weights) has landed: without this the compiler's wait-count bookkeeping carries
     // the weight loads into the loop as "maybe pending" and its in-order vmcnt waits then block on the loads of the
     // loop itself (vmcnt(0); expcnt / lgkmcnt fields left at their maxima)
     __builtin_amdgcn_s_waitcnt(0x0F70);
-    // Software pipeline over the sub-steps: the tile set-ups (table reads) and the frame-column loads of the NEXT
+    // Software pipeline over the sub-steps: the tile set-ups (table reads) and the frame-cell loads of the NEXT
     // sub-step's M-tiles are requested at the end of a sub-step, in front of the barrier; nothing is loaded in front of
     // its use, so every vmcnt wait names loads a whole sub-step old.  (vmcnt counts in order: one late load in front of
     // a wait exposes the full HBM latency, ~1 us, per sub-step.)
@@ -773,32 +851,9 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
     }
     HS_STAMP_OUT();
   } else {
-    // ================================================================ consumer waves (stage C + arg-max + stage A)
-    // the consumers are the MFMA-dense half of the workgroup and finish last: their instructions go first when a
-    // producer wave of the same SIMD competes for the issue slot (A/B on the chip: 17.2 against 17.9 ms)
-    __builtin_amdgcn_s_setprio(HS_C_PRIO);
+    // ================================================================ consumer waves (stage A + stencil + arg-max)
     // Every VALU instruction here is paid in matrix throughput (the f32 MFMAs and the VALU share the SIMD's issue
     // slots), so the per-pass bookkeeping is kept to running counters and the arg-max to a snapshot of the best pass.
-    // stage-C weights: register r, lane L holds W[k = 16 r + (L >> 2)][phase L & 3]; an MFMA picks its k with ABID
-    float wreg[5];
-#pragma unroll
-    for (int r = 0; r < 5; r++) {
-      const int k = 16 * r + (lane >> 2);
-      wreg[r] = k < 72 ? p.w4eff_c[((k / 9) * 4 + (lane & 3)) * 9 + (k % 9)] : 0.f;
-    }
-    // BF16: group g = ((channel * 3 + row) * 2 + pixel of the pair): register pair g >> 4, block g & 15 holds, for phase
-    // L & 3, the weights of the four columns x0 - 1 .. x0 + 2 the lane has read: (w0, w1, w2, 0) for the pair's first
-    // pixel, (0, w0, w1, w2) for its second
-    lp_x4 wbf[3];
-    if constexpr (BF16) {
-#pragma unroll
-      for (int r = 0; r < 3; r++) {
-        const int g = 16 * r + (lane >> 2), ch = g / 6, dy = (g >> 1) % 3, px = g & 1;
-        const float *wq = p.w4eff_c + (ch * 4 + (lane & 3)) * 9 + dy * 3;
-        const float w0 = wq[0], w1 = wq[1], w2 = wq[2];
-        wbf[r] = px ? lp_pk4<LP ? LP : 1>(0.f, w0, w1, w2) : lp_pk4<LP ? LP : 1>(w0, w1, w2, 0.f);
-      }
-    }
     const int n16 = lane & 15, kq = lane >> 4;
     const int ph = n16 >> 2, cl = n16 & 3, pa = ph >> 1, pb = ph & 1;
     const int cw = wv - HS_NB;
@@ -808,7 +863,7 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
     const float bias2 = p.b2[cl];
     const float *up1s = p.up1 + (size_t)s * 5000;
     const float *fr2 = p.u2fr + (size_t)s * 1600;
-    // ---- stage A (run by the consumer waves behind their stage-C pass: they wait at the barrier otherwise): one M-tile = 16 uprelu1 pixels of row pair `pr` -> 2 x 32 cells x 4 channels of uprelu2 ----
+    // ---- stage A (the consumers open a sub-step with it): one M-tile = 16 uprelu1 pixels of row pair `pr` -> 2 x 32 cells x 4 channels of uprelu2 ----
     // A[pixel][k = 4 j + kq]: tap = 2 j + (kq >> 1), ci = kq & 1 (K = 18, padded to 20)
     auto stageA_load = [&](int pr, int hh, float *av) {
       const int px0 = side ? (hh ? 34 : 23) : (hh ? 11 : 0);
@@ -872,7 +927,14 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
     const int tk = task_ok ? task : 249;
     const int r_in = tk / 50, jx = tk - 50 * r_in;   // row of the block, pixel pair of the row
     const float bias4 = p.b4[0];
-    const f32x4 binit4 = {bias4, bias4, bias4, bias4};
+    // coefficients of the x2 bilinear (wave-uniform: scalar registers)
+    float cy[2][3][3];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int t = 0; t < 3; t++) cy[a][k][t] = p.legacy ? HS_CL[a][k][t] : HS_CH[a][k][t];
     const bool fcol = task_ok && (side ? jx == 49 : jx == 0);  // the lane owns pixels of the strip's frame column
     const float *c4s = p.c4 + (size_t)s * 1600;
     const int x0 = 100 * side + 2 * jx;              // uprelu3 column of the lane's first pixel
@@ -889,7 +951,7 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
     float tv = -INFINITY;
     int tst = 0;
     f32x4 snap[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};  // the 8 values of the pass that holds the lane's maximum
-    const char *const u3b = reinterpret_cast<const char *>(u3r);
+    const char *const vb = reinterpret_cast<const char *>(vr);
 
     {  // prologue: uprelu2 row pairs 0 and 1, one tile per consumer wave
       float av0[6];
@@ -916,18 +978,12 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
       if (p.ablate & 1) { __syncthreads(); continue; }
 #endif
       HS_STAMP(0);
-#if HS_A_FIRST
-      // The consumers open a sub-step with their matrix-light work (stage A for the NEXT sub-step's M-tiles, the loads
-      // of the one after) while the producer wave that shares their SIMD opens it with its MFMAs; the stage-C pass
-      // follows when the producers are in their own matrix-light tail (tile set-ups for the next sub-step).  Both roles
-      // used to start their MFMA runs right behind the barrier and serialised on the SIMD's matrix pipe
-      // (s_memtime stamps: 4265 cycles per producer tile pair of 1152 matrix cycles, 2143 cycles per sub-step in the
-      // consumers' barrier wait).  Nothing inside a sub-step orders stage A against the pass: uprelu2 rows written in
-      // sub-step st are read by the producers in st + 1 (tools/head_schedule.py).
+      // The consumers open a sub-step with stage A for the NEXT sub-step's M-tiles and the loads of the one after.
+      // Nothing inside a sub-step orders stage A against the pass: uprelu2 rows written in sub-step st are read by the
+      // producers in st + 1 (tools/head_schedule.py).
       if (apr >= 0) stageA_compute(apr, ahh, av);
       stageA_pick(min(st + 1, HS_NS - 1));
       HS_STAMP(3);
-#endif
       if (__builtin_amdgcn_ballot_w64(ok) != 0) {    // wave-uniform
         // zero-padding corrections of frame pixels (global memory: requested up front, zero for the other lanes)
         f32x2 ccol = {0.f, 0.f};
@@ -935,71 +991,59 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
         if (fcol && ok) ccol = *reinterpret_cast<const f32x2 *>(c4s + coff);
         const bool edge = st < 3 || st > 38;         // wave-uniform: the block may hold row 0 or row 199
         if (edge && ok && (R == 0 || R == 199)) crow = *reinterpret_cast<const f32x4 *>(c4s + (R ? 1 : 0) * 400 + 2 * x0);
-        // accumulators [pixel][channel half]: 4 independent MFMA chains, combined at the end
-        f32x4 acc[2][2];
+        // ---- the stencil.  Vertical first: Z[a][kx] = sum_(ky, ty) cy[a][ky][ty] V_(ky, kx)[R + ty - 1] on the four
+        // columns x0 - 1 .. x0 + 2 the lane reads (two pairs); one (tap column, column pair) at a time, the 7 reads of the
+        // next one requested in front of the 12 packed FMAs of this one
+        f32x2 Z[2][3][2];
+        f32x2 V[2][HS_NKT];
+        auto ldv = [&](int u) {   // unit u = (tap column kx = u >> 1, column pair u & 1): 7 reads
 #pragma unroll
-        for (int px = 0; px < 2; px++) {
-          acc[px][0] = binit4;
-          acc[px][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        // software pipeline over 12 steps (step = channel pair (c, c + 4), row dy): the 4 reads of step t + 2 are
-        // requested before the 12 MFMAs of step t
-        f32x2 V[3][2][2];
-        auto ldv = [&](int t) {
-          const int c = t / 3, dy = t % 3;
-#pragma unroll
-          for (int hf = 0; hf < 2; hf++) {
-            const char *qq = u3b + q[dy] + (c + 4 * hf) * (HS_PL3 * 4);
-            V[t % 3][hf][0] = *(hs_lds_v2 *)(qq);
-            V[t % 3][hf][1] = *(hs_lds_v2 *)(qq + 8);
-          }
+          for (int n = 0; n < HS_NKT; n++)
+            V[u & 1][n] = *(hs_lds_v2 *)(vb + q[HS_KT[n][1]] + (3 * HS_KT[n][0] + (u >> 1)) * (HS_PL3 * 4) + 8 * (u & 1));
         };
         ldv(0);
-        ldv(1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < 12; t++) {
-          if (t + 2 < 12) ldv(t + 2);
-          const int c = t / 3, dy = t % 3;
-          if constexpr (BF16) {
+        for (int u = 0; u < 6; u++) {
+          if (u + 1 < 6) ldv(u + 1);
 #pragma unroll
-            for (int hf = 0; hf < 2; hf++) {
-              const lp_x4 b4 = lp_pk4<LP ? LP : 1>(V[t % 3][hf][0][0], V[t % 3][hf][0][1], V[t % 3][hf][1][0], V[t % 3][hf][1][1]);
+          for (int a = 0; a < 2; a++) {
+            f32x2 z = {0.f, 0.f};
+            bool first = true;
 #pragma unroll
-              for (int px = 0; px < 2; px++) {
-                const int g = ((c + 4 * hf) * 3 + dy) * 2 + px;
-                switch (g & 15) {
-#define HS_CASEB(B) case B: acc[px][hf] = lp_mfma4_bcast<LP ? LP : 1, B>(wbf[g >> 4], b4, acc[px][hf]); break;
-                  HS_CASEB(0) HS_CASEB(1) HS_CASEB(2) HS_CASEB(3) HS_CASEB(4) HS_CASEB(5) HS_CASEB(6) HS_CASEB(7)
-                  HS_CASEB(8) HS_CASEB(9) HS_CASEB(10) HS_CASEB(11) HS_CASEB(12) HS_CASEB(13) HS_CASEB(14) HS_CASEB(15)
-#undef HS_CASEB
-                }
-              }
+            for (int n = 0; n < HS_NKT; n++) {
+              const int ky = HS_KT[n][0], ty = HS_KT[n][1];
+              if (!HS_NZ[a][ky][ty]) continue;
+              if (first) { z = (f32x2){cy[a][ky][ty], cy[a][ky][ty]} * V[u & 1][n]; first = false; }
+              else z = hs_fma2(cy[a][ky][ty], V[u & 1][n], z);
             }
-          } else
-#pragma unroll
-          for (int dx = 0; dx < 3; dx++)
-#pragma unroll
-            for (int hf = 0; hf < 2; hf++) {
-              const int k = (c + 4 * hf) * 9 + dy * 3 + dx;
-#pragma unroll
-              for (int px = 0; px < 2; px++) {
-                // D[phase][pixel] += W[k][phase] * in[pixel][k]; A = block (k & 15) of register k >> 4, broadcast
-                const float v = V[t % 3][hf][(dx + px) >> 1][(dx + px) & 1];
-                switch (k & 15) {
-#define HS_CASE(B) case B: acc[px][hf] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[k >> 4], v, acc[px][hf], 4, B, 0); break;
-                  HS_CASE(0) HS_CASE(1) HS_CASE(2) HS_CASE(3) HS_CASE(4) HS_CASE(5) HS_CASE(6) HS_CASE(7)
-                  HS_CASE(8) HS_CASE(9) HS_CASE(10) HS_CASE(11) HS_CASE(12) HS_CASE(13) HS_CASE(14) HS_CASE(15)
-#undef HS_CASE
-                }
-              }
-            }
+            Z[a][u >> 1][u & 1] = z;
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
         HS_STAMP(1);
+        // horizontal: out[a][b] of the pair (x0, x0 + 1) = bias + sum_(kx, tx) cy[b][kx][tx] Z[a][kx](x + tx - 1); the pair
+        // of columns (x0 - 1, x0) / (x0, x0 + 1) / (x0 + 1, x0 + 2) for tx = 0 / 1 / 2
         f32x4 o[2];
 #pragma unroll
-        for (int px = 0; px < 2; px++) o[px] = acc[px][0] + acc[px][1];
+        for (int a = 0; a < 2; a++) {
+          f32x2 M[3];
+#pragma unroll
+          for (int kx = 0; kx < 3; kx++) M[kx] = (f32x2){Z[a][kx][0][1], Z[a][kx][1][0]};
+#pragma unroll
+          for (int b = 0; b < 2; b++) {
+            f32x2 acc = {bias4, bias4};
+#pragma unroll
+            for (int kx = 0; kx < 3; kx++)
+#pragma unroll
+              for (int tx = 0; tx < 3; tx++) {
+                if (!HS_NZ[b][kx][tx]) continue;
+                acc = hs_fma2(cy[b][kx][tx], tx == 0 ? Z[a][kx][0] : tx == 1 ? M[kx] : Z[a][kx][1], acc);
+              }
+            o[0][2 * a + b] = acc[0];
+            o[1][2 * a + b] = acc[1];
+          }
+        }
         // frame pixels: phase (a, b) of pixel px is heat-map pixel (2 R + a, 2 x + b); the corrections are zero elsewhere
         if (side) { o[1][1] -= ccol[0]; o[1][3] -= ccol[1]; }  // block-uniform
         else { o[0][0] -= ccol[0]; o[0][2] -= ccol[1]; }
@@ -1030,11 +1074,6 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
         }
       }
       HS_STAMP(2);
-#if !HS_A_FIRST
-      if (apr >= 0) stageA_compute(apr, ahh, av);
-      stageA_pick(min(st + 1, HS_NS - 1));
-      HS_STAMP(3);
-#endif
       R += 5;
       coff += 10;
 #pragma unroll
@@ -1074,11 +1113,11 @@ int ofx_head_compact(ofx_handle *h, int S, const uint8_t *mask, int32_t *live) {
   return OFX_OK;
 }
 
-size_t ofx_head_frame_bytes(size_t S, size_t *u2fr, size_t *u3fr, size_t *c4) {
+size_t ofx_head_frame_bytes(size_t S, size_t *u2fr, size_t *vfr, size_t *c4) {
   *u2fr = 4 * S * 1600;
-  *u3fr = 4 * S * 6400;
+  *vfr = 4 * S * 7200;
   *c4 = 4 * S * 1600;
-  return *u2fr + *u3fr + *c4;
+  return *u2fr + *vfr + *c4;
 }
 
 int ofx_launch_head(ofx_handle *h, const HeadParams2 &p0) {

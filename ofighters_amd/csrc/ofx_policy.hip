@@ -1324,7 +1324,7 @@ __global__ void k_policy_actions(int S, const ofx_state st, const int32_t *iacti
 
 // ---- workspace -----------------------------------------------------------------------
 struct PolicyWs {
-  float *p1, *p2, *p3, *p4, *g1, *d1, *u0, *up1, *u2fr, *u3fr, *c4;
+  float *p1, *p2, *p3, *p4, *g1, *d1, *u0, *up1, *u2fr, *vfr, *c4;
   unsigned long long *best;
   int32_t *iaction, *ipointer, *live;
 };
@@ -1356,7 +1356,7 @@ static int policy_workspace(ofx_handle *h, PolicyWs *ws, size_t N, size_t S) {
   if (rc) return rc;
   char *base = (char *)h->scratch;
   void **dst[] = {(void **)&ws->p1,   (void **)&ws->p2,   (void **)&ws->p3,      (void **)&ws->p4,      (void **)&ws->g1,
-                  (void **)&ws->d1,   (void **)&ws->u0,   (void **)&ws->up1,     (void **)&ws->u2fr,    (void **)&ws->u3fr,
+                  (void **)&ws->d1,   (void **)&ws->u0,   (void **)&ws->up1,     (void **)&ws->u2fr,    (void **)&ws->vfr,
                   (void **)&ws->c4,   (void **)&ws->best, (void **)&ws->iaction, (void **)&ws->ipointer,
                   (void **)&ws->live};
   for (size_t i = 0; i < sizeof(sz) / sizeof(sz[0]); i++) { *dst[i] = base; base += sz[i]; }
@@ -1583,7 +1583,7 @@ static int policy_forward_impl(ofx_handle *h, const float *weights, int N, int M
   hp2.w3mf = prep + L.w3mf; hp2.b3 = prep + L.ub[2]; hp2.w3raw = prep + L.uw[2];
   hp2.w4eff_c = prep + L.w4eff_c; hp2.b4 = prep + L.b4; hp2.w4raw = prep + L.w4raw;
   hp2.w2fr = prep + L.w2fr; hp2.w3fr = prep + L.w3fr; hp2.efr = prep + L.efr;
-  hp2.u2fr = ws.u2fr; hp2.u3fr = ws.u3fr; hp2.c4 = ws.c4;
+  hp2.u2fr = ws.u2fr; hp2.vfr = ws.vfr; hp2.c4 = ws.c4;
   hp2.frames_ref = h->opt_frames_ref; hp2.legacy = h->opt_bilinear_legacy;
   hp2.bf16 = lowp;  // the rollout's forward only: targets and fit stay fp32
   hp2.mask = ship_mask; hp2.live = ws.live; hp2.live_ready = ship_mask != nullptr; hp2.best = ws.best; hp2.heat = heatmap; hp2.probe = probe; hp2.ptr_probe = probe ? ptr_probe : nullptr;

@@ -644,7 +644,7 @@ static int dqn_fit_lean(ofx_handle *h, float *weights, float *adam_m, float *ada
   sz(4 * N * 625); sz(4 * N * 2); sz(4 * N * 100); sz(4 * N * 50); sz(4 * N * 5008); sz(4 * N * 5000);      // gu0 do1 dd1 dd2 df dp3
   sz(4 * (size_t)L.n_floats); sz(4 * 64); sz(4 * (2 * N + 4096)); sz(8 * ofx_fit_part_doubles()); sz(8 * 32);
   sz(4 * ofx_fit_out_floats()); sz(8 * ofx_fit_out_doubles(n)); sz(8 * ofx_fit_point_doubles(n));
-  for (int k = 0; k < 7; k++) { sz(4 * 16); sz(4 * 16); }
+  for (int k = 0; k < 7; k++) { sz(4 * 32); sz(4 * 16); }   // stat (+ the mean's low parts), act
   if ((rc = keep_workspace(h, &h->fitws, &h->fitws_bytes, need))) return rc;
   Arena A{(char *)h->fitws, 0, need};
   auto T = [&](int t) { return weights + L.offset[t]; };
@@ -659,11 +659,11 @@ static int dqn_fit_lean(ofx_handle *h, float *weights, float *adam_m, float *ada
   double *fpart = A.d(ofx_fit_out_doubles(n)), *pscratch = A.d(ofx_fit_point_doubles(n));
   float *tz[4], *tg[4], *tstat[4], *tact[4], *uz[3], *ug[3], *ustat[3], *uact[3], *tp[3];
   for (int i = 0; i < 3; i++) tp[i] = A.f(N * 8 * tS[i + 1] * tS[i + 1]);
-  for (int i = 0; i < 4; i++) { tz[i] = i ? A.f(N * 8 * tS[i] * tS[i]) : nullptr; tg[i] = A.f(N * 8 * tS[i] * tS[i] / (i ? 1 : 4)); tstat[i] = A.f(16); tact[i] = A.f(16); }
+  for (int i = 0; i < 4; i++) { tz[i] = i ? A.f(N * 8 * tS[i] * tS[i]) : nullptr; tg[i] = A.f(N * 8 * tS[i] * tS[i] / (i ? 1 : 4)); tstat[i] = A.f(32); tact[i] = A.f(16); }
   float *luts = A.f(ofx_fit_first_floats()), *w1t = A.f(5008 * 100);
   unsigned char *kk0 = (unsigned char *)A.take(N * 8 * 40000);
   double *cpart = A.d(ofx_fit_first_doubles(n));
-  for (int j = 0; j < 3; j++) { uz[j] = A.f(N * kUO[j] * uS[j] * uS[j]); ug[j] = A.f(N * kUO[j] * uS[j] * uS[j]); ustat[j] = A.f(16); uact[j] = A.f(16); }
+  for (int j = 0; j < 3; j++) { uz[j] = A.f(N * kUO[j] * uS[j] * uS[j]); ug[j] = A.f(N * kUO[j] * uS[j] * uS[j]); ustat[j] = A.f(32); uact[j] = A.f(16); }
   float *o2 = A.f(N * 160000), *do2 = A.f(N * 160000);
   float *p3 = A.f(N * 5000), *f = A.f(N * 5008), *d1 = A.f(N * 100), *d2 = A.f(N * 50), *o1 = A.f(N * 2), *u0 = A.f(N * 625);
   float *gu0 = A.f(N * 625), *do1 = A.f(N * 2), *dd1 = A.f(N * 100), *dd2 = A.f(N * 50), *df = A.f(N * 5008), *dp3 = A.f(N * 5000);

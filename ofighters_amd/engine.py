@@ -65,6 +65,15 @@ class DeviceBuffer:
             pass
 
 
+class _ArrayInterface:
+    """__cuda_array_interface__ (version 3) over a raw HBM pointer; `owner` keeps the memory's owner alive."""
+
+    def __init__(self, ptr, shape, typestr, owner):
+        self.owner = owner
+        self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (int(ptr), False), "version": 3,
+                                         "strides": None}
+
+
 def pack_actions(valid, shoot, thrust, px, py):
     """numpy -> [N][M] ofx_action records (lib/action.py:12-56; valid=0 is None)."""
     valid = np.asarray(valid)
@@ -230,6 +239,56 @@ class ArenaBatch:
 
     def device_ptr(self, field):
         return nat.lib().ofx_device_ptr(self._h, field)
+
+    # ------------------------------------------------------------ zero-copy views
+    # The batched form of the reference's plugin seam ("any object with .play(obs)", agents/agent.py:34-37): an external
+    # policy - a torch module, say - reads the maps and the ships' state where they lie in HBM and writes its actions
+    # into the [N][M] ofx_action array the next step() reads.  Nothing is copied; see include/ofx.h (ofx_field_desc) for
+    # the ownership rule: the CONTENTS are those of the last step / rasterise and the next one overwrites them in place.
+    # torch must have been imported BEFORE the library was loaded (both bring a HIP runtime of the same soname and the
+    # process keeps the first one: with libofx's first, torch finds no GPU).
+    def _view(self, desc, keep=None):
+        import torch
+        if not torch.cuda.is_available():
+            raise Exception("ArenaBatch tensor views need torch's GPU runtime: import torch before ofighters_amd loads "
+                            "libofx.so (the process keeps the first HIP runtime it loads)")
+        shape = tuple(int(desc.shape[i]) for i in range(desc.ndim))
+        holder = _ArrayInterface(desc.data, shape, nat.DT_TYPESTR[desc.dtype], keep or self)
+        return torch.as_tensor(holder, device=torch.device("cuda", int(desc.device)))
+
+    def tensor(self, field):
+        """State field `field` (nat.F_*) as a torch tensor over the handle's own memory: [N][M], [N][L] or [N]."""
+        d = nat.OfxTensorDesc()
+        nat.check(nat.lib().ofx_field_desc(self._h, int(field), C.byref(d)))
+        return self._view(d)
+
+    def maps_tensor(self, map_type=nat.MAP_U8):
+        """(ship_map, laser_map) of the handle's internal buffers of `map_type` as torch tensors [N][W = y][H = x]
+        ([N][W * H / 8] uint8 for MAP_BITS), filled by rasterise(map_type)."""
+        out = []
+        for which in (0, 1):
+            d = nat.OfxTensorDesc()
+            nat.check(nat.lib().ofx_map_desc(self._h, int(map_type), which, C.byref(d)))
+            out.append(self._view(d))
+        return tuple(out)
+
+    def actions_tensor(self):
+        """The [N][M] ofx_action array step() reads by default, as views of its fields: px, py int32 [N][M]; shoot,
+        thrust, valid uint8 [N][M] (lib/action.py:12-56; valid = 0 is the reference's None)."""
+        import torch
+        d = nat.OfxTensorDesc()
+        d.data, d.dtype, d.itemsize, d.ndim, d.device = self._actions.ptr, nat.DT_U8, 1, 3, self.cfg.device
+        d.shape[0], d.shape[1], d.shape[2] = self.N, self.M, ACTION_DTYPE.itemsize
+        raw = self._view(d, keep=self._actions)
+        words = raw.view(torch.int32)                    # [N][M][3]: px, py, (shoot | thrust << 8 | valid << 16)
+        return {"px": words[..., 0], "py": words[..., 1], "shoot": raw[..., 8], "thrust": raw[..., 9],
+                "valid": raw[..., 10], "raw": raw}
+
+    def torch_stream(self):
+        """The handle's HIP stream as a torch stream: `with torch.cuda.stream(batch.torch_stream()):` puts a policy's
+        kernels in order with step() / rasterise() (the handle's stream does not synchronise with torch's default one)."""
+        import torch
+        return torch.cuda.ExternalStream(int(nat.lib().ofx_stream(self._h)), device=torch.device("cuda", self.cfg.device))
 
     def overflow_count(self):
         v = C.c_int64(0)

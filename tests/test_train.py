@@ -398,3 +398,147 @@ def test_short_memories_are_not_padded_into_the_fit():
     with pytest.raises(Exception, match="padding"):     # refused before its two predict passes
         b.dqn_fit_reference(w_d, m_d, v_d, 1, 1e-4, n_all, rows_d.ptr, bp_d.ptr, bn_d.ptr, 0.9)
     b.close()
+
+
+# ---- the lean fit in the regime it is USED in (r04): minibatches of 128 - 4096 rows -------------------------------
+# Every persistent kernel of ofx_fit.hip loops over several tiles per block there (OFX_FIT_MAX_BLOCKS = 2048, 1024 for
+# the weight-gradient kernels), the reductions go through their two-level ordered combines and f_bits_corr through its
+# per-block partial rows - paths the 4- and 24-row comparisons above reach with one tile per block only.
+
+def _collect_minibatch(N, M=4, batch=4, seed=0x0F160077, ticks=10):
+    from ofighters_amd import ArenaBatch, DeviceBuffer
+    b = ArenaBatch(N, M)
+    b.replay_create(16, 0)
+    b.spawn_random(seed)
+    mask = np.zeros((N, M), np.uint8)
+    mask[:, [0, 3]] = 1
+    mask_d = DeviceBuffer(mask.nbytes).upload(mask)
+    ia_d, ip_d = DeviceBuffer(4 * N * M), DeviceBuffer(8 * N * M)
+    for t in range(ticks):
+        b.bot_actions(["random"] * M, seed, tick=t)
+        b.policy_explore(1.0, seed, tick=t, collecting=True, ship_mask_ptr=mask_d.ptr, iaction_ptr=ia_d.ptr, ipointer_ptr=ip_d.ptr)
+        b.policy_actions(out_ptr=b._actions.ptr, ship_mask_ptr=mask_d.ptr, iaction_ptr=ia_d.ptr, ipointer_ptr=ip_d.ptr)
+        b.replay_capture(t, mask_d.ptr, ia_d.ptr, ip_d.ptr)
+        b.step(actions_ptr=b._actions.ptr)
+    slot, _ = b.replay_sample(7, 0, batch)
+    rows_d, bp_d, bn_d = b.replay_gather_device(slot, batch)
+    n = N * batch
+    assert (rows_d.download(b.TRANSITION_DTYPE, (n,))["ship"] >= 0).all()
+    return b, n, rows_d, bp_d, bn_d
+
+
+def _fit_once(b, kind, w, n, rows_d, bp_d, bn_d, y, y2, bufs):
+    w_d, m_d, v_d, g_d = bufs
+    zeros = np.zeros_like(w)
+    w_d.upload(w); m_d.upload(zeros); v_d.upload(zeros)
+    if kind == "textbook":
+        l = b.dqn_fit(w_d, m_d, v_d, 1, 1e-4, n, rows_d.ptr, bp_d.ptr, y.ptr, y2.ptr, g_d)
+    else:
+        l = b.dqn_fit_reference(w_d, m_d, v_d, 1, 1e-4, n, rows_d.ptr, bp_d.ptr, bn_d.ptr, 0.9, g_d)
+    return l, g_d.download(np.float32, w.shape), w_d.download(np.float32, w.shape)
+
+
+@pytest.mark.parametrize("rows", [128, 1024])
+def test_lean_fit_equals_plain_fit_large_batches(rows):
+    """lean == plain at 128 rows (every persistent kernel past its first tile: f_conv_fwd at 200x200 loops from 52 rows,
+    f_b1_pool / f_b1_up / f_b1_first / f_bw_first / f_bits_corr from 26 - 110) and at 1024 rows (the bench's regime; the
+    plain form holds 62 GB of workspace there), textbook and reference targets: the per-tensor bounds of
+    test_lean_fit_equals_plain_fit, equal moved statistics, and two lean runs give the same bits."""
+    from ofighters_amd import DeviceBuffer, _native as nat
+    b, n, rows_d, bp_d, bn_d = _collect_minibatch(rows // 4)
+    assert n == rows
+    w, shapes = pyoracle.policy_init(5, trained_like=True)
+    rs = np.random.RandomState(3)
+    y = DeviceBuffer(4 * n).upload(rs.uniform(-1, 2, n).astype(np.float32))
+    y2 = DeviceBuffer(4 * n).upload(rs.uniform(-1, 2, n).astype(np.float32))
+    bufs = tuple(DeviceBuffer(w.nbytes) for _ in range(4))
+    for kind in ("textbook", "reference"):
+        b.set_option(nat.OPT_FIT_PLAIN, 0)
+        la, ga, wa = _fit_once(b, kind, w, n, rows_d, bp_d, bn_d, y, y2, bufs)
+        la2, ga2, wa2 = _fit_once(b, kind, w, n, rows_d, bp_d, bn_d, y, y2, bufs)
+        assert la == la2 and np.array_equal(ga, ga2) and np.array_equal(wa, wa2), "lean fit is not bit-reproducible at %d rows" % n
+        b.set_option(nat.OPT_FIT_PLAIN, 1)
+        lb, gb, wb = _fit_once(b, kind, w, n, rows_d, bp_d, bn_d, y, y2, bufs)
+        ga, gb = ga.astype(np.float64), gb.astype(np.float64)
+        assert np.isfinite(ga).all() and np.abs(ga).max() > 0
+        assert abs(la[0] - lb[0]) <= 1e-5 * max(1.0, abs(lb[0])) and abs(la[1] - lb[1]) <= 1e-5 * abs(lb[1]) + 1e-12, (kind, la, lb)
+        bad = []
+        for name, (o, shp) in shapes.items():
+            c = int(np.prod(shp))
+            layer, what = name.split(".")
+            if what in ("mean", "var"):
+                np.testing.assert_allclose(wa[o:o + c], wb[o:o + c], rtol=1e-5, atol=1e-7, err_msg="%s %s" % (kind, name))
+                continue
+            ko, kshp = shapes[layer + ".kernel"]
+            kscale = float(np.abs(gb[ko:ko + int(np.prod(kshp))]).max())
+            scale, err = float(np.abs(gb[o:o + c]).max()), float(np.abs(ga[o:o + c] - gb[o:o + c]).max())
+            print("%-10s %-18s scale %.3e  err/scale %.2e" % (kind, name, scale, err / max(scale, 1e-30)))
+            if what == "bias" and layer + ".gamma" in shapes:
+                # the bias of a convolution in front of a BatchNorm has an EXACTLY zero gradient: what either form delivers
+                # is the rounding noise of its sums (it grows with the batch) - bounded against the layer's kernel
+                # gradient, not compared element by element
+                lean_scale = float(np.abs(ga[o:o + c]).max())
+                assert max(scale, lean_scale) <= 2e-4 * kscale, (kind, name, scale, lean_scale, kscale)
+                if layer == "conv1":        # the first layer's is written as the exact zero (f_bw_first)
+                    assert lean_scale == 0.0, (kind, name)
+            elif err > 1e-4 * scale + 5e-5 * kscale:
+                bad.append((name, scale, err))
+        assert not bad, (kind, n, bad)
+    b.close()
+
+
+def _batch_statistics_f64(tmp_path, w, shapes, bits, vec8):
+    """tests/bn_stats64.py in a process of its own: torch's HIP runtime and libofx's do not initialise side by side in
+    one process in that order (torch reports no GPU once libofx has opened the device), and the checker shares nothing
+    with the library anyway."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = list(shapes)
+    fin, fout = str(tmp_path / "bn_in.npz"), str(tmp_path / "bn_out.npz")
+    np.savez(fin, w=w, bits=bits, vec8=vec8, names=np.array(names), offs=np.array([shapes[k][0] for k in names]),
+             shp=np.array([list(shapes[k][1]) + [0] * (4 - len(shapes[k][1])) for k in names]))
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "bn_stats64.py"), fin, fout], capture_output=True,
+                       text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = np.load(fout)
+    return {k[:-5]: (d[k], d[k[:-5] + ".var"]) for k in d.files if k.endswith(".mean")}
+
+
+def test_lean_fit_at_4096_rows(tmp_path):
+    """The bench's fit_batch: 4096 rows, lean form.  Two runs give the same bits, everything is finite, and the moved
+    statistics of EVERY BatchNorm - conv1 first (the layer the lean fit never materialises: its statistics come from the
+    autocorrelation of the 1-bit maps) up to upconv3 (the last normalised layer, behind all others) - equal
+    0.99 * old + 0.01 * (batch mean | biased batch variance) of a float64 evaluation of the same minibatch."""
+    from ofighters_amd import DeviceBuffer, _native as nat
+    b, n, rows_d, bp_d, bn_d = _collect_minibatch(1024)
+    assert n == 4096
+    w, shapes = pyoracle.policy_init(5, trained_like=True)
+    rs = np.random.RandomState(3)
+    y = DeviceBuffer(4 * n).upload(rs.uniform(-1, 2, n).astype(np.float32))
+    y2 = DeviceBuffer(4 * n).upload(rs.uniform(-1, 2, n).astype(np.float32))
+    bufs = tuple(DeviceBuffer(w.nbytes) for _ in range(4))
+    b.set_option(nat.OPT_FIT_PLAIN, 0)
+    for kind in ("textbook", "reference"):
+        la, ga, wa = _fit_once(b, kind, w, n, rows_d, bp_d, bn_d, y, y2, bufs)
+        la2, ga2, wa2 = _fit_once(b, kind, w, n, rows_d, bp_d, bn_d, y, y2, bufs)
+        assert la == la2 and np.array_equal(ga, ga2) and np.array_equal(wa, wa2), kind
+        assert np.isfinite(ga).all() and np.isfinite(wa).all() and np.isfinite(la).all() and np.abs(ga).max() > 0
+        rows = rows_d.download(b.TRANSITION_DTYPE, (n,))
+        bits = (bn_d if kind == "reference" else bp_d).download(np.uint32, (n, 2, 5000))     # the reference fits on next_state
+        vec8 = rows["head_next" if kind == "reference" else "head_prev"]
+        stats = _batch_statistics_f64(tmp_path, w.astype(np.float64), shapes, bits, vec8)
+        for layer, (bm, bv) in stats.items():
+            for what, batch_stat in (("mean", bm), ("var", bv)):
+                o, shp = shapes[layer + "." + what]
+                c = int(np.prod(shp))
+                want = 0.99 * w[o:o + c].astype(np.float64) + 0.01 * batch_stat
+                moved = wa[o:o + c].astype(np.float64) - 0.99 * w[o:o + c]
+                # the comparison is on the 1 % that moved: (new - 0.99 old) / 0.01 against the float64 batch statistic
+                scale = max(float(np.abs(batch_stat).max()), 1e-6)
+                err = float(np.abs(moved / 0.01 - batch_stat).max())
+                print("%-10s %-8s %-4s batch statistic scale %.3e  err %.2e" % (kind, layer, what, scale, err))
+                assert err <= 2e-4 * scale + 2e-5, (kind, layer, what, err, scale)
+                np.testing.assert_allclose(wa[o:o + c], want, rtol=5e-6, atol=1e-6)
+    b.close()

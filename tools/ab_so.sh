@@ -3,6 +3,7 @@
 # tools/ab_so.sh build/libofx_a.so build/libofx_b.so ...   each is timed twice, interleaved; restores the default build
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 cp ofighters_amd/libofx.so /tmp/libofx_keep.so
+trap 'cp /tmp/libofx_keep.so ofighters_amd/libofx.so' EXIT   # an interrupted run must not leave a variant installed
 for rep in 1 2; do
   for so in "$@"; do
     cp "$so" ofighters_amd/libofx.so
@@ -11,4 +12,3 @@ import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('[$so]', 'head ms', round(d['roofline']['avg_kernel_ms'],3), 'tick ms', round(d['ms_per_step'],3))"
   done
 done
-cp /tmp/libofx_keep.so ofighters_amd/libofx.so

@@ -3,6 +3,7 @@
 # 0 = product, 1 = forward tiles not filled, 2 = forward tiles not computed.  Results of 1 / 2 are wrong by construction.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 cp ofighters_amd/libofx.so /tmp/libofx_keep.so
+trap 'cp /tmp/libofx_keep.so ofighters_amd/libofx.so' EXIT   # an interrupted run must not leave a variant installed
 for a in 0 1 2; do
   cp build/libofx_abl$a.so ofighters_amd/libofx.so
   rm -rf gpurun_out/abl_stats
@@ -11,4 +12,3 @@ for a in 0 1 2; do
   python3 tools/kstats.py gpurun_out/abl_stats 40 | grep "f_conv_fwd"
 done
 rm -rf gpurun_out/abl_stats
-cp /tmp/libofx_keep.so ofighters_amd/libofx.so

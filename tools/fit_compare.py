@@ -1,8 +1,9 @@
 """Diagnostic (GPU box): the lean and the plain form of the fit on one minibatch of `rows` rows - per-tensor difference
 of the gradients, the losses.  usage: python tools/fit_compare.py [rows] [--reference]"""
+import os
 import sys
 import numpy as np
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ofighters_amd import ArenaBatch, DeviceBuffer, _native as nat
 from oracle import pyoracle
 

@@ -1,7 +1,8 @@
 """Diagnostic (GPU box, under rocprofv3 --kernel-trace --stats): DeviceTrainer.replay at one fit batch size.
 usage: python tools/fit_profile.py [fit_batch]"""
+import os
 import sys, time
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ofighters_amd import ArenaBatch
 from ofighters_amd.trainer import DeviceTrainer
 from ofighters_amd.agents.policy_weights import synthetic

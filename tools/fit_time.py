@@ -2,8 +2,9 @@
 usage: python tools/fit_time.py [--plain] [--reference] [fit_batch ...]     (default 8 64 256 1024 4096)
 --plain: the layer-by-layer form of the fit (OFX_OPT_FIT_PLAIN; 61 MB of workspace per row: keep it at <= 1024 rows)
 --reference: Trainer.replay as written (dense targets) instead of the textbook step"""
+import os
 import sys, time
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ofighters_amd import ArenaBatch, _native as nat
 from ofighters_amd.trainer import DeviceTrainer
 from ofighters_amd.agents.policy_weights import synthetic

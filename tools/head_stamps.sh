@@ -4,6 +4,8 @@
 tag=${1:-x}
 extra=$2
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+cp ofighters_amd/libofx.so /tmp/libofx_keep.so
+trap 'cp /tmp/libofx_keep.so ofighters_amd/libofx.so; touch ofighters_amd/csrc/ofx_head.hip' EXIT   # the default build comes back whatever happens
 mkdir -p gpurun_out
 make -C ofighters_amd/csrc HEAD_EXTRA="-DOFX_HEAD_HOOKS=1 $extra" -B ofx_head.o >/dev/null 2>&1 && make -C ofighters_amd/csrc >/dev/null 2>&1 || { echo "build failed"; exit 1; }
 run() { timeout -k 10 200 python bench.py --steps 30 --warmup 8 --no-cpu-baseline --no-extra 2>>gpurun_out/stamps_$tag.txt | python -c "

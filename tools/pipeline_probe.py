@@ -2,9 +2,10 @@
 own handles / HIP streams, launched alternately without a host sync - do the memory-bound kernels of one half (raster,
 trunk tables, frames, upconv1) hide behind the other half's MFMA-bound k_head_stream?
 usage: python tools/pipeline_probe.py [ticks]"""
+import os
 import sys, time
 import numpy as np
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ofighters_amd import ArenaBatch, DeviceBuffer
 from ofighters_amd.agents.policy_weights import synthetic
 

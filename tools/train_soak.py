@@ -1,7 +1,8 @@
 """Soak run (GPU box): TrainingRollout on 1024 arenas for 450 lock-steps with 1024-row fits on the reference's replay schedule -
 losses and weights stay finite, the TD loss falls (r03: 281 replays in 10 s, loss 5.5 -> 0.17)."""
+import os
 import sys, time, numpy as np
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ofighters_amd import ArenaBatch
 from ofighters_amd.lib.epsilon import Epsilon_decay
 from ofighters_amd.rollout import TrainingRollout
