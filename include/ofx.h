@@ -379,6 +379,13 @@ int ofx_replay_destroy(ofx_handle *h); /* also done by ofx_destroy            */
  * one per call and not restart at episode boundaries.                         */
 int ofx_replay_capture(ofx_handle *h, uint32_t tick, const uint8_t *ship_mask, const int32_t *iaction,
                        const int32_t *ipointer);
+/* QlearnIA.play's `if obs.done: ... self.done = True` (agents/qlearnIA_V2.py:376-384) for a caller that drives the
+ * learning schedule: counts the selected ships (ship_mask [N][M] uint8, NULL = all) that are destroyed now and were
+ * not yet marked in seen[N][M] (device uint8, caller-owned, zeroed by the caller at episode starts), marks them, and
+ * returns the count - the number of learning agents that see their death for the first time on this lock-step, i.e.
+ * how often the reference would call Trainer.replay here.  One 4-byte read instead of an [N][M] download.
+ * Synchronises.                                                                */
+int ofx_agents_first_done(ofx_handle *h, const uint8_t *ship_mask, uint8_t *seen, int32_t *count_host);
 /* len(memory) per arena [N] and the number of rows ever appended [N]; either
  * may be NULL.  Synchronises.                                                 */
 int ofx_replay_count(ofx_handle *h, int32_t *count_host, int64_t *appended_host);

@@ -121,6 +121,7 @@ SIGNATURES = {
     "ofx_replay_create": (_i, [_vp, C.c_int32, C.c_int32]),
     "ofx_replay_destroy": (_i, [_vp]),
     "ofx_replay_capture": (_i, [_vp, _u32, _vp, _vp, _vp]),
+    "ofx_agents_first_done": (_i, [_vp, _vp, _vp, C.POINTER(C.c_int32)]),
     "ofx_replay_count": (_i, [_vp, _vp, _vp]),
     "ofx_replay_rows_host": (_i, [_vp, C.c_int32, _vp, _vp]),
     "ofx_replay_frame_host": (_i, [_vp, C.c_int32, C.c_int32, _vp, _vp]),

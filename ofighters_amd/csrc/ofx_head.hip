@@ -31,6 +31,12 @@
 #include "ofx_lowp.h"
 #include <stdlib.h>
 
+#ifndef HS_B_PRIO
+#define HS_B_PRIO 0
+#endif
+#ifndef HS_C_PRIO
+#define HS_C_PRIO 0
+#endif
 #ifndef OFX_HEAD_HOOKS
 #define OFX_HEAD_HOOKS 0  // 1: the OFX_HEAD_ABLATE timing switches are compiled into k_head_stream (results are wrong)
 #endif
@@ -574,6 +580,9 @@ constexpr float HS_CH[2][3][3] = {{{0.75f, 0.25f, 0.f}, {0.25f, 0.75f, 0.f}, {0.
                                   {{0.25f, 0.75f, 0.f}, {0.f, 0.75f, 0.25f}, {0.f, 0.25f, 0.75f}}};
 constexpr float HS_CL[2][3][3] = {{{0.5f, 0.5f, 0.f}, {0.f, 1.f, 0.f}, {0.f, 0.5f, 0.5f}},
                                   {{0.f, 1.f, 0.f}, {0.f, 0.5f, 0.5f}, {0.f, 0.f, 1.f}}};
+static_assert(HS_CH[0][0][0] == HS_CH[0][2][1] && HS_CH[0][0][1] == HS_CH[0][2][2] && HS_CH[1][0][0] == HS_CH[1][2][1] &&
+              HS_CH[1][0][1] == HS_CH[1][2][2] && HS_CL[0][0][0] == HS_CL[0][2][1] && HS_CL[0][0][1] == HS_CL[0][2][2] &&
+              HS_CL[1][0][0] == HS_CL[1][2][1] && HS_CL[1][0][1] == HS_CL[1][2][2], "the stencil shares the sums of the outer taps");
 // the (k, t) pairs either output parity needs, in read order: 7 of the 9
 constexpr int HS_NKT = 7;
 constexpr int HS_KT[HS_NKT][2] = {{0, 0}, {0, 1}, {1, 0}, {1, 1}, {1, 2}, {2, 1}, {2, 2}};
@@ -625,6 +634,7 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
   // sees only one role's long-lived state at a time.
   if (wv < HS_NB) {
     // ================================================================ producer waves (stage B + the 1x1)
+    __builtin_amdgcn_s_setprio(HS_B_PRIO);
     // lane = (quad n16 of the M-tile, output parity kq = (pa, pb)): ONE uprelu3 pixel, all 8 channels
     const int n16 = lane & 15, kq = lane >> 4;
     const int qd = n16 & 3, lg = n16 >> 2, pa = kq >> 1, pb = kq & 1;
@@ -852,6 +862,7 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
     HS_STAMP_OUT();
   } else {
     // ================================================================ consumer waves (stage A + stencil + arg-max)
+    __builtin_amdgcn_s_setprio(HS_C_PRIO);
     // Every VALU instruction here is paid in matrix throughput (the f32 MFMAs and the VALU share the SIMD's issue
     // slots), so the per-pass bookkeeping is kept to running counters and the arg-max to a snapshot of the best pass.
     const int n16 = lane & 15, kq = lane >> 4;
@@ -1006,40 +1017,41 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
 #pragma unroll
         for (int u = 0; u < 6; u++) {
           if (u + 1 < 6) ldv(u + 1);
+          // reads n = 0 .. 6: V0[R-1], V0[R], V1[R-1], V1[R], V1[R+1], V2[R], V2[R+1] (V_ky of this tap column).  The
+          // first and the last tap row carry the same pair of coefficients one row apart (cy[a][0][0] = cy[a][2][1],
+          // cy[a][0][1] = cy[a][2][2], both conventions), so their sums are shared by the two parities: 10 packed
+          // operations per unit instead of 12
+          const f32x2 *v = V[u & 1];
+          const f32x2 s1 = v[0] + v[5], s2 = v[1] + v[6];
 #pragma unroll
           for (int a = 0; a < 2; a++) {
-            f32x2 z = {0.f, 0.f};
-            bool first = true;
+            f32x2 z = (f32x2){cy[a][0][0], cy[a][0][0]} * s1;
+            z = hs_fma2(cy[a][0][1], s2, z);
 #pragma unroll
-            for (int n = 0; n < HS_NKT; n++) {
-              const int ky = HS_KT[n][0], ty = HS_KT[n][1];
-              if (!HS_NZ[a][ky][ty]) continue;
-              if (first) { z = (f32x2){cy[a][ky][ty], cy[a][ky][ty]} * V[u & 1][n]; first = false; }
-              else z = hs_fma2(cy[a][ky][ty], V[u & 1][n], z);
-            }
+            for (int ty = 0; ty < 3; ty++)
+              if (HS_NZ[a][1][ty]) z = hs_fma2(cy[a][1][ty], v[2 + ty], z);
             Z[a][u >> 1][u & 1] = z;
           }
           __builtin_amdgcn_sched_barrier(0);
         }
         HS_STAMP(1);
         // horizontal: out[a][b] of the pair (x0, x0 + 1) = bias + sum_(kx, tx) cy[b][kx][tx] Z[a][kx](x + tx - 1); the pair
-        // of columns (x0 - 1, x0) / (x0, x0 + 1) / (x0 + 1, x0 + 2) for tx = 0 / 1 / 2
+        // of columns (x0 - 1, x0) / (x0, x0 + 1) / (x0 + 1, x0 + 2) for tx = 0 / 1 / 2, the same sharing between the
+        // first and the last tap column
         f32x4 o[2];
 #pragma unroll
         for (int a = 0; a < 2; a++) {
           f32x2 M[3];
 #pragma unroll
           for (int kx = 0; kx < 3; kx++) M[kx] = (f32x2){Z[a][kx][0][1], Z[a][kx][1][0]};
+          const f32x2 t1 = Z[a][0][0] + M[2], t2 = M[0] + Z[a][2][1];
 #pragma unroll
           for (int b = 0; b < 2; b++) {
-            f32x2 acc = {bias4, bias4};
+            f32x2 acc = hs_fma2(cy[b][0][0], t1, (f32x2){bias4, bias4});
+            acc = hs_fma2(cy[b][0][1], t2, acc);
 #pragma unroll
-            for (int kx = 0; kx < 3; kx++)
-#pragma unroll
-              for (int tx = 0; tx < 3; tx++) {
-                if (!HS_NZ[b][kx][tx]) continue;
-                acc = hs_fma2(cy[b][kx][tx], tx == 0 ? Z[a][kx][0] : tx == 1 ? M[kx] : Z[a][kx][1], acc);
-              }
+            for (int tx = 0; tx < 3; tx++)
+              if (HS_NZ[b][1][tx]) acc = hs_fma2(cy[b][1][tx], tx == 0 ? Z[a][1][0] : tx == 1 ? M[1] : Z[a][1][1], acc);
             o[0][2 * a + b] = acc[0];
             o[1][2 * a + b] = acc[1];
           }
@@ -1066,11 +1078,14 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
         const float m01 = hd_max_raw(hd_max_raw(o[0][0], o[0][1]), hd_max_raw(o[0][2], o[0][3]));
         const float m23 = hd_max_raw(hd_max_raw(o[1][0], o[1][1]), hd_max_raw(o[1][2], o[1][3]));
         const float m8 = hd_max_raw(m01, m23);
-        if (ok && m8 > tv) {
-          tv = m8;
-          tst = st;
-          snap[0] = o[0];
-          snap[1] = o[1];
+        const bool better = ok && m8 > tv;
+        if (__builtin_amdgcn_ballot_w64(better) != 0) {   // wave-uniform: most passes improve no lane's maximum
+          if (better) {
+            tv = m8;
+            tst = st;
+            snap[0] = o[0];
+            snap[1] = o[1];
+          }
         }
       }
       HS_STAMP(2);

@@ -239,6 +239,34 @@ extern "C" int ofx_replay_capture(ofx_handle *h, uint32_t tick, const uint8_t *s
   return OFX_OK;
 }
 
+// first-seen deaths of the selected ships (QlearnIA.play's done latch, agents/qlearnIA_V2.py:376-384)
+__global__ void k_first_done(int n, const uint8_t *alive, const uint8_t *mask, uint8_t *seen, int *count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool first = false;
+  if (i < n && alive[i] == 0 && (!mask || mask[i]) && !seen[i]) {
+    seen[i] = 1;
+    first = true;
+  }
+  const unsigned long long b = __builtin_amdgcn_ballot_w64(first);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(count, __popcll(b));
+}
+
+extern "C" int ofx_agents_first_done(ofx_handle *h, const uint8_t *ship_mask, uint8_t *seen, int32_t *count_host) {
+  if (!h || !seen || !count_host) { ofx_set_error("ofx_agents_first_done: null argument"); return OFX_ERR_INVALID; }
+  if (!h->spawned) { ofx_set_error("ofx_agents_first_done before ofx_spawn"); return OFX_ERR_STATE; }
+  OFX_HIP(hipSetDevice(h->cfg.device));
+  int rc;
+  if ((rc = ofx_ensure_scratch(h, 256))) return rc;
+  int *cnt = (int *)h->scratch;
+  OFX_HIP(hipMemsetAsync(cnt, 0, sizeof(int), h->stream));
+  const int n = h->cfg.n_arenas * h->cfg.n_ships;
+  hipLaunchKernelGGL(k_first_done, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, h->st.alive, ship_mask, seen, cnt);
+  OFX_HIP(hipGetLastError());
+  OFX_HIP(hipMemcpyAsync(count_host, cnt, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  OFX_HIP(hipStreamSynchronize(h->stream));
+  return OFX_OK;
+}
+
 extern "C" int ofx_replay_count(ofx_handle *h, int32_t *count_host, int64_t *appended_host) {
   if (!h || !h->replay) { ofx_set_error("ofx_replay_count: no replay memory"); return OFX_ERR_STATE; }
   OFX_HIP(hipSetDevice(h->cfg.device));

@@ -408,6 +408,13 @@ class ArenaBatch:
         """QlearnIA.play bookkeeping + Trainer.remember for this lock-step; call before step()."""
         nat.check(nat.lib().ofx_replay_capture(self._h, int(tick), ship_mask_ptr, iaction_ptr, ipointer_ptr))
 
+    def agents_first_done(self, ship_mask_ptr, seen_buf):
+        """How many selected ships are destroyed now and not yet marked in `seen_buf` (DeviceBuffer, uint8 [N][M]); marks
+        them.  QlearnIA.play's `if obs.done` (qlearnIA_V2.py:376-384) for all learning agents: one int crosses to the host."""
+        n = C.c_int32(0)
+        nat.check(nat.lib().ofx_agents_first_done(self._h, ship_mask_ptr, seen_buf.ptr, C.byref(n)))
+        return n.value
+
     def replay_count(self):
         cnt = np.empty(self.N, np.int32)
         app = np.empty(self.N, np.int64)
@@ -468,6 +475,13 @@ class ArenaBatch:
         nat.check(nat.lib().ofx_replay_gather_valid(self._h, slot.ptr, n_sampled.ptr, int(batch), int(first), int(max_rows),
                                                      rows.ptr, bp.ptr, bn.ptr, C.byref(n)))
         return rows, bp, bn, n.value
+
+    def replay_gather_valid_into(self, slot, n_sampled, batch, first, max_rows, rows, bits_prev, bits_next):
+        """replay_gather_valid into the caller's DeviceBuffers (a trainer keeps them between replays); returns n_rows."""
+        n = C.c_int32()
+        nat.check(nat.lib().ofx_replay_gather_valid(self._h, slot.ptr, n_sampled.ptr, int(batch), int(first), int(max_rows),
+                                                     rows.ptr, bits_prev.ptr, bits_next.ptr, C.byref(n)))
+        return n.value
 
     def policy_forward_obs(self, weights_ptr, n_obs, bits_ptr, vec8_ptr, want_probe_ptr=None):
         """Forward on stored observations (Trainer.replay's predictions): host dict of act / iaction / ipointer /

@@ -152,7 +152,8 @@ class TrainingRollout(ShardedRollout):
         self.policy_mask = mk
         engine.sync()
         self._mask = DeviceBuffer(mk.nbytes).upload(mk)
-        self._seen_done = np.zeros((engine.N, engine.M), bool)
+        self._zeros = np.zeros((engine.N, engine.M), np.uint8)
+        self._seen_done = DeviceBuffer(mk.nbytes).upload(self._zeros)   # the agents' `done` latches, on the device
         engine.policy_pin_weights(trainer.weights.ptr)
         self.policy = self._play
         self.capture_tick = 0                      # ofx_replay_capture's clock: never restarts at episode ends
@@ -161,7 +162,8 @@ class TrainingRollout(ShardedRollout):
         total = super()._episode_end()
         self.episode += 1
         self.epsilons.append(self.trainer.epsilon.get())
-        self._seen_done[:] = False
+        self.e.sync()
+        self._seen_done.upload(self._zeros)         # QlearnIA.reset: done = False (:360-368)
         if (self.is_learning and self.snapshot_folder is not None and self.snapshot_every
                 and self.episode % self.snapshot_every == 0):
             self.snapshots.append(self.trainer.save(id="iteration-%s" % self.episode, overwrite=True,
@@ -180,11 +182,8 @@ class TrainingRollout(ShardedRollout):
         t, m = self.trainer, self._mask.ptr
         collecting = self.total_steps < self.collecting_steps
         if self.is_learning and self.replay_on_death:
-            from . import _native as nat
-            done = (e.get(nat.F_SHIP_ALIVE) == 0) & (self.policy_mask == 1)
-            deaths = done & ~self._seen_done       # obs.done seen for the first time this lock-step (:375-378)
-            self._seen_done |= done
-            if deaths.any():
+            # obs.done seen for the first time this lock-step (:375-378): counted on the device, one int comes back
+            if e.agents_first_done(m, self._seen_done) > 0:
                 self._replay()
         e.policy_forward(t.weights.ptr, m)
         e.policy_explore(t.epsilon.get(), self.seed, tick=self.capture_tick, collecting=collecting, ship_mask_ptr=m)

@@ -31,7 +31,18 @@ class DeviceTrainer:
         self.fit_steps = 0
         self.draws = 0
         self.losses = []
+        self._buf = {}                                       # replay scratch kept between calls (grow-only)
         batch.replay_create(memory_size, frames)
+
+    def _scratch(self, name, nbytes):
+        """A device buffer of at least nbytes that lives as long as the trainer: no hipMalloc / hipFree per replay."""
+        b = self._buf.get(name)
+        if b is None or b.nbytes < nbytes:
+            if b is not None:
+                self.batch.sync()
+                b.free()
+            b = self._buf[name] = DeviceBuffer(int(nbytes))
+        return b
 
     def decay_epsilon(self):
         self.epsilon.next()
@@ -74,7 +85,10 @@ class DeviceTrainer:
             return None
         n = min(n_valid, int(self.fit_batch))
         start = ((self.draws - 1) * n) % (n_valid - n + 1)
-        rows, bits_prev, bits_next, got = b.replay_gather_valid(slot, n_s, bs, start, n)
+        words = b.W * b.H // 32
+        rows = self._scratch("rows", n * b.TRANSITION_DTYPE.itemsize)
+        bits_prev, bits_next = self._scratch("bits_prev", 4 * n * 2 * words), self._scratch("bits_next", 4 * n * 2 * words)
+        got = b.replay_gather_valid_into(slot, n_s, bs, start, n, rows, bits_prev, bits_next)
         if got != n:
             raise Exception("DeviceTrainer.replay: gathered %d of %d rows" % (got, n))
         rows_p, prev_p, next_p = rows.ptr, bits_prev.ptr, bits_next.ptr
@@ -84,7 +98,7 @@ class DeviceTrainer:
                                        rows_p, prev_p, next_p, self.gamma)
             self.losses.append(loss)
             return loss
-        y_act, y_ptr = DeviceBuffer(4 * n), DeviceBuffer(4 * n)
+        y_act, y_ptr = self._scratch("y_act", 4 * n), self._scratch("y_ptr", 4 * n)
         from . import _native as nat
         # q_sa / p_sp (the current values at the chosen action / pointer) are not asked for: the fit's own training-mode
         # forward produces them, so the targets need the forward on next_state only

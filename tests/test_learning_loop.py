@@ -41,6 +41,8 @@ class _FakeEngine:
     def __init__(self, N=3, M=2):
         self.N, self.M, self.episode, self.log, self.t = N, M, 0, [], 0
         self.alive = np.ones((N, M), np.uint8)
+        self.seen = np.zeros((N, M), bool)
+        self.mask = np.zeros((N, M), bool); self.mask[:, 0] = True
     def sync(self): pass
     def spawn_random(self, seed): pass
     def restart_random(self, seed):
@@ -48,6 +50,11 @@ class _FakeEngine:
     def episode_scores(self): return np.arange(self.M + 1, dtype=np.int64)
     def policy_pin_weights(self, p): self.log.append("pin")
     def get(self, field): return self.alive.copy()
+    def agents_first_done(self, mask_ptr, seen):          # the device-side `done` latches (ofx_agents_first_done)
+        if getattr(seen, "cleared", False): self.seen, seen.cleared = np.zeros((self.N, self.M), bool), False
+        first = (self.alive == 0) & self.mask & ~self.seen
+        self.seen |= first
+        return int(first.sum())
     def bot_actions(self, beh, seed, tick=None): self.log.append("bots")
     def policy_forward(self, w, m): self.log.append("forward")
     def policy_explore(self, eps, seed, tick=None, collecting=False, ship_mask_ptr=None):
@@ -65,7 +72,9 @@ def test_training_rollout_schedule(tmp_path, monkeypatch):
 
     class _DB:
         def __init__(self, n): self.ptr = 7
-        def upload(self, a): return self
+        def upload(self, a):
+            self.cleared = not np.asarray(a).any()         # TrainingRollout zeroes the latches at episode ends
+            return self
     monkeypatch.setattr(eng, "DeviceBuffer", _DB)
     e, t = _FakeEngine(), _FakeTrainer()
     r = TrainingRollout(e, t, ["idle", "idle"], seed=3, policy_ships=(0,), episode_ticks=40, snapshot_every=2,

@@ -41,6 +41,12 @@ def diff(start, count, names=("conv1.kernel", "conv1.gamma", "conv2.kernel")):
 
 
 print("whole", n, diff(0, n))
+if "--shift" in sys.argv:
+    for start in (0, 1, 4, 512, 1000, 1024):
+        if start + 1024 <= n:
+            print("window", start, 1024, ["%.2e" % v for v in diff(start, 1024)])
+    b.close()
+    sys.exit(0)
 if "--whole" in sys.argv:
     for count in (1023, 1024, 512, 2047 if n >= 2048 else 1000, 2048 if n >= 2048 else 1008):
         print("prefix", count, ["%.2e" % v for v in diff(0, count)])
