@@ -518,12 +518,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(workload, n_pol_, alive_only, warmup, steps, full_config, bf16=False):
+    def measure(workload, n_pol_, alive_only, warmup, steps, full_config, bf16=False, sparse=False):
         b = ArenaBatch(N, M, device=local_rank, arena_base=base)
         if args.trunk_form:
             b.set_option(nat.OPT_TRUNK_FUSE, args.trunk_form)
         if bf16:
             b.set_option(nat.OPT_POLICY_BF16, int(bf16))
+        if sparse:
+            b.set_option(nat.OPT_TRUNK_SPARSE, 1)
         ep = b.cfg.episode_ticks
         # an episode end (restart + score all-reduce) falls into the middle of the timed region whatever --steps is
         start = (ep - warmup - max(1, steps // 2)) % ep
@@ -536,6 +538,18 @@ def main():
         if wl.roll.score_log:
             rec["last_episode_score_sum"] = int(wl.roll.score_log[-1][:M].sum())
             rec["last_episode_arenas"] = int(wl.roll.score_log[-1][M])
+        if sparse:
+            run, total, trun, ttotal = b.policy_trunk_stats()      # over warm-up + timed region
+            frac = run / max(1, total)
+            # dense algorithmic work of the tick minus the conv2 M-tiles that were not run (conv2 = 23.04 MMAC per arena);
+            # the table passes that were skipped are LDS reads, not FLOPs
+            n_eff = rec["roofline"]["algorithmic_flops_per_launch"] / (N * 2.0 * 23.76e6)
+            whole = N * 2.0 * (53.28e6 + n_eff * 24.37e6)
+            executed = whole - N * 2.0 * 23.04e6 * (1.0 - frac)
+            rec["trunk_sparse"] = {"conv2_mtiles_executed_frac": frac, "conv1_table_passes_executed_frac": trun / max(1, ttotal),
+                                   "executed_flops_per_tick": executed,
+                                   "tick_tflops_on_executed_flops": executed / (dt / steps) / 1e12,
+                                   "frac_of_fp32_peak_on_executed_flops": executed / (dt / steps) / 1e12 / FP32_PEAK_TF}
         b.close()
         return rec
 
@@ -582,6 +596,16 @@ def main():
                 r["fp32_bound_arena_steps_per_s"] = N * FP32_PEAK_TF * 1e12 / flops
                 r["frac_of_fp32_bound"] = r["value"] / r["fp32_bound_arena_steps_per_s"]
             extra.append(r)
+        # OPT-IN, EXACT (OFX_OPT_TRUNK_SPARSE): the streaming trunk skips the constant windows of its ~1 %-dense input,
+        # bit-identical results (tests/test_gpu_policy.py); the headline `value` above stays on the DENSE trunk this round
+        for np_ in (M, 1):
+            r = measure("step+obs+policy", np_, False, 40, 200, False, sparse=True)
+            flops = r["roofline"]["algorithmic_flops_per_launch"] / 23.76e6 * 24.37e6 + N * 2.0 * 53.28e6
+            r["fp32_bound_arena_steps_per_s"] = N * FP32_PEAK_TF * 1e12 / flops
+            r["frac_of_fp32_bound"] = r["value"] / r["fp32_bound_arena_steps_per_s"]
+            r["note"] = ("opt-in OFX_OPT_TRUNK_SPARSE = 1: exact (bit-identical outputs), fp32; a secondary line - the "
+                         "headline runs the dense trunk")
+            extra.append(r)
         # OPT-IN reduced precision (OFX_OPT_POLICY_BF16): never `value`, no parity and no roofline claim - the speed of the
         # bf16-operand head for 8 and 1 policy ships next to its measured error against the float64 graph
         acc = None
@@ -627,10 +651,13 @@ def main():
         out["config"]["secondary"] = {
             "step": brief(extra[0]), "step_obs": brief(extra[1]),
             "policy_1ship": brief(extra[2], "frac_of_fp32_bound"), "policy_alive_only": brief(extra[3], "frac_of_fp32_bound"),
-            "bf16_8ships": brief(extra[4], "frac_of_north_star_target"), "bf16_1ship": brief(extra[5], "frac_of_north_star_target"),
+            "sparse_trunk_8ships": brief(extra[4], "frac_of_fp32_bound"), "sparse_trunk_1ship": brief(extra[5], "frac_of_fp32_bound"),
+            "sparse_trunk_conv2_mtiles_executed_frac": (extra[4].get("trunk_sparse") or {}).get("conv2_mtiles_executed_frac"),
+            "bf16_8ships": brief(extra[6], "frac_of_north_star_target"), "bf16_1ship": brief(extra[7], "frac_of_north_star_target"),
             "train_tick_ms": tt.get("ms_per_step"), "fit4096_ms": tt.get("ms_per_replay_fit_batch_4096"),
             "scratch_feed_obs": brief(extra[-1]),
-            "note": "secondary lines, never `value`; full records in extra_configs; bf16 = opt-in OFX_OPT_POLICY_BF16 (no parity credit)",
+            "note": "secondary lines, never `value`; full records in extra_configs; sparse_trunk = opt-in exact OFX_OPT_TRUNK_SPARSE; "
+                    "bf16 = opt-in OFX_OPT_POLICY_BF16 (no parity credit)",
         }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -326,6 +326,16 @@ int ofx_policy_pin_weights(ofx_handle *h, const float *weights);
  * (0) is the lean form: only the pre-activation tensor of every convolution and the trunk's pooled activations are kept (11 MB per row; the first layer is never materialised), everything else
  * is recomputed inside fused tiles.  Same function; the results agree up to fp32 summation order (tests/test_train.py).*/
 #define OFX_OPT_FIT_PLAIN 6
+/* OPT-IN, EXACT: the streaming trunk (OFX_OPT_TRUNK_FUSE) uses the sparsity of its input.  The two input planes are 1-bit
+ * maps with ~1 % of the cells set (lib/observation.py:79-95): conv1 of an empty neighbourhood is ONE value per channel,
+ * and most of conv2's 16-pixel M-tiles multiply that constant.  value 1: a wave of pixel pairs whose bit windows are all
+ * empty writes that value instead of looking its table rows up, and an M-tile whose whole input window holds it (and
+ * touches no zero padding) stores the constant the dense matrix sequence produces for it instead of running the
+ * sequence.  The results are BIT-IDENTICAL to the dense form (tests/test_gpu_policy.py); fp32 forward only (ignored with
+ * OFX_OPT_POLICY_BF16).  bench.py reports it as a labelled secondary line; the headline stays on the dense trunk.
+ * ofx_policy_trunk_stats: since the last call, M-tiles run / all and table passes run / all [4] (resets; synchronises). */
+#define OFX_OPT_TRUNK_SPARSE 7
+int ofx_policy_trunk_stats(ofx_handle *h, int64_t *counts_host);
 int ofx_set_option(ofx_handle *h, int32_t option, int32_t value);
 /* Exploration of the bi-head action space (Trainer.get_best_action epsilon branch, agents/qlearnIA_V2.py:199-204,
  * and the collecting phase :393-395): for every selected ship, with probability `epsilon` - or always when

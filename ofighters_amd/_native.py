@@ -29,7 +29,7 @@ BEHAVIOURS = {None: BOT_IDLE, "idle": BOT_IDLE, "random": BOT_RANDOM, "turret": 
  F_OBS_REWARD) = range(19)
 
 MAP_U8, MAP_F32, MAP_F64, MAP_BITS = range(4)
-OPT_TRUNK_PLAIN, OPT_FRAMES_REF, OPT_BILINEAR_LEGACY, OPT_TRUNK_FUSE, OPT_POLICY_BF16, OPT_FIT_PLAIN = 1, 2, 3, 4, 5, 6   # ofx_set_option
+OPT_TRUNK_PLAIN, OPT_FRAMES_REF, OPT_BILINEAR_LEGACY, OPT_TRUNK_FUSE, OPT_POLICY_BF16, OPT_FIT_PLAIN, OPT_TRUNK_SPARSE = 1, 2, 3, 4, 5, 6, 7   # ofx_set_option
 
 
 class OfxError(Exception):
@@ -134,6 +134,7 @@ SIGNATURES = {
     "ofx_policy_profile": (_i, [_vp, C.c_int32]),
     "ofx_policy_pin_weights": (_i, [_vp, _vp]),
     "ofx_set_option": (_i, [_vp, C.c_int32, C.c_int32]),
+    "ofx_policy_trunk_stats": (_i, [_vp, C.POINTER(C.c_int64)]),
     "ofx_event_elapsed": (_i, [_vp, C.c_int32, C.c_int32, C.POINTER(C.c_float)]),
 }
 

@@ -165,7 +165,7 @@ extern "C" int ofx_destroy(ofx_handle *h) {
   ofx_state &s = h->st;
   void *ptrs[] = {s.ship_x, s.ship_y, s.ship_px, s.ship_py, s.hull, s.reward, s.score, s.obs_reward, s.last_score,
                   s.alive, s.killer, s.time, s.n_lasers, s.laser_x, s.laser_y, s.laser_dx, s.laser_dy,
-                  s.laser_owner, s.laser_dead, s.overflow, s.episode_sums, h->bot_behaviours, h->scratch, h->aux, h->prep, h->prep_tmp, h->counter, h->fitws, h->fitws2};
+                  s.laser_owner, s.laser_dead, s.overflow, s.episode_sums, h->bot_behaviours, h->scratch, h->aux, h->prep, h->prep_tmp, h->counter, h->fitws, h->fitws2, h->trunk_stat};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   for (int t = 0; t < 5; t++) for (int w = 0; w < 2; w++) if (h->maps[t][w]) (void)hipFree(h->maps[t][w]);
   if (h->events) { (void)hipEventDestroy(h->ev0); (void)hipEventDestroy(h->ev1); }

@@ -29,6 +29,7 @@
 // the minibatch 11 MB of workspace instead of 61 MB; 4096 rows in 66 ms.
 #include "ofx_internal.h"
 #include "ofx_fit.h"
+#include "ofx_diag.h"
 
 namespace {
 
@@ -111,12 +112,6 @@ __device__ __forceinline__ float src_value(const FitSrc &S, size_t s, int c, int
 // or three workgroups per CU nothing hides ~2 us of HBM latency per iteration (the first lean build spent 38 000 cycles
 // on a tile that holds 4 000 cycles of instructions).
 constexpr int FILL_U = 8;
-#ifndef OFX_FIT_SW
-#define OFX_FIT_SW 1
-#endif
-#ifndef OFX_FIT_ABLATE   /* diagnostic builds only: 1 = no tile fill, 2 = no tile compute in f_conv_fwd / f_bw (wrong results) */
-#define OFX_FIT_ABLATE 0
-#endif
 
 // The input tile of a convolution: in[CI][TR + 2][LP] <- source values of rows y0 - 1 .. y0 + TR, columns x0 - 1 ..
 // x0 + TW (zero outside the plane).  Up-sampling sources first stage the low-res activation they interpolate
@@ -317,12 +312,10 @@ __global__ __launch_bounds__(256, 3) void f_conv_fwd(int n, int H, int W, FitSrc
   constexpr int TPR = (TW + 3) / 4, LP = 4 * TPR + 4;
   static_assert(F_TR * TPR <= 256, "tile does not fit the block");
   __shared__ __align__(16) float in[CI][F_TR + 2][LP];
-  __shared__ __align__(16) float wl[9 * CI * CO];
   __shared__ float lo[lo_floats<SRC, CI, F_TR, TW>];
   __shared__ double red[4][2 * CO];
   const int tid = threadIdx.x, r = tid / TPR, q = tid - r * TPR;
   const bool active = r < F_TR;
-  for (int e = tid; e < 9 * CI * CO; e += 256) wl[e] = w[e];
   const int tx_n = W / TW, ty_n = H / F_TR, per_s = tx_n * ty_n;
   const long ntiles = (long)n * per_s;
   double d1[CO], d2[CO];
@@ -347,14 +340,12 @@ __global__ __launch_bounds__(256, 3) void f_conv_fwd(int n, int H, int W, FitSrc
       }
     }
     if (!active || OFX_FIT_ABLATE == 2) continue;
-#if OFX_FIT_SW
     // weights through the scalar cache (s_load, an SGPR pair per v_pk_fma_f32): 18 broadcast ds_read_b128 per input channel
     // kept the LDS return path busier than the vector ALU.  The offset the compiler cannot see through keeps the loads
     // inside the tile loop (hoisted, all 9 CI CO of them would sit in vector registers).
     int zoff;
     asm volatile("s_mov_b32 %0, 0" : "=s"(zoff));
     const float *__restrict__ wt = w + zoff;
-#endif
     float acc[4][CO];
 #pragma unroll
     for (int co = 0; co < CO; co++) {
@@ -373,12 +364,8 @@ __global__ __launch_bounds__(256, 3) void f_conv_fwd(int n, int H, int W, FitSrc
 #pragma unroll
         for (int kx = 0; kx < 3; kx++) {
           float wv[CO];
-#if OFX_FIT_SW
 #pragma unroll
           for (int co = 0; co < CO; co++) wv[co] = wt[((ky * 3 + kx) * CI + ci) * CO + co];
-#else
-          lds_vec<CO>(&wl[((ky * 3 + kx) * CI + ci) * CO], wv);
-#endif
 #pragma unroll
           for (int px = 0; px < 4; px++) fma_row<CO>(acc[px], v[px + kx], wv);
         }
@@ -753,10 +740,7 @@ __global__ __launch_bounds__(256, 2) void f_b1_up(int n, int h, int w, const flo
 
 // ---------------------------------------------------------------- backward 2: dz + the weight gradient
 constexpr int W_TR = 8, W_FLUSH = 16;
-#ifndef OFX_FIT_BW_NT
-#define OFX_FIT_BW_NT 512
-#define OFX_FIT_BW_TR 8
-#endif
+constexpr int OFX_FIT_BW_NT = 512, OFX_FIT_BW_TR = 8;   // f_bw workgroups (256 threads on 4-row tiles: 4 % slower, r03)
 // PHASE: g is ONE plane of 2 H x 2 W per sample (d loss / d heat map) and output channel 2 a + b of cell (y, x) is its
 // element (2 y + a, 2 x + b) - the weight gradient of the output convolution in phase form (f_out_prep).
 template <int CI, int CO, int SRC, int TW, bool BN, int NT, int TR, bool PHASE = false>

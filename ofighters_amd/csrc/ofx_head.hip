@@ -29,17 +29,9 @@
 // of its rings with the exact values and starts the heat-map accumulators of frame pixels at bias - correction.
 #include "ofx_head.h"
 #include "ofx_lowp.h"
+#include "ofx_diag.h"
 #include <stdlib.h>
 
-#ifndef HS_B_PRIO
-#define HS_B_PRIO 0
-#endif
-#ifndef HS_C_PRIO
-#define HS_C_PRIO 0
-#endif
-#ifndef OFX_HEAD_HOOKS
-#define OFX_HEAD_HOOKS 0  // 1: the OFX_HEAD_ABLATE timing switches are compiled into k_head_stream (results are wrong)
-#endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -634,7 +626,6 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
   // sees only one role's long-lived state at a time.
   if (wv < HS_NB) {
     // ================================================================ producer waves (stage B + the 1x1)
-    __builtin_amdgcn_s_setprio(HS_B_PRIO);
     // lane = (quad n16 of the M-tile, output parity kq = (pa, pb)): ONE uprelu3 pixel, all 8 channels
     const int n16 = lane & 15, kq = lane >> 4;
     const int qd = n16 & 3, lg = n16 >> 2, pa = kq >> 1, pb = kq & 1;
@@ -862,7 +853,6 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
     HS_STAMP_OUT();
   } else {
     // ================================================================ consumer waves (stage A + stencil + arg-max)
-    __builtin_amdgcn_s_setprio(HS_C_PRIO);
     // Every VALU instruction here is paid in matrix throughput (the f32 MFMAs and the VALU share the SIMD's issue
     // slots), so the per-pass bookkeeping is kept to running counters and the arg-max to a snapshot of the best pass.
     const int n16 = lane & 15, kq = lane >> 4;

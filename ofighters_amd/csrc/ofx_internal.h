@@ -73,6 +73,8 @@ struct ofx_handle {
   bool opt_trunk_plain, opt_frames_ref, opt_bilinear_legacy;  // ofx_set_option
   int opt_policy_lowp;             // OFX_OPT_POLICY_BF16: 0 fp32, 1 bf16 operands, 2 fp16 operands (opt-in)
   bool opt_fit_plain;              // OFX_OPT_FIT_PLAIN: the fit's layer-by-layer form (test reference)
+  bool opt_trunk_sparse;           // OFX_OPT_TRUNK_SPARSE: the streaming trunk skips constant windows (exact, opt-in)
+  unsigned long long *trunk_stat;  // [4] device counters of the sparse trunk (allocated with the option)
 };
 #define OFX_RING_MAX 65536         /* numbered events of ofx_event_record */
 

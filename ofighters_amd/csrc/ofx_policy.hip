@@ -278,6 +278,7 @@ struct ConvParams {
   int legacy;                      // k_upconv1: TF1 legacy source mapping (src = dst / 2) instead of half-pixel centres
   int images;                      // k_convm: number of images (the grid is padded to a multiple of 8 of them)
   const int32_t *live;             // k_upconv1 with a mask: ordered list of the selected images (live[0] = count), else null
+  unsigned long long *stat;        // k_trunk12<0, true>: [4] M-tiles executed / all, table waves executed / all (may be null)
 };
 
 // MODE: 0 planar f32 input, 1 two 1-bit maps
@@ -846,6 +847,80 @@ __device__ __forceinline__ void ts_gemm_phase(const float *abase, const float (&
   }
 }
 
+// OFX_OPT_TRUNK_SPARSE (opt-in, exact): the same GEMM phase, but an M-tile whose whole input window - 4 tile rows x 18
+// columns - holds the layer's CONSTANT input (conv1 of an empty neighbourhood: every channel plane at K1[ci]) and touches
+// no zero padding stores the constant K2[co] the dense MFMA sequence gives for such a window (computed by that very
+// sequence once per workgroup: the same bits) instead of running its 24 MFMAs.  nz: per tile row 8 words, bit x set
+// <-> column x of that row is NOT known to be constant (phase A).  An M-tile that crosses from one row pair into the
+// next contains columns 199 and 0, i.e. touches the padding: only tiles inside one row pair with 1 <= x, x + 15 <= 198
+// can be constant.  top / bottom: tile row 0 / the last tile row is a padding row of the image.
+template <int WD, int RP, int LS, int PLS>
+__device__ __forceinline__ void ts_gemm_phase_sparse(const float *abase, const float (&bw)[24], const f32x4 binit, int wv, int lane,
+                                                     int n16, int kq, int r, float *orow, const unsigned *nz, float k2,
+                                                     bool top, bool bottom, unsigned &n_exec, unsigned &n_all) {
+  constexpr int NK = 24, NPX = RP * WD, NT = (NPX + 15) / 16;
+  auto aof = [&](int j) -> int { return (4 * (j & 1)) * PLS + ((j >> 1) / 3) * LS + ((j >> 1) % 3); };
+  auto finish = [&](const f32x4 d, int T) {
+    float q0, q1;
+    q0 = max_raw(max_raw(d[0], 0.f), d[1]);
+    q1 = max_raw(max_raw(d[2], 0.f), d[3]);
+    q0 = max_raw(q0, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, q0), 0xB1, 0xF, 0xF, true)));
+    q1 = max_raw(q1, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, q1), 0xB1, 0xF, 0xF, true)));
+    const int P = 16 * T + 4 * kq;
+    const int rp = P / WD, x = P - rp * WD;
+    if (r == 0 && P < NPX) *reinterpret_cast<float2 *>(orow + rp * (WD / 2) + (x >> 1)) = make_float2(q0, q1);
+  };
+  auto a_of_tile = [&](int T) -> const float * {
+    const int P = min(16 * T + n16, NPX - 1);
+    const int rp = P / WD, x = P - rp * WD;
+    return abase + 2 * rp * LS + x;
+  };
+  // wave-uniform: does tile T have to run?  Lanes 0-7 look at (tile row 2 rp + (lane >> 1), word (x >> 5) + (lane & 1))
+  auto must_run = [&](int T) -> bool {
+    const int P = 16 * T, rp = P / WD, x = P - rp * WD;
+    if (x < 1 || x + 15 > WD - 2 || P + 15 >= NPX) return true;          // image columns 0 / WD - 1, or the ragged last tile
+    if ((top && rp == 0) || (bottom && rp == RP - 1)) return true;       // a padding row above / below
+    const int row = 2 * rp + ((lane >> 1) & 3), w0 = (x - 1) >> 5, lo = (x - 1) & 31;  // window = bits x - 1 .. x + 16 of the row
+    const unsigned m = (lane & 1) ? (lo + 18 > 32 ? (1u << (lo + 18 - 32)) - 1u : 0u) : (0x3FFFFu << lo);
+    const unsigned v = lane < 8 ? (nz[row * 8 + w0 + (lane & 1)] & m) : 0u;
+    return __builtin_amdgcn_ballot_w64(v != 0u) != 0;
+  };
+  auto store_const = [&](int T) {                                          // the constant tile: the dense result, stored
+    const int P = 16 * T + 4 * kq, rp = P / WD, x = P - rp * WD;
+    if (r == 0) *reinterpret_cast<float2 *>(orow + rp * (WD / 2) + (x >> 1)) = make_float2(k2, k2);
+  };
+  auto run1 = [&](int T0) {
+    const float *a0 = a_of_tile(T0);
+    f32x4 d0 = binit;
+#pragma unroll
+    for (int j = 0; j < NK; j++) d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[aof(j)], bw[j], d0, 0, 0, 0);
+    finish(d0, T0);
+  };
+  // the wave's M-tiles two at a time (two accumulator chains when both have to run)
+#pragma unroll 1
+  for (int T = wv; T < NT; T += 32) {
+    const int T1 = T + 16;
+    const bool two = T1 < NT;                                              // wave-uniform
+    const bool g0 = must_run(T), g1 = two && must_run(T1);
+    n_all += two ? 2u : 1u;
+    n_exec += (g0 ? 1u : 0u) + (g1 ? 1u : 0u);
+    if (g0 && g1) {
+      const float *a0 = a_of_tile(T), *a1 = a_of_tile(T1);
+      f32x4 d0 = binit, d1 = binit;
+#pragma unroll
+      for (int j = 0; j < NK; j++) {
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[aof(j)], bw[j], d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[aof(j)], bw[j], d1, 0, 0, 0);
+      }
+      finish(d0, T);
+      finish(d1, T1);
+    } else {
+      if (g0) run1(T); else store_const(T);
+      if (two) { if (g1) run1(T1); else store_const(T1); }
+    }
+  }
+}
+
 // OFX_OPT_POLICY_BF16 (opt-in): the same banded GEMM on v_mfma_f32_16x16x16_bf16 - K = 96 as 6 MFMAs of K = 16 instead
 // of 24 of K = 4.  MFMA J, lane (pixel n16, k-quarter kq), element i: k <-> (tap = 2 J + (kq >> 1), ci = 4 (kq & 1) + i):
 // the A operand is the four channel planes 4 (kq & 1) .. + 3 at the tap's (row, dx) of the fp32 LDS tile, rounded to
@@ -920,14 +995,24 @@ static_assert(F12_PLS % 64 == 16 && F12_PLS % 4 == 0 && F12_LS % 4 == 0, "tile l
 static_assert(2 * F12_BR * F12_WR <= F12_THREADS, "one staged word per thread");
 static_assert((F12_TH + 1) * 100 <= 2 * F12_THREADS && F12_TH * 100 <= F12_THREADS, "pixel pairs per step");
 
-template <int LP>
+// SPARSE (OFX_OPT_TRUNK_SPARSE, opt-in, fp32 only): the two input planes are ~1 % set bits (lib/observation.py:79-95), so
+// most of conv1's output is ONE value per channel - K1[c] = relu(bn(conv1(empty window))), table pattern 0 - and most
+// of conv2's M-tiles multiply that constant.  Exact: a wave whose 64 pixel pairs all see empty 4 x 6 bit windows writes
+// K1 instead of reading its 16 table rows per pixel (the same sum of the same two table entries), every other pixel
+// pair marks its two columns in a per-row bit map, and the GEMM phase skips M-tiles whose whole window is unmarked and
+// away from the padding (ts_gemm_phase_sparse).  Bit-identical to the dense kernel (tests/test_gpu_policy.py).
+template <int LP, bool SPARSE = false>
 __global__ __launch_bounds__(F12_THREADS) void k_trunk12(ConvParams p, const float *lut) {
   constexpr bool BF16 = LP != 0;
+  static_assert(!(BF16 && SPARSE), "the sparse form is the fp32 kernel's");
   constexpr int W = PS, H = PS, H1 = PS / 2, H2 = PS / 4, LS = F12_LS, PLS = F12_PLS, NK = 24;
   __shared__ __align__(16) float slut[2 * 512 * 8];
   __shared__ __align__(16) float tile[8 * F12_PLS];
   __shared__ unsigned rows[2][2][F12_BR][F12_WR];  // [buffer][channel][bit row][word]
   __shared__ __align__(16) float halo[2][8][2][F12_LS];  // the last two p1 rows of a step = the first two of the next
+  __shared__ unsigned nz[SPARSE ? 2 : 1][F12_ROWS][8];   // SPARSE: [buffer][tile row]: bit x <-> column x may differ from K1
+  __shared__ __align__(16) float k1s[8], k2s[8];         // SPARSE: the constants of an empty neighbourhood
+  unsigned n_exec = 0, n_all = 0, t_exec = 0, t_all = 0; // SPARSE: the wave's counts (M-tiles run / all, table passes run / all)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n16 = lane & 15, kq = lane >> 4, co = n16 >> 1, r = n16 & 1;
@@ -977,10 +1062,32 @@ __global__ __launch_bounds__(F12_THREADS) void k_trunk12(ConvParams p, const flo
   }
   const float bias = p.b[co];
   const f32x4 binit = {bias, bias, bias, bias};
+  const float *abase = &tile[kq * PLS + 3];
+  if constexpr (SPARSE) {
+    // K1: the table form's value for pattern 0 in both channels (the max of four equal sums and 0); K2: conv2 + pool + ReLU
+    // of a window of K1 planes, through the kernel's own MFMA sequence on a tile filled with them
+    __syncthreads();                                               // slut stands
+    if (tid < 8) k1s[tid] = fmaxf(slut[tid] + slut[512 * 8 + tid], 0.f);
+    for (int e = tid; e < 2 * F12_ROWS * 8; e += F12_THREADS) (&nz[0][0][0])[e] = 0u;
+    __syncthreads();
+    for (int e = tid; e < 8 * PLS; e += F12_THREADS) tile[e] = k1s[min(e / PLS, 7)];
+    __syncthreads();
+    if (wv == 0) {
+      auto aof = [&](int j) -> int { return (4 * (j & 1)) * PLS + ((j >> 1) / 3) * LS + ((j >> 1) % 3); };
+      const float *a0 = abase + 2 * LS + 16 + n16;                 // any interior M-tile: row pair 1, columns 16 .. 31
+      f32x4 d0 = binit;
+#pragma unroll
+      for (int j = 0; j < NK; j++) d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[aof(j)], bw[j], d0, 0, 0, 0);
+      float q0 = max_raw(max_raw(d0[0], 0.f), d0[1]);
+      q0 = max_raw(q0, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, q0), 0xB1, 0xF, 0xF, true)));
+      if (r == 0 && kq == 0) k2s[co] = q0;
+    }
+    __syncthreads();
+    for (int e = tid; e < 8 * PLS / 4; e += F12_THREADS) reinterpret_cast<f32x4 *>(tile)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   bits_commit(0, 0, F12_TH + 1, bits_fetch((int)blockIdx.x, 0, F12_TH + 1));
   __syncthreads();
-
-  const float *abase = &tile[kq * PLS + 3];
+  const float k2 = SPARSE ? k2s[co] : 0.f;
 
   // persistent: a workgroup takes images blockIdx.x, blockIdx.x + gridDim.x, ... (table, weights and the zero frame of
   // the tile are set up once; the first bit rows of the next image are fetched under the last step of this one)
@@ -1003,6 +1110,9 @@ __global__ __launch_bounds__(F12_THREADS) void k_trunk12(ConvParams p, const flo
       const int c4 = tid % (LS / 4), rr = (tid / (LS / 4)) & 1, ci = tid / (2 * (LS / 4));
       reinterpret_cast<f32x4 *>(&tile[ci * PLS + rr * LS])[c4] = reinterpret_cast<const f32x4 *>(&halo[buf][ci][rr][0])[c4];
     }
+    if constexpr (SPARSE) {  // ... and their column marks (the rows this step writes start at tile row 2: no overlap)
+      if (step && tid < 16) nz[buf][tid >> 3][tid & 7] = nz[buf ^ 1][F12_TH + (tid >> 3)][tid & 7];
+    }
     for (int q = tid; q < (pb - pa) * 100; q += F12_THREADS) {
       const int py = q / 100, pp = q - py * 100;
       const int x0 = 4 * pp;                                       // window = staged bits x0 .. x0 + 5 of rows 2 py .. 2 py + 3
@@ -1015,6 +1125,21 @@ __global__ __launch_bounds__(F12_THREADS) void k_trunk12(ConvParams p, const flo
           f[ci][rr] = __funnelshift_r(rw[0], rw[1], (unsigned)(x0 & 31)) & 63u;
         }
       float m2[8][2];
+      bool dense_pass = true;
+      if constexpr (SPARSE) {
+        const unsigned any = (f[0][0] | f[0][1] | f[0][2] | f[0][3]) | (f[1][0] | f[1][1] | f[1][2] | f[1][3]);
+        dense_pass = __builtin_amdgcn_ballot_w64(any != 0u) != 0;  // wave-uniform
+        t_all++;
+        if (dense_pass) {
+          t_exec++;
+          if (any != 0u) atomicOr(&nz[buf][pa + py - (R0 - 1)][(2 * pp) >> 5], 3u << ((2 * pp) & 31));  // columns 2 pp, 2 pp + 1: an even bit and its neighbour
+        } else {
+          const f32x4 ka = *reinterpret_cast<const f32x4 *>(&k1s[0]), kb = *reinterpret_cast<const f32x4 *>(&k1s[4]);
+#pragma unroll
+          for (int c = 0; c < 8; c++) m2[c][0] = m2[c][1] = c < 4 ? ka[c & 3] : kb[c & 3];
+        }
+      }
+      if (dense_pass) {
 #pragma unroll
       for (int j = 0; j < 2; j++) {
         f32x4 acc[4][2];                                           // [2x2 pixel][channels 0-3 | 4-7]
@@ -1036,6 +1161,7 @@ __global__ __launch_bounds__(F12_THREADS) void k_trunk12(ConvParams p, const flo
           m2[c][j] = m;
         }
       }
+      }  // dense_pass
       const int trow = pa + py - (R0 - 1);
       float *dst = &tile[trow * LS + 4 + 2 * pp];
 #pragma unroll
@@ -1059,11 +1185,23 @@ __global__ __launch_bounds__(F12_THREADS) void k_trunk12(ConvParams p, const flo
     if constexpr (BF16)
       ts_gemm_phase_bf16<200, F12_TH / 2, F12_LS, F12_PLS, LP ? LP : 1>(abase, bwb, binit, wv, n16, kq, r,
                                                             p.out + (((size_t)img * 8 + co) * H2 + (R0 >> 1)) * H2);
-    else
+    else if constexpr (SPARSE) {
+      ts_gemm_phase_sparse<200, F12_TH / 2, F12_LS, F12_PLS>(abase, bw, binit, wv, lane, n16, kq, r,
+                                                              p.out + (((size_t)img * 8 + co) * H2 + (R0 >> 1)) * H2,
+                                                              &nz[buf][0][0], k2, step == 0, last, n_exec, n_all);
+      // the other buffer's marks are last step's: cleared for the next step (its first two rows are copied in there)
+      for (int e = tid; e < F12_ROWS * 8; e += F12_THREADS) (&nz[buf ^ 1][0][0])[e] = 0u;
+    } else
       ts_gemm_phase<200, F12_TH / 2, F12_LS, F12_PLS>(abase, bw, binit, wv, n16, kq, r,
                                                        p.out + (((size_t)img * 8 + co) * H2 + (R0 >> 1)) * H2);
     if (more) bits_commit(buf ^ 1, na, nb, nextw);  // the other buffer: phase A of this step is behind every wave
     __syncthreads();
+  }
+  if constexpr (SPARSE) {
+    if (p.stat && lane == 0) {
+      atomicAdd(&p.stat[0], (unsigned long long)n_exec); atomicAdd(&p.stat[1], (unsigned long long)n_all);
+      atomicAdd(&p.stat[2], (unsigned long long)t_exec); atomicAdd(&p.stat[3], (unsigned long long)t_all);
+    }
   }
 }
 
@@ -1453,6 +1591,17 @@ int ofx_policy_weights_updated(ofx_handle *h, const float *weights) {  // ofx_tr
   return OFX_OK;
 }
 
+extern "C" int ofx_policy_trunk_stats(ofx_handle *h, int64_t *counts_host) {
+  if (!h || !counts_host) { ofx_set_error("ofx_policy_trunk_stats: null argument"); return OFX_ERR_INVALID; }
+  for (int i = 0; i < 4; i++) counts_host[i] = 0;
+  if (!h->trunk_stat) return OFX_OK;
+  OFX_HIP(hipSetDevice(h->cfg.device));
+  OFX_HIP(hipMemcpyAsync(counts_host, h->trunk_stat, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+  OFX_HIP(hipMemsetAsync(h->trunk_stat, 0, 4 * sizeof(unsigned long long), h->stream));
+  OFX_HIP(hipStreamSynchronize(h->stream));
+  return OFX_OK;
+}
+
 extern "C" int ofx_set_option(ofx_handle *h, int32_t option, int32_t value) {
   if (!h) { ofx_set_error("ofx_set_option: null handle"); return OFX_ERR_INVALID; }
   switch (option) {
@@ -1461,6 +1610,13 @@ extern "C" int ofx_set_option(ofx_handle *h, int32_t option, int32_t value) {
       if (value < 0 || value > 2) { ofx_set_error("ofx_set_option: OFX_OPT_TRUNK_FUSE takes 0 (auto), 1 (always), 2 (never)"); return OFX_ERR_INVALID; }
       h->opt_trunk_fuse = value; return OFX_OK;
     case OFX_OPT_FRAMES_REF: h->opt_frames_ref = value != 0; return OFX_OK;
+    case OFX_OPT_TRUNK_SPARSE:
+      if (value && !h->trunk_stat) {
+        OFX_HIP(hipSetDevice(h->cfg.device));
+        OFX_HIP(hipMalloc((void **)&h->trunk_stat, 4 * sizeof(unsigned long long)));
+        OFX_HIP(hipMemsetAsync(h->trunk_stat, 0, 4 * sizeof(unsigned long long), h->stream));
+      }
+      h->opt_trunk_sparse = value != 0; return OFX_OK;
     case OFX_OPT_FIT_PLAIN: h->opt_fit_plain = value != 0; return OFX_OK;
     case OFX_OPT_POLICY_BF16:
       if (value < 0 || value > 2) { ofx_set_error("ofx_set_option: OFX_OPT_POLICY_BF16 takes 0 (fp32), 1 (bf16 operands), 2 (fp16 operands)"); return OFX_ERR_INVALID; }
@@ -1510,7 +1666,10 @@ static int policy_forward_impl(ofx_handle *h, const float *weights, int N, int M
     const dim3 g12((unsigned)(N < h->n_cus ? N : h->n_cus));
     if (lowp == 1) hipLaunchKernelGGL(k_trunk12<1>, g12, dim3(F12_THREADS), 0, h->stream, cp, (const float *)(prep + L.lut1));
     else if (lowp == 2) hipLaunchKernelGGL(k_trunk12<2>, g12, dim3(F12_THREADS), 0, h->stream, cp, (const float *)(prep + L.lut1));
-    else hipLaunchKernelGGL(k_trunk12<0>, g12, dim3(F12_THREADS), 0, h->stream, cp, (const float *)(prep + L.lut1));
+    else if (h->opt_trunk_sparse) {
+      cp.stat = h->trunk_stat;
+      hipLaunchKernelGGL((k_trunk12<0, true>), g12, dim3(F12_THREADS), 0, h->stream, cp, (const float *)(prep + L.lut1));
+    } else hipLaunchKernelGGL(k_trunk12<0>, g12, dim3(F12_THREADS), 0, h->stream, cp, (const float *)(prep + L.lut1));
     OFX_HIP(hipGetLastError());
   } else {
     cp.H = 400; cp.W = 400;

@@ -347,6 +347,12 @@ class ArenaBatch:
         """Diagnostic switches of the forward: nat.OPT_TRUNK_PLAIN, nat.OPT_FRAMES_REF (reference variants)."""
         nat.check(nat.lib().ofx_set_option(self._h, int(option), int(value)))
 
+    def policy_trunk_stats(self):
+        """OPT_TRUNK_SPARSE: (M-tiles run, M-tiles, table passes run, table passes) since the last call."""
+        v = (C.c_int64 * 4)()
+        nat.check(nat.lib().ofx_policy_trunk_stats(self._h, v))
+        return tuple(int(x) for x in v)
+
     def policy_actions(self, out_ptr=None, iaction_ptr=None, ipointer_ptr=None, ship_mask_ptr=None):
         """QlearnIA.play packing of the last forward into [N][M] ofx_action."""
         out_ptr = out_ptr or self._actions.ptr

@@ -159,6 +159,57 @@ def test_trunk_fused_matches_split():
     b.close()
 
 
+def test_trunk_sparse_is_bit_identical():
+    """OFX_OPT_TRUNK_SPARSE (opt-in, exact): the streaming trunk writes conv1's constant for waves of empty bit windows and
+    stores conv2's constant for M-tiles whose whole window holds it - the dense kernel's own bits, so every output of the
+    forward is EQUAL (==), on a mid-episode rollout (300 arenas: the persistent loop), on fresh spawns (no lasers), with
+    ships pushed against every border and corner, on a brawl packed into one corner, and for 1 / 2 / 5 images; the heat map
+    too.  The counters show that work was actually skipped."""
+    from ofighters_amd import ArenaBatch, _native as nat
+    from oracle import pyoracle
+    w, _ = pyoracle.policy_init(7, trained_like=True)
+
+    def both(b, want_heat=False):
+        b.set_option(nat.OPT_TRUNK_FUSE, 1)
+        b.set_option(nat.OPT_TRUNK_SPARSE, 0)
+        dense = b.policy_forward_host(w, want_heat=want_heat)
+        b.set_option(nat.OPT_TRUNK_SPARSE, 1)
+        b.policy_trunk_stats()
+        sparse = b.policy_forward_host(w, want_heat=want_heat)
+        st = b.policy_trunk_stats()
+        b.set_option(nat.OPT_TRUNK_SPARSE, 0)
+        for k in dense:
+            assert np.array_equal(sparse[k], dense[k]), k
+        return st
+
+    N, M = 300, 2
+    b = _rollout(N, M, seed=19, ticks=25)
+    run, total, trun, ttotal = both(b)
+    assert total == N * 20 * 63 and 0 < run < 0.7 * total, (run, total)          # 63 M-tiles per step, 20 steps per image
+    assert ttotal > 0 and 0 < trun < 0.8 * ttotal, (trun, ttotal)
+    # ships on the borders and in the corners of the map (x, y in {0, 1, 199 .. 400}), lasers flying
+    rs = np.random.RandomState(5)
+    edge = np.array([0, 1, 2, 7, 8, 199, 200, 391, 392, 398, 399, 400])
+    b.set_ships(x=rs.choice(edge, (N, M)), y=rs.choice(edge, (N, M)))
+    both(b)
+    b.close()
+    fresh = ArenaBatch(64, 8)
+    fresh.spawn_random(3)                                                        # tick 0: ships only
+    run, total, _, _ = both(fresh)
+    assert run < 0.5 * total
+    # a brawl in one corner: everything non-constant there, nothing elsewhere
+    fresh.set_ships(x=rs.randint(0, 40, (64, 8)), y=rs.randint(360, 401, (64, 8)))
+    for t in range(12):
+        fresh.bot_actions(["turret"] * 8, 5, tick=t)
+        fresh.step(actions_ptr=fresh._actions.ptr)
+    both(fresh)
+    fresh.close()
+    for n_small in (1, 2, 5):
+        bs = _rollout(n_small, M, seed=23 + n_small, ticks=30)
+        both(bs, want_heat=True)
+        bs.close()
+
+
 def test_legacy_bilinear_option():
     """OFX_OPT_BILINEAR_LEGACY: the TF1 resize_bilinear convention of UpSampling2D (src = dst / 2) - the second
     meaning the reference's unpinned keras range admits (qlearnIA_V2.py:166-184).  Against the restatement with the
