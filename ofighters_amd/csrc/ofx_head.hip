@@ -468,12 +468,17 @@ __global__ __launch_bounds__(HG_THREADS) void k_head_frames(HeadParams2 p) {
   __syncthreads();
   // the tap planes along the four lines: V_t = sum_c w4[t][c] uprelu3_c (what k_head_stream's ring holds; the same
   // sequential sum over c as the 1x1's MFMA chain)
-  for (int e = tid; e < 4 * 200 * 9; e += HG_THREADS) {
-    const int tp = e % 9, cell = e / 9;
-    float acc = 0.f;
+  for (int cell = tid; cell < 4 * 200; cell += HG_THREADS) {   // a thread owns a cell: 8 channels in, 9 taps out (weights: scalar loads)
+    const f32x4 ua = *reinterpret_cast<const f32x4 *>(u3l + cell * 8), ub = *reinterpret_cast<const f32x4 *>(u3l + cell * 8 + 4);
+    const float u[8] = {ua[0], ua[1], ua[2], ua[3], ub[0], ub[1], ub[2], ub[3]};
+    float *dst = p.vfr + (size_t)s * 7200 + cell * 9;
 #pragma unroll
-    for (int ci = 0; ci < 8; ci++) acc = fmaf(p.w4raw[tp * 8 + ci], u3l[cell * 8 + ci], acc);
-    p.vfr[(size_t)s * 7200 + e] = acc;
+    for (int tp = 0; tp < 9; tp++) {
+      float acc = 0.f;
+#pragma unroll
+      for (int ci = 0; ci < 8; ci++) acc = fmaf(p.w4raw[tp * 8 + ci], u[ci], acc);
+      dst[tp] = acc;
+    }
   }
 
   // ---- corrections of the heat-map frame pixels (PrepLayout::efr: the conv taps of the row / column outside the
