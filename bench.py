@@ -186,7 +186,7 @@ def train_tick(N, M, device, base, w_host, fence):
     b = ArenaBatch(N, M, device=device, arena_base=base)
     eps = Epsilon_decay()
     eps.set(0.1)
-    tr = DeviceTrainer(b, w_host, epsilon=eps, batch_size=8, memory_size=64, frames=96, fit_batch=64)
+    tr = DeviceTrainer(b, w_host, epsilon=eps, batch_size=8, memory_size=64, frames=96, fit_batch=256)
     roll = TrainingRollout(b, tr, ["random"] * M, SEED, policy_ships=(0,), episode_ticks=b.cfg.episode_ticks)
     warm, steps = 30, 120
     roll.run(warm)
@@ -217,7 +217,7 @@ def train_tick(N, M, device, base, w_host, fence):
         big_ms = "failed: %s" % e
     rec = {"workload": "%d arenas x %d ships per GPU, TRAINING tick: one policy ship per arena (forward + epsilon-greedy + "
                        "transition capture) + step + obs + DeviceTrainer.replay on the reference's schedule "
-                       "(every 50 steps and on lock-steps with a first-seen death), fit_batch 64" % (N, M),
+                       "(every 50 steps or on lock-steps with a first-seen death: at most one per lock-step), fit_batch 256" % (N, M),
            "value": N * steps / dt, "unit": "arena-steps/s", "steps": steps, "warmup": warm,
            "ms_per_step": dt / steps * 1e3, "replays_in_timed_region": n_rep, "ms_per_replay": rep_ms,
            "last_losses": [float(x) for x in roll.losses[-3:]],
@@ -627,6 +627,17 @@ def main():
                     r["accuracy_vs_float64"] = ({k: acc[k] for k in ("fp32", tag, "ships", "argmax_%s_equal_fp32" % tag)}
                                                 if "error" not in acc else acc)
                 extra.append(r)
+        # both opt-ins together on the reference's own line-up: the line that passes north_star's 1 M arena-steps/s
+        try:
+            r = measure("step+obs+policy", 1, False, 30, 150, False, bf16=1, sparse=True)
+            r["dtype"] = "bf16 operands / fp32 accumulation (OFX_OPT_POLICY_BF16 = 1) + the exact sparse trunk (OFX_OPT_TRUNK_SPARSE = 1)"
+            r["north_star_target_arena_steps_per_s"] = 1.0e6
+            r["frac_of_north_star_target"] = r["value"] / 1.0e6
+            r["roofline"] = None
+            r["note"] = "both opt-ins, one policy ship per arena: no parity or roofline credit (16-bit operands)"
+            extra.append(r)
+        except Exception as e:
+            extra.append({"workload": "bf16 + sparse trunk", "error": repr(e)})
         try:
             extra.append(train_tick(N, M, local_rank, base, w_host, fence))
         except Exception as e:
@@ -654,6 +665,7 @@ def main():
             "sparse_trunk_8ships": brief(extra[4], "frac_of_fp32_bound"), "sparse_trunk_1ship": brief(extra[5], "frac_of_fp32_bound"),
             "sparse_trunk_conv2_mtiles_executed_frac": (extra[4].get("trunk_sparse") or {}).get("conv2_mtiles_executed_frac"),
             "bf16_8ships": brief(extra[6], "frac_of_north_star_target"), "bf16_1ship": brief(extra[7], "frac_of_north_star_target"),
+            "bf16_sparse_trunk_1ship": brief(extra[10], "frac_of_north_star_target"),
             "train_tick_ms": tt.get("ms_per_step"), "fit4096_ms": tt.get("ms_per_replay_fit_batch_4096"),
             "scratch_feed_obs": brief(extra[-1]),
             "note": "secondary lines, never `value`; full records in extra_configs; sparse_trunk = opt-in exact OFX_OPT_TRUNK_SPARSE; "

@@ -331,8 +331,9 @@ int ofx_policy_pin_weights(ofx_handle *h, const float *weights);
  * and most of conv2's 16-pixel M-tiles multiply that constant.  value 1: a wave of pixel pairs whose bit windows are all
  * empty writes that value instead of looking its table rows up, and an M-tile whose whole input window holds it (and
  * touches no zero padding) stores the constant the dense matrix sequence produces for it instead of running the
- * sequence.  The results are BIT-IDENTICAL to the dense form (tests/test_gpu_policy.py); fp32 forward only (ignored with
- * OFX_OPT_POLICY_BF16).  bench.py reports it as a labelled secondary line; the headline stays on the dense trunk.
+ * sequence.  The results are BIT-IDENTICAL to the dense form (tests/test_gpu_policy.py), also under OFX_OPT_POLICY_BF16
+ * (the constant then comes from the 16-bit sequence).  The forwards on stored observations (ofx_policy_forward_obs, the DQN
+ * targets) always run this form.  bench.py reports it as a labelled secondary line; the headline stays on the dense trunk.
  * ofx_policy_trunk_stats: since the last call, M-tiles run / all and table passes run / all [4] (resets; synchronises). */
 #define OFX_OPT_TRUNK_SPARSE 7
 int ofx_policy_trunk_stats(ofx_handle *h, int64_t *counts_host);

@@ -854,12 +854,51 @@ __device__ __forceinline__ void ts_gemm_phase(const float *abase, const float (&
 // <-> column x of that row is NOT known to be constant (phase A).  An M-tile that crosses from one row pair into the
 // next contains columns 199 and 0, i.e. touches the padding: only tiles inside one row pair with 1 <= x, x + 15 <= 198
 // can be constant.  top / bottom: tile row 0 / the last tile row is a padding row of the image.
-template <int WD, int RP, int LS, int PLS>
-__device__ __forceinline__ void ts_gemm_phase_sparse(const float *abase, const float (&bw)[24], const f32x4 binit, int wv, int lane,
+// LP != 0: the same with the 16-bit operand sequence of ts_gemm_phase_bf16 (K2 then comes from THAT sequence).
+template <int WD, int RP, int LS, int PLS, int LP>
+__device__ __forceinline__ void ts_gemm_phase_sparse(const float *abase, const float (&bw)[LP ? 1 : 24], const lp_x4 (&bwb)[6],
+                                                     const f32x4 binit, int wv, int lane,
                                                      int n16, int kq, int r, float *orow, const unsigned *nz, float k2,
                                                      bool top, bool bottom, unsigned &n_exec, unsigned &n_all) {
   constexpr int NK = 24, NPX = RP * WD, NT = (NPX + 15) / 16;
   auto aof = [&](int j) -> int { return (4 * (j & 1)) * PLS + ((j >> 1) / 3) * LS + ((j >> 1) % 3); };
+  int toff[6];  // LP: abase carries the fp32 form's + kq * PLS: taken out again (ts_gemm_phase_bf16)
+#pragma unroll
+  for (int J = 0; J < 6; J++) {
+    const int tap = 2 * J + (kq >> 1);
+    toff[J] = (4 * (kq & 1) - kq) * PLS + (tap / 3) * LS + tap % 3;
+  }
+  // the M-tile's matrix sequence: one or two accumulator chains
+  auto mm1 = [&](const float *a0, f32x4 &d0) {
+    if constexpr (LP != 0) {
+#pragma unroll
+      for (int J = 0; J < 6; J++) {
+        const float *q0 = a0 + toff[J];
+        d0 = lp_mfma16<LP ? LP : 1>(lp_pk4<LP ? LP : 1>(q0[0], q0[PLS], q0[2 * PLS], q0[3 * PLS]), bwb[J], d0);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NK; j++) d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[aof(j)], bw[LP ? 0 : j], d0, 0, 0, 0);
+    }
+  };
+  auto mm2 = [&](const float *a0, const float *a1, f32x4 &d0, f32x4 &d1) {
+    if constexpr (LP != 0) {
+#pragma unroll
+      for (int J = 0; J < 6; J++) {
+        const float *q0 = a0 + toff[J], *q1 = a1 + toff[J];
+        const lp_x4 A0 = lp_pk4<LP ? LP : 1>(q0[0], q0[PLS], q0[2 * PLS], q0[3 * PLS]);
+        const lp_x4 A1 = lp_pk4<LP ? LP : 1>(q1[0], q1[PLS], q1[2 * PLS], q1[3 * PLS]);
+        d0 = lp_mfma16<LP ? LP : 1>(A0, bwb[J], d0);
+        d1 = lp_mfma16<LP ? LP : 1>(A1, bwb[J], d1);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NK; j++) {
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[aof(j)], bw[LP ? 0 : j], d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[aof(j)], bw[LP ? 0 : j], d1, 0, 0, 0);
+      }
+    }
+  };
   auto finish = [&](const f32x4 d, int T) {
     float q0, q1;
     q0 = max_raw(max_raw(d[0], 0.f), d[1]);
@@ -890,10 +929,8 @@ __device__ __forceinline__ void ts_gemm_phase_sparse(const float *abase, const f
     if (r == 0) *reinterpret_cast<float2 *>(orow + rp * (WD / 2) + (x >> 1)) = make_float2(k2, k2);
   };
   auto run1 = [&](int T0) {
-    const float *a0 = a_of_tile(T0);
     f32x4 d0 = binit;
-#pragma unroll
-    for (int j = 0; j < NK; j++) d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[aof(j)], bw[j], d0, 0, 0, 0);
+    mm1(a_of_tile(T0), d0);
     finish(d0, T0);
   };
   // the wave's M-tiles two at a time (two accumulator chains when both have to run)
@@ -905,13 +942,8 @@ __device__ __forceinline__ void ts_gemm_phase_sparse(const float *abase, const f
     n_all += two ? 2u : 1u;
     n_exec += (g0 ? 1u : 0u) + (g1 ? 1u : 0u);
     if (g0 && g1) {
-      const float *a0 = a_of_tile(T), *a1 = a_of_tile(T1);
       f32x4 d0 = binit, d1 = binit;
-#pragma unroll
-      for (int j = 0; j < NK; j++) {
-        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[aof(j)], bw[j], d0, 0, 0, 0);
-        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[aof(j)], bw[j], d1, 0, 0, 0);
-      }
+      mm2(a_of_tile(T), a_of_tile(T1), d0, d1);
       finish(d0, T);
       finish(d1, T1);
     } else {
@@ -1004,7 +1036,6 @@ static_assert((F12_TH + 1) * 100 <= 2 * F12_THREADS && F12_TH * 100 <= F12_THREA
 template <int LP, bool SPARSE = false>
 __global__ __launch_bounds__(F12_THREADS) void k_trunk12(ConvParams p, const float *lut) {
   constexpr bool BF16 = LP != 0;
-  static_assert(!(BF16 && SPARSE), "the sparse form is the fp32 kernel's");
   constexpr int W = PS, H = PS, H1 = PS / 2, H2 = PS / 4, LS = F12_LS, PLS = F12_PLS, NK = 24;
   __shared__ __align__(16) float slut[2 * 512 * 8];
   __shared__ __align__(16) float tile[8 * F12_PLS];
@@ -1073,11 +1104,20 @@ __global__ __launch_bounds__(F12_THREADS) void k_trunk12(ConvParams p, const flo
     for (int e = tid; e < 8 * PLS; e += F12_THREADS) tile[e] = k1s[min(e / PLS, 7)];
     __syncthreads();
     if (wv == 0) {
-      auto aof = [&](int j) -> int { return (4 * (j & 1)) * PLS + ((j >> 1) / 3) * LS + ((j >> 1) % 3); };
       const float *a0 = abase + 2 * LS + 16 + n16;                 // any interior M-tile: row pair 1, columns 16 .. 31
       f32x4 d0 = binit;
+      if constexpr (BF16) {
 #pragma unroll
-      for (int j = 0; j < NK; j++) d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[aof(j)], bw[j], d0, 0, 0, 0);
+        for (int J = 0; J < 6; J++) {
+          const int tap = 2 * J + (kq >> 1);
+          const float *q0 = a0 + (4 * (kq & 1) - kq) * PLS + (tap / 3) * LS + tap % 3;
+          d0 = lp_mfma16<LP ? LP : 1>(lp_pk4<LP ? LP : 1>(q0[0], q0[PLS], q0[2 * PLS], q0[3 * PLS]), bwb[J], d0);
+        }
+      } else {
+        auto aof = [&](int j) -> int { return (4 * (j & 1)) * PLS + ((j >> 1) / 3) * LS + ((j >> 1) % 3); };
+#pragma unroll
+        for (int j = 0; j < NK; j++) d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[aof(j)], bw[BF16 ? 0 : j], d0, 0, 0, 0);
+      }
       float q0 = max_raw(max_raw(d0[0], 0.f), d0[1]);
       q0 = max_raw(q0, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, q0), 0xB1, 0xF, 0xF, true)));
       if (r == 0 && kq == 0) k2s[co] = q0;
@@ -1182,16 +1222,16 @@ __global__ __launch_bounds__(F12_THREADS) void k_trunk12(ConvParams p, const flo
     unsigned nextw = 0u;
     if (more) nextw = bits_fetch(nimg, na, nb);
 
-    if constexpr (BF16)
-      ts_gemm_phase_bf16<200, F12_TH / 2, F12_LS, F12_PLS, LP ? LP : 1>(abase, bwb, binit, wv, n16, kq, r,
-                                                            p.out + (((size_t)img * 8 + co) * H2 + (R0 >> 1)) * H2);
-    else if constexpr (SPARSE) {
-      ts_gemm_phase_sparse<200, F12_TH / 2, F12_LS, F12_PLS>(abase, bw, binit, wv, lane, n16, kq, r,
-                                                              p.out + (((size_t)img * 8 + co) * H2 + (R0 >> 1)) * H2,
-                                                              &nz[buf][0][0], k2, step == 0, last, n_exec, n_all);
+    if constexpr (SPARSE) {
+      ts_gemm_phase_sparse<200, F12_TH / 2, F12_LS, F12_PLS, LP>(abase, bw, bwb, binit, wv, lane, n16, kq, r,
+                                                                  p.out + (((size_t)img * 8 + co) * H2 + (R0 >> 1)) * H2,
+                                                                  &nz[buf][0][0], k2, step == 0, last, n_exec, n_all);
       // the other buffer's marks are last step's: cleared for the next step (its first two rows are copied in there)
       for (int e = tid; e < F12_ROWS * 8; e += F12_THREADS) (&nz[buf ^ 1][0][0])[e] = 0u;
-    } else
+    } else if constexpr (BF16)
+      ts_gemm_phase_bf16<200, F12_TH / 2, F12_LS, F12_PLS, LP ? LP : 1>(abase, bwb, binit, wv, n16, kq, r,
+                                                            p.out + (((size_t)img * 8 + co) * H2 + (R0 >> 1)) * H2);
+    else
       ts_gemm_phase<200, F12_TH / 2, F12_LS, F12_PLS>(abase, bw, binit, wv, n16, kq, r,
                                                        p.out + (((size_t)img * 8 + co) * H2 + (R0 >> 1)) * H2);
     if (more) bits_commit(buf ^ 1, na, nb, nextw);  // the other buffer: phase A of this step is behind every wave
@@ -1664,12 +1704,13 @@ static int policy_forward_impl(ofx_handle *h, const float *weights, int N, int M
   else if (fused12) {
     cp.out = ws.p2; cp.b = prep + L.tb[1]; cp.wbm = prep + L.wbm[0]; cp.images = N;
     const dim3 g12((unsigned)(N < h->n_cus ? N : h->n_cus));
-    if (lowp == 1) hipLaunchKernelGGL(k_trunk12<1>, g12, dim3(F12_THREADS), 0, h->stream, cp, (const float *)(prep + L.lut1));
-    else if (lowp == 2) hipLaunchKernelGGL(k_trunk12<2>, g12, dim3(F12_THREADS), 0, h->stream, cp, (const float *)(prep + L.lut1));
-    else if (h->opt_trunk_sparse) {
-      cp.stat = h->trunk_stat;
-      hipLaunchKernelGGL((k_trunk12<0, true>), g12, dim3(F12_THREADS), 0, h->stream, cp, (const float *)(prep + L.lut1));
-    } else hipLaunchKernelGGL(k_trunk12<0>, g12, dim3(F12_THREADS), 0, h->stream, cp, (const float *)(prep + L.lut1));
+    const bool sparse = h->opt_trunk_sparse || vec8 != nullptr;   // exact either way: the forwards on stored observations (DQN targets) always take it
+    cp.stat = h->opt_trunk_sparse ? h->trunk_stat : nullptr;
+    const float *lut1 = prep + L.lut1;
+#define T12(LP_) do { if (sparse) hipLaunchKernelGGL((k_trunk12<LP_, true>), g12, dim3(F12_THREADS), 0, h->stream, cp, lut1); \
+                      else hipLaunchKernelGGL((k_trunk12<LP_, false>), g12, dim3(F12_THREADS), 0, h->stream, cp, lut1); } while (0)
+    if (lowp == 1) T12(1); else if (lowp == 2) T12(2); else T12(0);
+#undef T12
     OFX_HIP(hipGetLastError());
   } else {
     cp.H = 400; cp.W = 400;

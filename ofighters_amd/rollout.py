@@ -120,8 +120,8 @@ class TrainingRollout(ShardedRollout):
           and on the lock-steps where a learning agent first sees its death    :376-378
         a snapshot every `snapshot_every` episodes                             :416-417
 
-    The reference calls replay once per dying agent; the batched form does ONE replay on a lock-step with deaths (its
-    minibatch already draws from every arena's memory).  After a fit the trainer's blob has changed in place and
+    The reference calls replay once per dying agent; the batched form does at most ONE replay per lock-step (its
+    minibatch already draws from every arena's memory), on `DeviceTrainer.fit_batch` rows of what it sampled.  After a fit the trainer's blob has changed in place and
     libofx re-prepares the pinned copy itself (ofx_dqn_fit -> ofx_policy_weights_updated), so the next forward plays
     with the new weights like Keras' shared model does.
 
@@ -181,10 +181,12 @@ class TrainingRollout(ShardedRollout):
         self.total_steps += 1                      # Agent.step increments before bot_play (agent.py:67-68)
         t, m = self.trainer, self._mask.ptr
         collecting = self.total_steps < self.collecting_steps
+        replayed = False
         if self.is_learning and self.replay_on_death:
             # obs.done seen for the first time this lock-step (:375-378): counted on the device, one int comes back
             if e.agents_first_done(m, self._seen_done) > 0:
                 self._replay()
+                replayed = True
         e.policy_forward(t.weights.ptr, m)
         e.policy_explore(t.epsilon.get(), self.seed, tick=self.capture_tick, collecting=collecting, ship_mask_ptr=m)
         e.replay_capture(self.capture_tick, ship_mask_ptr=m)
@@ -192,5 +194,7 @@ class TrainingRollout(ShardedRollout):
         self.capture_tick += 1
         if not collecting and self.is_learning:
             t.decay_epsilon()
-        if self.is_learning and self.replay_every and self.total_steps % self.replay_every == 0:
+        # at most ONE replay per lock-step: the batched replay already draws from every arena's memory, a second one on
+        # the same lock-step (deaths AND total_steps % 50 == 0) would fit the same memories twice
+        if self.is_learning and self.replay_every and self.total_steps % self.replay_every == 0 and not replayed:
             self._replay()

@@ -208,6 +208,12 @@ def test_trunk_sparse_is_bit_identical():
         bs = _rollout(n_small, M, seed=23 + n_small, ticks=30)
         both(bs, want_heat=True)
         bs.close()
+    # with 16-bit operands the constant is the 16-bit sequence's own: still equal to that mode's dense form
+    lp = _rollout(40, M, seed=31, ticks=30)
+    for mode in (1, 2):
+        lp.set_option(nat.OPT_POLICY_BF16, mode)
+        both(lp)
+    lp.close()
 
 
 def test_legacy_bilinear_option():
