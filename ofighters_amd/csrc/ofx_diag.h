@@ -14,3 +14,10 @@
 #ifndef OFX_FIT_ABLATE
 #define OFX_FIT_ABLATE 0
 #endif
+
+// k_trunk12<., true> (ofx_policy.hip): ofx_policy_trunk_stats returns s_memtime sums of wave 0 of every workgroup instead of
+// the counts, summed over the workgroups: cycles in phase A (incl. its barrier) / in the rest of the step / of that in the
+// classification + constant stores / in the run tiles.
+#ifndef OFX_TRUNK_STAMPS
+#define OFX_TRUNK_STAMPS 0
+#endif

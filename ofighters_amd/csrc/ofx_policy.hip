@@ -26,6 +26,7 @@
 
 #include "ofx_internal.h"
 #include "ofx_head.h"
+#include "ofx_diag.h"
 #include "ofx_lowp.h"
 
 #define PS 400 /* the model's fixed input side: Input((DEFAULT_WIDTH, DEFAULT_HEIGHT, 2)) */
@@ -859,7 +860,14 @@ template <int WD, int RP, int LS, int PLS, int LP>
 __device__ __forceinline__ void ts_gemm_phase_sparse(const float *abase, const float (&bw)[LP ? 1 : 24], const lp_x4 (&bwb)[6],
                                                      const f32x4 binit, int wv, int lane,
                                                      int n16, int kq, int r, float *orow, const unsigned *nz, float k2,
-                                                     bool top, bool bottom, unsigned &n_exec, unsigned &n_all) {
+                                                     bool top, bool bottom, unsigned &n_exec, unsigned &n_all,
+                                                     unsigned long long *dbg = nullptr) {
+#if OFX_TRUNK_STAMPS
+  unsigned long long g_last = __builtin_amdgcn_s_memtime();
+#define TSG_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); dbg[i] += t_ - g_last; g_last = t_; } while (0)
+#else
+#define TSG_STAMP(i) do { } while (0)
+#endif
   constexpr int NK = 24, NPX = RP * WD, NT = (NPX + 15) / 16;
   auto aof = [&](int j) -> int { return (4 * (j & 1)) * PLS + ((j >> 1) / 3) * LS + ((j >> 1) % 3); };
   int toff[6];  // LP: abase carries the fp32 form's + kq * PLS: taken out again (ts_gemm_phase_bf16)
@@ -914,16 +922,27 @@ __device__ __forceinline__ void ts_gemm_phase_sparse(const float *abase, const f
     const int rp = P / WD, x = P - rp * WD;
     return abase + 2 * rp * LS + x;
   };
-  // wave-uniform: does tile T have to run?  Lanes 0-7 look at (tile row 2 rp + (lane >> 1), word (x >> 5) + (lane & 1))
-  auto must_run = [&](int T) -> bool {
-    const int P = 16 * T, rp = P / WD, x = P - rp * WD;
-    if (x < 1 || x + 15 > WD - 2 || P + 15 >= NPX) return true;          // image columns 0 / WD - 1, or the ragged last tile
-    if ((top && rp == 0) || (bottom && rp == RP - 1)) return true;       // a padding row above / below
-    const int row = 2 * rp + ((lane >> 1) & 3), w0 = (x - 1) >> 5, lo = (x - 1) & 31;  // window = bits x - 1 .. x + 16 of the row
-    const unsigned m = (lane & 1) ? (lo + 18 > 32 ? (1u << (lo + 18 - 32)) - 1u : 0u) : (0x3FFFFu << lo);
-    const unsigned v = lane < 8 ? (nz[row * 8 + w0 + (lane & 1)] & m) : 0u;
-    return __builtin_amdgcn_ballot_w64(v != 0u) != 0;
-  };
+  // Every wave classifies ALL the step's M-tiles by itself, lane T tile T: no list to build, no barrier.  Bit T of the
+  // mask: tile T has to run.  (A first version let a wave test its own four tiles one after the other with eight lanes each
+  // and appended to a shared list behind a barrier: 4 500 cycles per step for the classification alone, stamps.)
+  unsigned long long run_mask;
+  {
+    const int T = lane, P = 16 * T, rp = P / WD, x = P - rp * WD;
+    bool run = T < NT;
+    if (run && !(x < 1 || x + 15 > WD - 2 || P + 15 >= NPX || (top && rp == 0) || (bottom && rp == RP - 1))) {
+      // window = bits x - 1 .. x + 16 of tile rows 2 rp .. 2 rp + 3: two words per row
+      const int w0 = (x - 1) >> 5, lo = (x - 1) & 31;
+      const unsigned m0 = 0x3FFFFu << lo, m1 = lo + 18 > 32 ? (1u << (lo + 18 - 32)) - 1u : 0u;
+      unsigned any = 0u;
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++) {
+        const unsigned *rw = nz + (2 * rp + rr) * 8 + w0;
+        any |= (rw[0] & m0) | (rw[1] & m1);
+      }
+      run = any != 0u;
+    }
+    run_mask = __builtin_amdgcn_ballot_w64(run);
+  }
   auto store_const = [&](int T) {                                          // the constant tile: the dense result, stored
     const int P = 16 * T + 4 * kq, rp = P / WD, x = P - rp * WD;
     if (r == 0) *reinterpret_cast<float2 *>(orow + rp * (WD / 2) + (x >> 1)) = make_float2(k2, k2);
@@ -933,24 +952,31 @@ __device__ __forceinline__ void ts_gemm_phase_sparse(const float *abase, const f
     mm1(a_of_tile(T0), d0);
     finish(d0, T0);
   };
-  // the wave's M-tiles two at a time (two accumulator chains when both have to run)
+  // the wave's own four tiles: the constant ones are stored; then the RUN tiles are dealt out over all 16 waves - wave w
+  // takes the w-th, (w + 16)-th, ... set bit of the mask (a tile's result does not depend on who computes it)
 #pragma unroll 1
-  for (int T = wv; T < NT; T += 32) {
-    const int T1 = T + 16;
-    const bool two = T1 < NT;                                              // wave-uniform
-    const bool g0 = must_run(T), g1 = two && must_run(T1);
-    n_all += two ? 2u : 1u;
-    n_exec += (g0 ? 1u : 0u) + (g1 ? 1u : 0u);
-    if (g0 && g1) {
+  for (int T = wv; T < NT; T += 16)
+    if (!((run_mask >> T) & 1ull)) store_const(T);
+  if (wv == 0) { n_all += (unsigned)NT; n_exec += (unsigned)__builtin_popcountll(run_mask); }
+  TSG_STAMP(0);
+  unsigned long long m = run_mask;
+  for (int i = 0; i < wv && m; i++) m &= m - 1;                             // skip the bits of the waves in front
+#pragma unroll 1
+  while (m) {
+    const int T0 = __builtin_ctzll(m);
+    unsigned long long m2 = m;
+    for (int i = 0; i < 16 && m2; i++) m2 &= m2 - 1;                        // 16 set bits further on: this wave's next tile
+    if (m2) {                                                               // two accumulator chains
+      const int T1 = __builtin_ctzll(m2);
       f32x4 d0 = binit, d1 = binit;
-      mm2(a_of_tile(T), a_of_tile(T1), d0, d1);
-      finish(d0, T);
+      mm2(a_of_tile(T0), a_of_tile(T1), d0, d1);
+      finish(d0, T0);
       finish(d1, T1);
-    } else {
-      if (g0) run1(T); else store_const(T);
-      if (two) { if (g1) run1(T1); else store_const(T1); }
-    }
+      for (int i = 0; i < 16 && m2; i++) m2 &= m2 - 1;
+    } else run1(T0);
+    m = m2;
   }
+  TSG_STAMP(2);
 }
 
 // OFX_OPT_POLICY_BF16 (opt-in): the same banded GEMM on v_mfma_f32_16x16x16_bf16 - K = 96 as 6 MFMAs of K = 16 instead
@@ -1043,7 +1069,18 @@ __global__ __launch_bounds__(F12_THREADS) void k_trunk12(ConvParams p, const flo
   __shared__ __align__(16) float halo[2][8][2][F12_LS];  // the last two p1 rows of a step = the first two of the next
   __shared__ unsigned nz[SPARSE ? 2 : 1][F12_ROWS][8];   // SPARSE: [buffer][tile row]: bit x <-> column x may differ from K1
   __shared__ __align__(16) float k1s[8], k2s[8];         // SPARSE: the constants of an empty neighbourhood
+  // SPARSE (fp32): the 24 B operands of a lane are re-read from here in every phase B instead of living in registers
+  // through phase A - with them the loop spilled, and every spill reload is an s_waitcnt vmcnt(0), i.e. a wait for the bit
+  // rows in flight and for the stores' acknowledgements (stamps: 3 400 of a step's 13 700 cycles in front of phase A's
+  // barrier, 5 000 behind the last M-tile)
+  __shared__ float wbs[(SPARSE && !BF16) ? 24 * 64 : 1];
   unsigned n_exec = 0, n_all = 0, t_exec = 0, t_all = 0; // SPARSE: the wave's counts (M-tiles run / all, table passes run / all)
+#if OFX_TRUNK_STAMPS
+  unsigned long long st_a = 0, st_b = 0, st_last = __builtin_amdgcn_s_memtime(), st_begin = st_last, st_g[3] = {0, 0, 0};
+#define T12_STAMP(acc) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - st_last; st_last = t_; } while (0)
+#else
+#define T12_STAMP(acc) do { } while (0)
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n16 = lane & 15, kq = lane >> 4, co = n16 >> 1, r = n16 & 1;
@@ -1084,10 +1121,12 @@ __global__ __launch_bounds__(F12_THREADS) void k_trunk12(ConvParams p, const flo
     reinterpret_cast<f32x4 *>(slut)[e] = reinterpret_cast<const f32x4 *>(lut)[e];
   for (int e = tid; e < 8 * PLS / 4; e += F12_THREADS) reinterpret_cast<f32x4 *>(tile)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int e = tid; e < 2 * 8 * 2 * LS / 4; e += F12_THREADS) reinterpret_cast<f32x4 *>(&halo[0][0][0][0])[e] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float bw[BF16 ? 1 : NK];
+  float bw[(BF16 || SPARSE) ? 1 : NK];
   lp_x4 bwb[6];
   if constexpr (BF16) ts_bw_lp<LP ? LP : 1>(p.wbm, n16, kq, bwb);
-  else {
+  else if constexpr (SPARSE) {
+    for (int e = tid; e < NK * 64; e += F12_THREADS) wbs[e] = p.wbm[e];
+  } else {
 #pragma unroll
     for (int j = 0; j < NK; j++) bw[j] = p.wbm[j * 64 + lane];   // per-lane B operand of k_convm (PrepLayout::wbm)
   }
@@ -1116,7 +1155,7 @@ __global__ __launch_bounds__(F12_THREADS) void k_trunk12(ConvParams p, const flo
       } else {
         auto aof = [&](int j) -> int { return (4 * (j & 1)) * PLS + ((j >> 1) / 3) * LS + ((j >> 1) % 3); };
 #pragma unroll
-        for (int j = 0; j < NK; j++) d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[aof(j)], bw[BF16 ? 0 : j], d0, 0, 0, 0);
+        for (int j = 0; j < NK; j++) d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[aof(j)], wbs[(BF16 ? 0 : j) * 64 + lane], d0, 0, 0, 0);
       }
       float q0 = max_raw(max_raw(d0[0], 0.f), d0[1]);
       q0 = max_raw(q0, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, q0), 0xB1, 0xF, 0xF, true)));
@@ -1126,6 +1165,8 @@ __global__ __launch_bounds__(F12_THREADS) void k_trunk12(ConvParams p, const flo
     for (int e = tid; e < 8 * PLS / 4; e += F12_THREADS) reinterpret_cast<f32x4 *>(tile)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   bits_commit(0, 0, F12_TH + 1, bits_fetch((int)blockIdx.x, 0, F12_TH + 1));
+  unsigned w_ahead = 0u;                                // SPARSE: the bit rows of the step after next, in flight
+  if constexpr (SPARSE) { if ((int)blockIdx.x < p.images) w_ahead = bits_fetch((int)blockIdx.x, F12_TH + 1, 2 * F12_TH + 1); }
   __syncthreads();
   const float k2 = SPARSE ? k2s[co] : 0.f;
 
@@ -1140,7 +1181,24 @@ __global__ __launch_bounds__(F12_THREADS) void k_trunk12(ConvParams p, const flo
     // the last one leaves row 200 zero
     const int pa = step ? R0 + 1 : 0, pb = min(R0 + F12_TH + 1, H1);
     const int buf = step & 1;
+    // the next step's bit rows (of the workgroup's next image behind the last step)
+    const bool last = step + 1 == H1 / F12_TH;
+    const int nimg = last ? img + (int)gridDim.x : img;
+    const bool more = nimg < p.images;
+    const int na = last ? 0 : R0 + F12_TH + 1, nb = last ? F12_TH + 1 : min(R0 + 2 * F12_TH + 1, H1);
+    unsigned nextw = 0u;
+    // SPARSE: the bit rows travel TWO steps ahead.  The dense GEMM phase hides the ~2 us of a fetch issued at its start;
+    // the sparse step is over before the word lands (stamps: 5 700 of a step's 12 600 cycles in front of bits_commit).
+    // Here the word fetched a whole step ago is committed (the next step's rows) and the step after that is requested.
+    if constexpr (SPARSE) {
+      if (more) bits_commit(buf ^ 1, na, nb, w_ahead);
+      int i2 = nimg, s2 = last ? 0 : step + 1;
+      if (++s2 == H1 / F12_TH) { s2 = 0; i2 += (int)gridDim.x; }
+      const int r2 = s2 * F12_TH;
+      w_ahead = i2 < p.images ? bits_fetch(i2, s2 ? r2 + 1 : 0, min(r2 + F12_TH + 1, H1)) : 0u;
+    }
 
+    T12_STAMP(st_b);
     // ---- phase A: conv1 table look-up + pool + ReLU, two adjacent p1 pixels per thread ----
     if (step && pb - pa < F12_TH)  // last step: p1 row 200 does not exist - the tile row behind the image is zero
       for (int e = tid; e < 8 * LS; e += F12_THREADS) tile[(e / LS) * PLS + (F12_TH + 1) * LS + e % LS] = 0.f;
@@ -1214,18 +1272,25 @@ __global__ __launch_bounds__(F12_THREADS) void k_trunk12(ConvParams p, const flo
     }
     __syncthreads();
 
+    T12_STAMP(st_a);
     // ---- phase B: conv2 on the tile; the next step's bit rows are fetched meanwhile ----
-    const bool last = step + 1 == H1 / F12_TH;
-    const int nimg = last ? img + (int)gridDim.x : img;
-    const bool more = nimg < p.images;
-    const int na = last ? 0 : R0 + F12_TH + 1, nb = last ? F12_TH + 1 : min(R0 + 2 * F12_TH + 1, H1);
-    unsigned nextw = 0u;
-    if (more) nextw = bits_fetch(nimg, na, nb);
+    if constexpr (!SPARSE) { if (more) nextw = bits_fetch(nimg, na, nb); }
 
     if constexpr (SPARSE) {
-      ts_gemm_phase_sparse<200, F12_TH / 2, F12_LS, F12_PLS, LP>(abase, bw, bwb, binit, wv, lane, n16, kq, r,
+      float bwl[BF16 ? 1 : NK];
+      if constexpr (!BF16) {
+        int zoff;                                   // an offset the compiler cannot see through: the reads stay in the loop
+        asm volatile("s_mov_b32 %0, 0" : "=s"(zoff));
+#pragma unroll
+        for (int j = 0; j < NK; j++) bwl[j] = wbs[j * 64 + lane + zoff];
+      }
+      ts_gemm_phase_sparse<200, F12_TH / 2, F12_LS, F12_PLS, LP>(abase, bwl, bwb, binit, wv, lane, n16, kq, r,
                                                                   p.out + (((size_t)img * 8 + co) * H2 + (R0 >> 1)) * H2,
-                                                                  &nz[buf][0][0], k2, step == 0, last, n_exec, n_all);
+                                                                  &nz[buf][0][0], k2, step == 0, last, n_exec, n_all
+#if OFX_TRUNK_STAMPS
+                                                                  , st_g
+#endif
+                                                                  );
       // the other buffer's marks are last step's: cleared for the next step (its first two rows are copied in there)
       for (int e = tid; e < F12_ROWS * 8; e += F12_THREADS) (&nz[buf ^ 1][0][0])[e] = 0u;
     } else if constexpr (BF16)
@@ -1234,14 +1299,22 @@ __global__ __launch_bounds__(F12_THREADS) void k_trunk12(ConvParams p, const flo
     else
       ts_gemm_phase<200, F12_TH / 2, F12_LS, F12_PLS>(abase, bw, binit, wv, n16, kq, r,
                                                        p.out + (((size_t)img * 8 + co) * H2 + (R0 >> 1)) * H2);
-    if (more) bits_commit(buf ^ 1, na, nb, nextw);  // the other buffer: phase A of this step is behind every wave
+    if constexpr (!SPARSE) { if (more) bits_commit(buf ^ 1, na, nb, nextw); }  // the other buffer: phase A of this step is behind every wave
     __syncthreads();
   }
   if constexpr (SPARSE) {
+#if OFX_TRUNK_STAMPS
+    T12_STAMP(st_b);
+    if (p.stat && tid == 0) {   // diagnostic: cycles of wave 0 in phase A (up to its barrier) / phase B / whole kernel / blocks
+      atomicAdd(&p.stat[0], st_a); atomicAdd(&p.stat[1], st_b);          // phase A (with its barrier) / the rest of the step
+      atomicAdd(&p.stat[2], st_g[0]); atomicAdd(&p.stat[3], st_g[2]);    // of that: classification + constant stores / the run tiles
+    }
+#else
     if (p.stat && lane == 0) {
       atomicAdd(&p.stat[0], (unsigned long long)n_exec); atomicAdd(&p.stat[1], (unsigned long long)n_all);
       atomicAdd(&p.stat[2], (unsigned long long)t_exec); atomicAdd(&p.stat[3], (unsigned long long)t_all);
     }
+#endif
   }
 }
 

@@ -13,6 +13,7 @@ ALLOWED = {
     r's_mov_b32 %0, 0x7f800000" : "=s"\(pinf\)': "scalar constant: no vector operand",
     r'v_max3_f32 %0, %1, %2, 0" : "=v"\(m\) : "v"\(acc\[0\]': "k_conv1_lut: operands are table sums (VALU adds), no MFMA in that kernel",
     r'v_max3_f32 %0, %1, %2, %3" : "=v"\(m\) : "v"\(acc\[2\]': "k_conv1_lut: as above",
+    r's_mov_b32 %0, 0" : "=s"\(zoff\)': "scalar zero the compiler cannot see through (keeps LDS reads inside a loop): no vector operand",
 }
 
 

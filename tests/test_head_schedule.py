@@ -32,6 +32,8 @@ def test_kernel_constants_match():
     assert const("HS_GPR") == m.GPR and const("HS_NTILES") == m.NTILES and const("HS_NS") == m.NS
     assert int(re.search(r"HS_NR3 = (\d+)", src).group(1)) == m.NR3
     assert int(re.search(r"HS_NR2 = (\d+)", src).group(1)) == m.NR2
+    assert "HS_TABP = 16 * HS_GPR" in src and m.TABP == 16 * m.GPR and "(T * 1261) >> 16" in src
+    assert const("HS_NV") == 9
     # the consumers' first row and the kernels' closed forms
     assert "int R = r_in - 8;" in src and m.C_ROW0 == -8
     assert "8 * (s + 1) + ((s + 1) >> 3)" in src

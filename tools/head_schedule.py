@@ -6,15 +6,17 @@ check().
 One workgroup streams a 100-column half of one ship's 200x200 uprelu3 plane top to bottom in NS sub-steps:
   * the B waves produce uprelu3 in 16-quad M-tiles, flat over (quad row, group of 4 quads), 13 groups per quad row:
     8 tiles per sub-step and a ninth in every eighth one (325 tiles in 40 sub-steps);
-  * the C waves consume 5 uprelu3 rows per sub-step, rows 5 s - 8 .. 5 s - 4 in sub-step s;
+  * the C waves consume 5 uprelu3 rows per sub-step, rows 5 s - 8 .. 5 s - 4 in sub-step s (r04: the ring holds the nine
+    tap planes of those rows instead of their eight channels - same rows, same lags);
   * stage A (uprelu2 row pairs from uprelu1) runs one sub-step ahead of the tiles that read them.
 """
 GPR = 13                    # groups of 4 quads per quad row (52 quad slots: 50 + halo + pad)
 QROWS = 100
 NTILES = QROWS * GPR // 4   # 325
 NS = 42                     # sub-steps
-NR3 = 16                    # uprelu3 ring rows
+NR3 = 16                    # ring rows of uprelu3 - since r04 of its nine tap planes V_t = sum_c w4[t][c] uprelu3_c
 NR2 = 16                    # uprelu2 ring rows
+TABP = 208                  # entries of the group table (r04)
 C_ROW0 = -8                 # first uprelu3 row of the C block of sub-step 0 (5 s + C_ROW0)
 
 
@@ -79,6 +81,20 @@ def check():
     # group index / 13 by multiply-shift, as the kernel does it
     for g in range(4 * NTILES + 4):
         assert (g * 5042) >> 16 == g // GPR, g
+    # r04: ONE group table of TABP = 16 quad rows x 13 groups entries - the (uprelu2 ring, tap-plane ring) offsets of a
+    # group depend on its quad row modulo 16 only - addressed by 4 (T mod 52) + lane group, T mod 52 by multiply-shift
+    assert TABP == 16 * GPR == 4 * 52
+    for t in range(NTILES):
+        assert t - 52 * ((t * 1261) >> 16) == t % 52, t
+        for lg in range(4):
+            g = 4 * t + lg
+            q, gg = divmod(g, GPR)
+            e = 4 * (t % 52) + lg
+            qe, gge = divmod(e, GPR)
+            assert gge == gg and (qe & 15) == (q & 15) and ((2 * qe) & (NR3 - 1)) == ((2 * q) & (NR3 - 1)), (t, lg)
+    # LDS of a workgroup: 9 tap planes + the uprelu2 ring + the table: two workgroups per CU (160 KB)
+    lds = 4 * (9 * (NR3 * 106 + 4) + 4 * (NR2 + 2) * 56 + TABP)
+    assert lds <= 80 * 1024, lds
     return ad, span3, span2
 
 
