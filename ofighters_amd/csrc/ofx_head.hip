@@ -585,82 +585,6 @@ constexpr int HS_NKT = 7;
 constexpr int HS_KT[HS_NKT][2] = {{0, 0}, {0, 1}, {1, 0}, {1, 1}, {1, 2}, {2, 1}, {2, 2}};
 __device__ __forceinline__ f32x2 hs_fma2(float c, f32x2 v, f32x2 z) { return __builtin_elementwise_fma((f32x2){c, c}, v, z); }
 
-// ---- stage A: one M-tile = 16 uprelu1 pixels of row pair `pr` -> 2 x 32 cells x 4 channels of uprelu2 ----
-// A[pixel][k = 4 j + kq]: tap = 2 j + (kq >> 1), ci = kq & 1 (K = 18, padded to 20); lane (n16 = (phase, channel), kq)
-struct HsStageA {
-  float bw2[5];
-  float bias2;
-  const float *up1s, *fr2;
-  float *u2r;
-  int lane, n16, kq, cl, pa, pb, side;
-  __device__ __forceinline__ void init(const HeadParams2 &p, int s, int side_, int lane_, float *u2r_) {
-    lane = lane_; side = side_; u2r = u2r_;
-    n16 = lane & 15; kq = lane >> 4;
-    const int ph = n16 >> 2;
-    cl = n16 & 3; pa = ph >> 1; pb = ph & 1;
-#pragma unroll
-    for (int j = 0; j < 5; j++) bw2[j] = p.w2mf[(4 * j + kq) * 16 + n16];
-    bias2 = p.b2[cl];
-    up1s = p.up1 + (size_t)s * 5000;
-    fr2 = p.u2fr + (size_t)s * 1600;
-  }
-  __device__ __forceinline__ void load(int pr, int hh, float *av) const {
-    const int px0 = side ? (hh ? 34 : 23) : (hh ? 11 : 0);
-    const int j1 = px0 + n16;
-#pragma unroll
-    for (int j = 0; j < 5; j++) {
-      const int tap = min(2 * j + (kq >> 1), 8);
-      const int yy = min(max(pr + tap / 3 - 1, 0), 49), xx = min(max(j1 + tap % 3 - 1, 0), 49);
-      av[j] = up1s[((kq & 1) * 50 + yy) * 50 + xx];
-    }
-    // the exact frame-column cell lanes 0-7 write behind the tile (2 rows x 4 channels), requested with the rest: a
-    // load in front of its use would expose the HBM latency in every second stage-A tile.
-    // (r03: lane-constant column offsets + a wave-uniform row base take these six loads' ~18 address instructions
-    // away and the kernel got SLOWER, 15.5 against 15.3 ms in one call - tools/ab_so.sh; left as the compiler has it)
-    av[5] = fr2[((side ? 3 : 2) * 100 + 2 * pr + ((lane >> 2) & 1)) * 4 + (lane & 3)];
-  }
-  __device__ __forceinline__ void compute(int pr, int hh, const float *av) const {
-    const int px0 = side ? (hh ? 34 : 23) : (hh ? 11 : 0);
-    f32x4 d = {bias2, bias2, bias2, bias2};
-#pragma unroll
-    for (int j = 0; j < 5; j++) d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bw2[j], d, 0, 0, 0);
-    // D: rows = pixels px0 + 4 kq + i, column n16 = (phase, channel)
-    const int col = 2 * (px0 + 4 * kq) + pb - (side ? 46 : -1);
-    float *w = &u2r[cl * HS_PL2 + ((2 * pr + pa + 1) & (HS_NR2 - 1)) * HS_P2 + col];
-    const bool mir = ((2 * pr + pa + 1) & (HS_NR2 - 1)) < 2;  // rows 2 pr, 2 pr + 1 sit in slots 0 / 1 when pr % 8 is 7 / 0
-#pragma unroll
-    for (int i = 0; i < 4; i++) w[2 * i] = hd_max_raw(d[i], 0.f);
-    if ((pr & 7) == 0 || (pr & 7) == 7) {  // wave-uniform
-      if (mir) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) w[HS_NR2 * HS_P2 + 2 * i] = hd_max_raw(d[i], 0.f);
-      }
-    }
-    // exact frame cells + the clamp copies outside the plane (same wave: LDS operations of a wave stay in order)
-    if ((side == 0 && hh == 0) || (side == 1 && hh == 1)) {  // the strip's frame column: 2 rows x 4 channels
-      if (lane < 8) {
-        const int yp = lane >> 2, ch = lane & 3, y = 2 * pr + yp;
-        const float v = av[5];
-        const int cf = side ? 53 : 1, cc = side ? 54 : 0;
-        hs_u2_store(u2r, ch, y, cf, v);
-        hs_u2_store(u2r, ch, y, cc, v);
-        if (y == 0) { hs_u2_store(u2r, ch, -1, cf, v); hs_u2_store(u2r, ch, -1, cc, v); }
-        if (y == 99) { hs_u2_store(u2r, ch, 100, cf, v); hs_u2_store(u2r, ch, 100, cc, v); }
-      }
-    }
-    if (pr == 0 || pr == 49) {  // frame row of the plane (and its clamp copy) over the tile's 32 columns
-      const int c = lane >> 1, chh = lane & 1, x = 2 * px0 + c;
-      const int y = pr ? 99 : 0, yc = pr ? 100 : -1;
-      const f32x2 v = *reinterpret_cast<const f32x2 *>(fr2 + ((pr ? 1 : 0) * 100 + x) * 4 + 2 * chh);
-      const int ci2 = x - (side ? 46 : -1);
-#pragma unroll
-      for (int k = 0; k < 2; k++) {
-        hs_u2_store(u2r, 2 * chh + k, y, ci2, v[k]);
-        hs_u2_store(u2r, 2 * chh + k, yc, ci2, v[k]);
-      }
-    }
-  }
-};
 constexpr int HS_NB = 4;                 // producer waves (two M-tiles per sub-step each); 4 consumer waves behind them
 constexpr int HS_THREADS = 64 * (HS_NB + 4);
 
@@ -936,9 +860,77 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
     // ================================================================ consumer waves (stage A + stencil + arg-max)
     // Every VALU instruction here is paid in matrix throughput (the f32 MFMAs and the VALU share the SIMD's issue
     // slots), so the per-pass bookkeeping is kept to running counters and the arg-max to a snapshot of the best pass.
+    const int n16 = lane & 15, kq = lane >> 4;
+    const int ph = n16 >> 2, cl = n16 & 3, pa = ph >> 1, pb = ph & 1;
     const int cw = wv - HS_NB;
-    HsStageA A;                                      // the consumers run stage A (on the producers: 15.85 against 13.6 ms, r04)
-    A.init(p, s, side, lane, u2r);
+    float bw2[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) bw2[j] = p.w2mf[(4 * j + kq) * 16 + n16];
+    const float bias2 = p.b2[cl];
+    const float *up1s = p.up1 + (size_t)s * 5000;
+    const float *fr2 = p.u2fr + (size_t)s * 1600;
+    // ---- stage A (the consumers open a sub-step with it): one M-tile = 16 uprelu1 pixels of row pair `pr` -> 2 x 32 cells x 4 channels of uprelu2 ----
+    // A[pixel][k = 4 j + kq]: tap = 2 j + (kq >> 1), ci = kq & 1 (K = 18, padded to 20)
+    // (kept as lambdas over the consumer's locals: the same code as a struct with init/load/compute members compiles to
+    // 114 instead of 122 VGPRs and a different schedule, and measures 15.05 against 13.63 ms in one call - r04,
+    // tools/ab_so.sh; stage A on the producer waves: 15.85 ms)
+    auto stageA_load = [&](int pr, int hh, float *av) {
+      const int px0 = side ? (hh ? 34 : 23) : (hh ? 11 : 0);
+      const int j1 = px0 + n16;
+#pragma unroll
+      for (int j = 0; j < 5; j++) {
+        const int tap = min(2 * j + (kq >> 1), 8);
+        const int yy = min(max(pr + tap / 3 - 1, 0), 49), xx = min(max(j1 + tap % 3 - 1, 0), 49);
+        av[j] = up1s[((kq & 1) * 50 + yy) * 50 + xx];
+      }
+      // the exact frame-column cell lanes 0-7 write behind the tile (2 rows x 4 channels), requested with the rest: a
+      // load in front of its use would expose the HBM latency in every second stage-A tile.
+      // (r03: lane-constant column offsets + a wave-uniform row base take these six loads' ~18 address instructions
+      // away and the kernel got SLOWER, 15.5 against 15.3 ms in one call - tools/ab_so.sh; left as the compiler has it)
+      av[5] = fr2[((side ? 3 : 2) * 100 + 2 * pr + ((lane >> 2) & 1)) * 4 + (lane & 3)];
+    };
+    auto stageA_compute = [&](int pr, int hh, const float *av) {
+      const int px0 = side ? (hh ? 34 : 23) : (hh ? 11 : 0);
+      f32x4 d = {bias2, bias2, bias2, bias2};
+#pragma unroll
+      for (int j = 0; j < 5; j++) d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bw2[j], d, 0, 0, 0);
+      // D: rows = pixels px0 + 4 kq + i, column n16 = (phase, channel)
+      const int col = 2 * (px0 + 4 * kq) + pb - (side ? 46 : -1);
+      float *w = &u2r[cl * HS_PL2 + ((2 * pr + pa + 1) & (HS_NR2 - 1)) * HS_P2 + col];
+      const bool mir = ((2 * pr + pa + 1) & (HS_NR2 - 1)) < 2;  // rows 2 pr, 2 pr + 1 sit in slots 0 / 1 when pr % 8 is 7 / 0
+#pragma unroll
+      for (int i = 0; i < 4; i++) w[2 * i] = hd_max_raw(d[i], 0.f);
+      if ((pr & 7) == 0 || (pr & 7) == 7) {  // wave-uniform
+        if (mir) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) w[HS_NR2 * HS_P2 + 2 * i] = hd_max_raw(d[i], 0.f);
+        }
+      }
+      // exact frame cells + the clamp copies outside the plane (same wave: LDS operations of a wave stay in order)
+      if ((side == 0 && hh == 0) || (side == 1 && hh == 1)) {  // the strip's frame column: 2 rows x 4 channels
+        if (lane < 8) {
+          const int yp = lane >> 2, ch = lane & 3, y = 2 * pr + yp;
+          const float v = av[5];
+          const int cf = side ? 53 : 1, cc = side ? 54 : 0;
+          hs_u2_store(u2r, ch, y, cf, v);
+          hs_u2_store(u2r, ch, y, cc, v);
+          if (y == 0) { hs_u2_store(u2r, ch, -1, cf, v); hs_u2_store(u2r, ch, -1, cc, v); }
+          if (y == 99) { hs_u2_store(u2r, ch, 100, cf, v); hs_u2_store(u2r, ch, 100, cc, v); }
+        }
+      }
+      if (pr == 0 || pr == 49) {  // frame row of the plane (and its clamp copy) over the tile's 32 columns
+        const int c = lane >> 1, chh = lane & 1, x = 2 * px0 + c;
+        const int y = pr ? 99 : 0, yc = pr ? 100 : -1;
+        const f32x2 v = *reinterpret_cast<const f32x2 *>(fr2 + ((pr ? 1 : 0) * 100 + x) * 4 + 2 * chh);
+        const int ci2 = x - (side ? 46 : -1);
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+          hs_u2_store(u2r, 2 * chh + k, y, ci2, v[k]);
+          hs_u2_store(u2r, 2 * chh + k, yc, ci2, v[k]);
+        }
+      }
+    };
+
     const int task = 64 * (wv - HS_NB) + lane;       // 250 two-pixel tasks per sub-step: 5 rows x 50
     const bool task_ok = task < 250;
     const int tk = task_ok ? task : 249;
@@ -972,8 +964,8 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
 
     {  // prologue: uprelu2 row pairs 0 and 1, one tile per consumer wave
       float av0[6];
-      A.load(cw >> 1, cw & 1, av0);
-      A.compute(cw >> 1, cw & 1, av0);
+      stageA_load(cw >> 1, cw & 1, av0);
+      stageA_compute(cw >> 1, cw & 1, av0);
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // see the producers
     // stage-A tile of this wave in sub-step st (uprelu2 rows for the M-tiles of st + 1): tile id 2 pair + half belongs to
@@ -984,7 +976,7 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
       const int row = reinterpret_cast<const int *>(&kHsPick.v[0][0])[st];   // wave-uniform: a scalar load
       apr = (int)(signed char)(row >> (8 * cw));
       ahh = cw & 1;
-      A.load(max(apr, 0), ahh, av);
+      stageA_load(max(apr, 0), ahh, av);
     };
     stageA_pick(0);
     __syncthreads();
@@ -998,7 +990,7 @@ __global__ __launch_bounds__(HS_THREADS, 4) void k_head_stream(HeadParams2 p) {
       // The consumers open a sub-step with stage A for the NEXT sub-step's M-tiles and the loads of the one after.
       // Nothing inside a sub-step orders stage A against the pass: uprelu2 rows written in sub-step st are read by the
       // producers in st + 1 (tools/head_schedule.py).
-      if (apr >= 0) A.compute(apr, ahh, av);
+      if (apr >= 0) stageA_compute(apr, ahh, av);
       stageA_pick(min(st + 1, HS_NS - 1));
       HS_STAMP(3);
       if (__builtin_amdgcn_ballot_w64(ok) != 0) {    // wave-uniform
