@@ -36,28 +36,26 @@ int ofx_fit_finish(hipStream_t st, int nblocks, int c_n, double count, const dou
 int ofx_fit_pool_act(hipStream_t st, int n, int C, int H, int W, const float *z, const float *act, float *p);
 // g = d loss / d (BN output of the layer), ReLU-masked, through the pooling in front of the next convolution
 // (conv: dzn = that convolution's dz [n][8][H/2][W/2], wn its kernel; else dzn = d pooled output)
-// conv = 2 (the first layer): g is written compact - the one non-zero of every 2 x 2 window [n][8][H/2][W/2] - with the
-// window position of the maximum in kk (one byte per window), for ofx_fit_bw_first
 int ofx_fit_b1_pool(hipStream_t st, int n, int H, int W, int conv, const float *dzn, const float *wn, const float *z,
-                    const float *stat, const float *act, float *g, double *part, int *nblocks, unsigned char *kk = nullptr);
+                    const float *stat, const float *act, float *g, double *part, int *nblocks);
 size_t ofx_fit_first_doubles(int n);
 size_t ofx_fit_first_floats(void);
 struct ofx_handle;
 // the first trunk layer without its tensor z0 (see ofx_fit.hip "the first layer is never materialised")
 int ofx_fit_first_fwd(ofx_handle *h, int n, const void *bits, const float *w, const float *b, const float *gamma,
                       const float *beta, double *cpart, float *stat, float *act, float *luts, float *p0);
-int ofx_fit_b1_first(hipStream_t st, int n, const void *bits, const float *dzn, const float *wn, const float *luts,
-                     const float *gamma, const float *beta, float *gc, unsigned char *kk, double *part, int *nblocks);
-int ofx_fit_bw_first(hipStream_t st, int n, const void *bits, const float *gc, const unsigned char *kk, const float *w,
-                     const float *b, const float *stat, const float *gamma, const double *sums, double *part,
-                     double *cpart, float *dw, float *db, float *dgamma, float *dbeta);
+// its backward from the second layer's dz (dzn, out of BatchNorm's backward; kernel wn): only the 2 x 2 windows that see a
+// set bit are visited
+int ofx_fit_first_bwd(hipStream_t st, int n, const void *bits, const float *dzn, const float *wn, const float *luts, const float *w, const float *b, const float *stat, const float *gamma,
+                      const float *beta, double *part, double *cpart, float *dw, float *db, float *dgamma, float *dbeta);
 // the same through the x2 up-sampling in front of a convolution with `con` output channels at 2h x 2w
 int ofx_fit_b1_up(hipStream_t st, int n, int c, int con, int h, int w, int bn, const float *dzn, const float *wn,
                   const float *zp, const float *stat, const float *act, int legacy, float *g, double *part, int *nblocks);
-// dz over g in place (bn), dw / db (/ dgamma, dbeta from sums)
+// dz over g in place (bn), dw / db (/ dgamma, dbeta from sums); gpatch + rows (the last head layer under the textbook
+// targets): g is not read - it is zero but for the 4 x 4 patch per sample and channel ofx_fit_top_point left in gpatch
 int ofx_fit_bw(hipStream_t st, int n, int ci, int co, int H, int W, const ofx_fit_src &src, int bn, float *g,
                const float *z, const float *stat, const float *gamma, const double *sums, double *part, float *dw,
-               float *db, float *dgamma, float *dbeta);
+               float *db, float *dgamma, float *dbeta, const float *gpatch = nullptr, const ofx_transition *rows = nullptr);
 // the output convolution (8 -> 1 at 400 x 400 behind the last x2 up-sampling) in phase form: forward + frame correction;
 // weff: ofx_fit_out_floats() floats of scratch; the weight gradient needs part (ofx_fit_part_doubles) and fpart
 // (ofx_fit_out_doubles(n) doubles)
@@ -70,4 +68,4 @@ int ofx_fit_out_bw(hipStream_t st, int n, const ofx_fit_src &src, const float *d
 size_t ofx_fit_point_doubles(int n);
 int ofx_fit_top_point(hipStream_t st, int n, const ofx_transition *rows, const ofx_fit_src &src, const float *w, const float *b,
                       const float *o1, const float *y_act, const float *y_ptr, const float *stat, float *o2p, float *do1,
-                      float *d2p, float *lpart, float *g, double *scratch, double *sums, float *dw, float *db);
+                      float *d2p, float *lpart, float *gpatch, double *scratch, double *sums, float *dw, float *db);

@@ -16,7 +16,8 @@
 //                (f_bw_small: the layers with CI x CO <= 8, a thread owns 4 pixels and all sums.)
 //   f_first_* /  the first layer (1-bit inputs) is never materialised: batch statistics and the weight gradient (BatchNorm's
 //   f_bits_corr  backward folded in analytically) from the autocorrelation of the shifted bit maps (popcounts), its pooled
-//   f_b1_first   activation through the forward's table kernel, the pooling backward from an x-hat table; g kept compact.
+//                activation through the forward's table kernel; the backward visits only the windows that see a set bit
+//                (x-hat from a table), the empty ones enter through sums of the second layer's dz (f_first_bwd).
 //   f_top_point_* the textbook targets (one error per sample): the output convolution, its gradients and the last head layer's g
 //                from the ONE heat-map pixel that carries an error.
 //   f_out_*      (dense targets) the output convolution (8 -> 1 at 400 x 400 behind the last up-sampling) in PHASE form: a 3 x 3
@@ -462,14 +463,11 @@ __global__ void f_pool_act(int n, int C, int H, int W, const float *z, const flo
 // dp given (the last trunk layer: the dense head's gradient); g = dp at the first maximum of each 2 x 2 window of
 // a = relu(bn(z)) where that maximum is positive, zero elsewhere; part[block] = {sum g, sum g xhat} per channel.
 constexpr int P_TR = 10, P_TW = 50;
-// COMPACT (the first layer): g has ONE non-zero per 2 x 2 window; it is stored as that value [n][8][H/2][W/2] (in g) plus the
-// window position 0..3 of the maximum (kk, one byte per window) - 1.6 MB per row instead of 5.12 MB, for f_bw_first.
-template <bool CONV, bool COMPACT = false>
+template <bool CONV>
 __global__ __launch_bounds__(256, 3) void f_b1_pool(int n, int H, int W, const float *__restrict__ dzn,
                                                  const float *__restrict__ wn, const float *__restrict__ z,
                                                  const float *__restrict__ stat, const float *__restrict__ act,
-                                                 float *__restrict__ g, double *__restrict__ part,
-                                                 unsigned char *__restrict__ kk) {
+                                                 float *__restrict__ g, double *__restrict__ part) {
   constexpr int C = 8, LP = P_TW + 4;
   __shared__ __align__(16) float dzt[CONV ? C : 1][P_TR + 2][LP];
   __shared__ __align__(16) float wl[CONV ? 9 * C * C : 4];   // [tap][co][ci]: the C input channels of one read contiguous
@@ -557,8 +555,6 @@ __global__ __launch_bounds__(256, 3) void f_b1_pool(int n, int H, int W, const f
         }
       }
       float o[2][4];
-      float gcv[2] = {0.f, 0.f};
-      int kcv[2] = {0, 0};
 #pragma unroll
       for (int j = 0; j < 2; j++) {
         const float zv[4] = {zr[0][2 * j], zr[0][2 * j + 1], zr[1][2 * j], zr[1][2 * j + 1]};
@@ -573,20 +569,10 @@ __global__ __launch_bounds__(256, 3) void f_b1_pool(int n, int H, int W, const f
         const float gv = (av[k] > 0.f && (j == 0 || both)) ? d : 0.f;
         o[0][2 * j] = k == 0 ? gv : 0.f; o[0][2 * j + 1] = k == 1 ? gv : 0.f;
         o[1][2 * j] = k == 2 ? gv : 0.f; o[1][2 * j + 1] = k == 3 ? gv : 0.f;
-        gcv[j] = gv; kcv[j] = k;
         s1[ci] += (double)gv;
         s2[ci] += (double)(gv * ((zv[k] - mean) * rs));
       }
-      if constexpr (COMPACT) {
-        const size_t at = ((s * C + ci) * (size_t)Hp + yp) * Wp + xp;   // xp even, Wp even: 8-byte aligned
-        if (both) {
-          *reinterpret_cast<float2 *>(g + at) = make_float2(gcv[0], gcv[1]);
-          *reinterpret_cast<uchar2 *>(kk + at) = make_uchar2((unsigned char)kcv[0], (unsigned char)kcv[1]);
-        } else {
-          g[at] = gcv[0];
-          kk[at] = (unsigned char)kcv[0];
-        }
-      } else if (vec) {
+      if (vec) {
         *reinterpret_cast<float4 *>(g + base) = make_float4(o[0][0], o[0][1], o[0][2], o[0][3]);
         *reinterpret_cast<float4 *>(g + base + W) = make_float4(o[1][0], o[1][1], o[1][2], o[1][3]);
       } else {
@@ -743,11 +729,15 @@ constexpr int W_TR = 8, W_FLUSH = 16;
 constexpr int OFX_FIT_BW_NT = 512, OFX_FIT_BW_TR = 8;   // f_bw workgroups (256 threads on 4-row tiles: 4 % slower, r03)
 // PHASE: g is ONE plane of 2 H x 2 W per sample (d loss / d heat map) and output channel 2 a + b of cell (y, x) is its
 // element (2 y + a, 2 x + b) - the weight gradient of the output convolution in phase form (f_out_prep).
-template <int CI, int CO, int SRC, int TW, bool BN, int NT, int TR, bool PHASE = false>
+// POINT (the last head layer under the textbook targets): g is zero but for a 4 x 4 patch of cells per sample and channel
+// (gp [n][CO][16], f_top_point_bwd; the patch starts at cell ((py - 1) / 2 - 1, (px - 1) / 2 - 1) of the sample's pointer):
+// g is not read - 1.28 MB per row that were a memset and a read of zeros - and dz is written to it.
+template <int CI, int CO, int SRC, int TW, bool BN, int NT, int TR, bool PHASE = false, bool POINT = false>
 __global__ __launch_bounds__(NT) void f_bw(int n, int H, int W, FitSrc S, float *__restrict__ g,
                                             const float *__restrict__ z, const float *__restrict__ stat,
                                             const float *__restrict__ gamma, const double *__restrict__ sums, double count,
-                                            double *__restrict__ part) {
+                                            double *__restrict__ part, const float *__restrict__ gp,
+                                            const ofx_transition *__restrict__ rows) {
   constexpr int LP = TW + 2, NA = 9 * CO + CO, NSUB = (NT / 64) / CI, NPX = TR * TW, NGRP = (NPX + 63) / 64;
   __shared__ float in[CI][TR + 2][LP];
   float *const lo = nullptr;   // no staging here (STAGE = false)
@@ -793,6 +783,11 @@ __global__ __launch_bounds__(NT) void f_bw(int n, int H, int W, FitSrc S, float 
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const size_t s = tile / per_s;
     const int t = (int)(tile - (long)s * per_s), y0 = (t / tx_n) * TR, x0 = (t % tx_n) * TW;
+    int pk0 = 0, pm0 = 0;   // POINT: first cell of the sample's patch
+    if constexpr (POINT) {
+      pk0 = (((min(max(rows[s].py, 0), 399)) - 1) >> 1) - 1;
+      pm0 = (((min(max(rows[s].px, 0), 399)) - 1) >> 1) - 1;
+    }
     __syncthreads();
     fill_input<SRC, CI, TR, TW, LP, NT, 1, false>(in, lo, S, s, y0, x0, H, W, tid);
     // V gradient values per step (16-byte loads where the rows allow): the index arithmetic is paid once per V values
@@ -823,7 +818,18 @@ __global__ __launch_bounds__(NT) void f_bw(int n, int H, int W, FitSrc S, float 
       if (y < H) {
         const size_t at = ((s * CO + co) * (size_t)H + y) * W + x0 + V * xv;
         float zz[V];
-        if constexpr (V == 4) {
+        if constexpr (POINT) {
+          static_assert(!POINT || (V == 4 && BN), "patch form");
+          const float4 z4 = *reinterpret_cast<const float4 *>(z + at);
+          zz[0] = z4.x; zz[1] = z4.y; zz[2] = z4.z; zz[3] = z4.w;
+          if ((unsigned)(y - pk0) < 4u) {
+#pragma unroll
+            for (int k = 0; k < V; k++) {
+              const int xx = x0 + V * xv + k - pm0;
+              if ((unsigned)xx < 4u) d[k] = gp[(s * CO + co) * 16 + (y - pk0) * 4 + xx];
+            }
+          }
+        } else if constexpr (V == 4) {
           const float4 g4 = *reinterpret_cast<const float4 *>(g + at);
           d[0] = g4.x; d[1] = g4.y; d[2] = g4.z; d[3] = g4.w;
           if constexpr (BN) { const float4 z4 = *reinterpret_cast<const float4 *>(z + at); zz[0] = z4.x; zz[1] = z4.y; zz[2] = z4.z; zz[3] = z4.w; }
@@ -1147,8 +1153,8 @@ __global__ void f_out_bw_finish(const double *q, const double *fr, int legacy, f
 //   dW[u][co] = sum_p in_u[p] dz[co][p] = a_co ( A[u][co] - m0_co B[u] - c_co ( T[u][co] - mean_co B[u] ) ),  u = (tap, ci),
 //   A = sum in_u g,   B[u] = sum in_u,   T[u][co] = sum in_u z[co] = b_co B[u] + sum_u' w[u'][co] Cc[u][u'],
 //   Cc[u][u'] = sum_p in_u[p] in_u'[p]  - the autocorrelation of the shifted bit maps (popcounts; B is its diagonal).
-// So the 5.12 MB per row of z0 are not read again, dz0 is never formed, and g0 arrives compact (f_b1_pool COMPACT): the
-// kernel that moved 27 GB per 2048 rows moves 3.  The bias gradient of a convolution in front of BatchNorm is exactly 0.
+// So the 5.12 MB per row of z0 are not read again and dz0 is never formed; A comes out of the kernel that forms g0
+// (f_first_bwd, below).  The bias gradient of a convolution in front of BatchNorm is exactly 0.
 constexpr int C0_ROWS = 40;   // rows of a correlation chunk
 // part[block][324]: Cc over the block's rows of one sample; block = 384 threads, thread q < 324 owns the pair (q / 18, q % 18)
 __global__ __launch_bounds__(384) void f_bits_corr(int n, const uint32_t *__restrict__ bits, double *__restrict__ part) {
@@ -1232,243 +1238,255 @@ __global__ __launch_bounds__(256) void f_first_prepare(const double *cc, const f
   }
 }
 
-// f_b1_pool<true, COMPACT> for the first layer without z0: the windows' x-hat from lut_x (LDS) and the bit rows of the tile
-__global__ __launch_bounds__(256, 2) void f_b1_first(int n, const uint32_t *__restrict__ bits, const float *__restrict__ dzn,
-                                                     const float *__restrict__ wn, const float *__restrict__ lut_x,
-                                                     const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                     float *__restrict__ g, unsigned char *__restrict__ kk,
-                                                     double *__restrict__ part) {
-  constexpr int C = 8, LP = P_TW + 4, H = 400, W = 400, Hp = 200, Wp = 200, NR = 2 * P_TR + 2;
-  __shared__ __align__(16) float dzt[C][P_TR + 2][LP];
-  __shared__ __align__(16) float wl[9 * C * C];
+// ---- the first layer's backward over the windows that see a set bit --------------------------------------------------------
+// g0 = d loss / d (BatchNorm output of layer 0) is the transposed convolution of the second layer's dz pushed back through the
+// pooling - and layer 0 reads 1-bit maps that are ~1 % set.  A 2 x 2 window whose 4 x 4 bit neighbourhood is EMPTY in both
+// maps has z0 = b at its four pixels: the same x-hat xc, the same activation ac, its first pixel as the maximum, and no input
+// under any tap of that pixel.  So such a window adds nothing to A = sum in_u g, and to BatchNorm's sums it adds
+// [ac > 0] dp and [ac > 0] xc dp, where dp is the transposed convolution at the window.  The sum of dp over ALL windows is
+// linear in sums of dz over the plane with a border row / column left out.  The batch total of dz itself is ZERO: the second
+// layer's dz comes out of BatchNorm's backward, dz = a (g - mean g - xhat mean(g xhat)), which sums to zero per channel; what
+// the stored fp32 values sum to is rounding noise (taking their exact total in doubles instead gives the same test results;
+// the float total the weight-gradient kernel has for the bias moved conv1's beta gradient by 7e-4 of its scale - r04).  So
+//   sum over all windows of dp = - sum_{co, tap} w (the border row / column / corner the tap shifts out)      (f_first_border)
+//   sum over the empty windows of dp = (sum over all) - (sum over the windows that see a bit),
+// and only the windows that see a bit are evaluated: ~2.5 % of them on arena observations (every window on a dense map -
+// the result is the same, only the time differs).  The 94 GMAC of the dense transposed convolution per 4096 rows, the
+// compact g0 (1.6 MB per row written and read back) and a kernel of its own for A are gone.
+// Per band of 20 pooled rows: the bit rows in LDS, every wave classifies its 5 rows x 200 windows into a list (ballot order:
+// fixed), walks the list 64 windows at a time (dz straight from global memory: the windows cluster), and adds A from the
+// 64 records it leaves in LDS, (tap, map, channel) per lane, in list order.
+constexpr int FS_BR = 20, FS_WR = FS_BR / 4, FS_NW = FS_WR * 200, FS_ROWS = 2 * FS_BR + 2, FS_WORDS = 14, FS_NV = 144 + 24;
+struct FsEntry {
+  float gv[8];          // g of the window per channel (0 behind the ReLU)
+  uint32_t kpack;       // window position of the maximum, 2 bits per channel
+  uint16_t pat[2][4];   // the 3 x 3 bit pattern around each of the window's four pixels, per map
+};
+__global__ __launch_bounds__(256) void f_first_bwd(int n, const uint32_t *__restrict__ bits, const float *__restrict__ dzn,
+                                                   const float *__restrict__ wn, const float *__restrict__ lut_x,
+                                                   const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                   double *__restrict__ part) {
+  constexpr int C = 8, H = 400, W = 400, Hp = 200, Wp = 200;
+  __shared__ __align__(16) float wl[9 * C * C];   // [tap][co][ci]
   __shared__ __align__(16) float slut[2 * 512 * 8];
-  __shared__ uint32_t rows[2][NR][5];   // bit i of a staged row <-> image column 2 x0 - 1 + i (0 outside the plane)
-  __shared__ double red[4][2 * C];
-  const int tid = threadIdx.x, r = tid / (P_TW / 2), q = tid - r * (P_TW / 2);
+  __shared__ uint32_t rows[2][FS_ROWS][FS_WORDS];   // bit i of a staged row <-> image column i - 1 (0 outside the plane)
+  __shared__ uint16_t list[4][FS_NW];
+  __shared__ __align__(16) FsEntry ent[4][64];
+  __shared__ double red[4][FS_NV];
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   for (int e = tid; e < 9 * C * C; e += 256) {
     const int ci = e % C, co = (e / C) % C, tap = e / (C * C);
     wl[e] = wn[(tap * C + ci) * C + co];
   }
   for (int e = tid; e < 2 * 512 * 8 / 4; e += 256) reinterpret_cast<float4 *>(slut)[e] = reinterpret_cast<const float4 *>(lut_x)[e];
-  const int tx_n = Wp / P_TW, ty_n = Hp / P_TR, per_s = tx_n * ty_n;
-  const long ntiles = (long)n * per_s;
-  double s1[C], s2[C];
+  float gm[C], bt[C];
 #pragma unroll
-  for (int c = 0; c < C; c++) { s1[c] = 0.0; s2[c] = 0.0; }
-  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const size_t s = tile / per_s;
-    const int t = (int)(tile - (long)s * per_s), y0 = (t / tx_n) * P_TR, x0 = (t % tx_n) * P_TW;
+  for (int c = 0; c < C; c++) { gm[c] = gamma[c]; bt[c] = beta[c]; }
+  double s1[C], s2[C], s3[C], accA[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+  for (int c = 0; c < C; c++) { s1[c] = 0.0; s2[c] = 0.0; s3[c] = 0.0; }
+  const uint64_t lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+  const long nbands = (long)n * (Hp / FS_BR);
+  for (long band = blockIdx.x; band < nbands; band += gridDim.x) {
+    const size_t s = band / (Hp / FS_BR);
+    const int y0 = (int)(band - (long)s * (Hp / FS_BR)) * FS_BR;
     __syncthreads();
-    {
-      constexpr int NE = C * (P_TR + 2) * (P_TW + 2);
-      for (int e0 = tid; e0 < NE; e0 += 256 * FILL_U) {
-        float v[FILL_U];
-#pragma unroll
-        for (int u = 0; u < FILL_U; u++) {
-          const int e = e0 + u * 256;
-          const int co = e / ((P_TR + 2) * (P_TW + 2)), rem = e - co * ((P_TR + 2) * (P_TW + 2));
-          const int yy = rem / (P_TW + 2), xx = rem - yy * (P_TW + 2);
-          const int y = y0 - 1 + yy, x = x0 - 1 + xx;
-          v[u] = (e < NE && y >= 0 && y < Hp && x >= 0 && x < Wp) ? dzn[((s * C + co) * (size_t)Hp + y) * Wp + x] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < FILL_U; u++) {
-          const int e = e0 + u * 256;
-          if (e < NE) (&dzt[0][0][0])[(e / (P_TW + 2)) * LP + e % (P_TW + 2)] = v[u];
-        }
-      }
-    }
-    // image rows 2 y0 - 1 .. 2 y0 + 2 P_TR, columns 2 x0 - 1 .. 2 x0 + 2 P_TW (102 bits -> 4 words + one spare)
-    for (int e = tid; e < 2 * NR * 5; e += 256) {
-      const int wd = e % 5, rr = (e / 5) % NR, ci = e / (5 * NR);
+    // image rows 2 y0 - 1 .. 2 y0 + 2 FS_BR, columns -1 .. 400 (402 bits -> 13 words + one of zeros)
+    for (int e = tid; e < 2 * FS_ROWS * FS_WORDS; e += 256) {
+      const int wd = e % FS_WORDS, rr = (e / FS_WORDS) % FS_ROWS, ci = e / (FS_WORDS * FS_ROWS);
       const int gy = 2 * y0 - 1 + rr;
       uint32_t out = 0u;
-      if (gy >= 0 && gy < H && wd < 4) {
-        const int c0 = 2 * x0 - 1 + 32 * wd;                          // image column of the word's bit 0
-        const long s0 = (long)gy * W + c0;                            // its cell (-1 only at gy = 0, c0 = -1)
-        const uint32_t *pl = bits + ((size_t)s * 2 + ci) * 5000;
+      if (gy >= 0 && gy < H && wd < 13) {
+        const int c0 = 32 * wd - 1;                                   // image column of the word's bit 0
+        const long s0 = (long)gy * W + c0;                            // its cell (-1 only at gy = 0, wd = 0)
+        const uint32_t *pl = bits + (s * 2 + ci) * 5000;
         const long sw = s0 >> 5;
         const uint32_t lo = (sw >= 0 && sw < 5000) ? pl[sw] : 0u, hi = (sw + 1 >= 0 && sw + 1 < 5000) ? pl[sw + 1] : 0u;
         out = __funnelshift_r(lo, hi, (unsigned)(s0 & 31));
         if (c0 < 0) out &= ~1u;                                       // column -1
         const int over = c0 + 32 - W;                                 // bits past the last column of THIS row
-        if (over > 0) out = over >= 32 ? 0u : (out & (0xFFFFFFFFu >> over));
+        if (over > 0) out &= 0xFFFFFFFFu >> over;
       }
       rows[ci][rr][wd] = out;
     }
     __syncthreads();
-    const int yp = y0 + r, xp = x0 + 2 * q;
-    if (r >= P_TR) continue;
-    float dp[2][C];
+    // window wi = 200 yl + xp of the wave's rows: staged rows 2 r .. 2 r + 3 (r = FS_WR wv + yl), staged bits 2 xp .. 2 xp + 3
+    auto window_bits = [&](int wi, uint32_t (&f)[2][4]) {
+      const int yl = wi / Wp, xp = wi - yl * Wp, r = FS_WR * wv + yl, wd = (2 * xp) >> 5;
+      const unsigned sh = (unsigned)((2 * xp) & 31);
 #pragma unroll
-    for (int j = 0; j < 2; j++)
+      for (int ci = 0; ci < 2; ci++)
 #pragma unroll
-      for (int ci = 0; ci < C; ci++) dp[j][ci] = 0.f;
-#pragma unroll 1
-    for (int co = 0; co < C; co++) {
+        for (int k = 0; k < 4; k++) {
+          const uint32_t *rw = &rows[ci][2 * r + k][wd];
+          f[ci][k] = __funnelshift_r(rw[0], rw[1], sh) & 15u;
+        }
+    };
+    int cnt = 0;   // wave-uniform
+    for (int it = 0; it < (FS_NW + 63) / 64; it++) {
+      const int wi = 64 * it + lane;
+      uint32_t f[2][4], any = 0u;
+      window_bits(min(wi, FS_NW - 1), f);
 #pragma unroll
-      for (int ky = 0; ky < 3; ky++) {
-        const float2 a = *reinterpret_cast<const float2 *>(&dzt[co][r - ky + 2][2 * q]);
-        const float2 c2 = *reinterpret_cast<const float2 *>(&dzt[co][r - ky + 2][2 * q + 2]);
-        const float v[4] = {a.x, a.y, c2.x, c2.y};
+      for (int k = 0; k < 4; k++) any |= f[0][k] | f[1][k];
+      const bool ne = wi < FS_NW && any != 0u;
+      const uint64_t m = __builtin_amdgcn_ballot_w64(ne);
+      if (ne) list[wv][cnt + __builtin_popcountll(m & lt)] = (uint16_t)wi;
+      cnt += __builtin_popcountll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const float *dzs = dzn + s * (size_t)(C * Hp * Wp);
+    for (int c0 = 0; c0 < cnt; c0 += 64) {
+      const bool ok = c0 + lane < cnt;
+      const int wi = list[wv][ok ? c0 + lane : c0];
+      uint32_t f[2][4];
+      window_bits(wi, f);
+      const int yl = wi / Wp, xp = wi - yl * Wp, yp = y0 + FS_WR * wv + yl;
+      float dp[C];
 #pragma unroll
-        for (int kx = 0; kx < 3; kx++) {
-          float wv[C];
-          lds_vec<C>(&wl[((ky * 3 + kx) * C + co) * C], wv);
-          fma_row<C>(dp[0], v[2 - kx], wv);
-          fma_row<C>(dp[1], v[3 - kx], wv);
+      for (int ci = 0; ci < C; ci++) dp[ci] = 0.f;
+#pragma unroll 2
+      for (int co = 0; co < C; co++) {
+        float v[9];
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+          const int y = yp - (t / 3 - 1), x = xp - (t % 3 - 1);
+          v[t] = (y >= 0 && y < Hp && x >= 0 && x < Wp) ? dzs[(co * Hp + y) * Wp + x] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+          float wv8[C];
+          lds_vec<C>(&wl[(t * C + co) * C], wv8);
+          fma_row<C>(dp, v[t], wv8);
         }
       }
-    }
-    // the 2 x 4 block of first-layer pixels under the thread's two windows: rows 2 r, 2 r + 1 of the tile, columns 4 q ..
-    // 4 q + 3; staged row 2 r + dy + ky <-> image row (2 y0 + 2 r + dy) + ky - 1, staged bit 4 q + dx + kx <-> column + kx - 1
-    uint32_t f[2][4];
+      // x-hat of the window's four pixels (dy, dx): pattern = bits dx .. dx + 2 of staged rows dy .. dy + 2
+      float xh[4][C];
+      FsEntry E;
 #pragma unroll
-    for (int ci = 0; ci < 2; ci++)
-#pragma unroll
-      for (int rr = 0; rr < 4; rr++) {
-        const uint32_t *rw = &rows[ci][2 * r + rr][(4 * q) >> 5];
-        f[ci][rr] = __funnelshift_r(rw[0], rw[1], (unsigned)((4 * q) & 31)) & 63u;
-      }
-    float xh[2][4][C];   // [row][column][channel]
-#pragma unroll
-    for (int dy = 0; dy < 2; dy++)
-#pragma unroll
-      for (int dx = 0; dx < 4; dx++) {
+      for (int px = 0; px < 4; px++) {
+        const int dy = px >> 1, dx = px & 1;
         float4 lo4, hi4;
 #pragma unroll
         for (int ci = 0; ci < 2; ci++) {
           const uint32_t pat = ((f[ci][dy] >> dx) & 7u) | (((f[ci][dy + 1] >> dx) & 7u) << 3) | (((f[ci][dy + 2] >> dx) & 7u) << 6);
+          E.pat[ci][px] = (uint16_t)pat;
           const float4 *e = reinterpret_cast<const float4 *>(&slut[(ci * 512 + pat) * 8]);
           if (ci == 0) { lo4 = e[0]; hi4 = e[1]; }
           else { lo4.x += e[0].x; lo4.y += e[0].y; lo4.z += e[0].z; lo4.w += e[0].w; hi4.x += e[1].x; hi4.y += e[1].y; hi4.z += e[1].z; hi4.w += e[1].w; }
         }
-        xh[dy][dx][0] = lo4.x; xh[dy][dx][1] = lo4.y; xh[dy][dx][2] = lo4.z; xh[dy][dx][3] = lo4.w;
-        xh[dy][dx][4] = hi4.x; xh[dy][dx][5] = hi4.y; xh[dy][dx][6] = hi4.z; xh[dy][dx][7] = hi4.w;
+        xh[px][0] = lo4.x; xh[px][1] = lo4.y; xh[px][2] = lo4.z; xh[px][3] = lo4.w;
+        xh[px][4] = hi4.x; xh[px][5] = hi4.y; xh[px][6] = hi4.z; xh[px][7] = hi4.w;
       }
+      E.kpack = 0u;
 #pragma unroll
-    for (int ci = 0; ci < C; ci++) {
-      const float gm = gamma[ci], bt = beta[ci];
-      float gcv[2];
-      int kcv[2];
-#pragma unroll
-      for (int j = 0; j < 2; j++) {
-        const float xv[4] = {xh[0][2 * j][ci], xh[0][2 * j + 1][ci], xh[1][2 * j][ci], xh[1][2 * j + 1][ci]};
+      for (int c = 0; c < C; c++) {
         float av[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) av[i] = fmaxf(fmaf(gm, xv[i], bt), 0.f);
+        for (int i = 0; i < 4; i++) av[i] = fmaxf(fmaf(gm[c], xh[i][c], bt[c]), 0.f);
         int k = 0;
 #pragma unroll
         for (int i = 1; i < 4; i++) if (av[i] > av[k]) k = i;
-        const float gv = av[k] > 0.f ? dp[j][ci] : 0.f;
-        gcv[j] = gv; kcv[j] = k;
-        s1[ci] += (double)gv;
-        s2[ci] += (double)(gv * xv[k]);
+        const float xk = k == 0 ? xh[0][c] : k == 1 ? xh[1][c] : k == 2 ? xh[2][c] : xh[3][c];
+        const float gv = (ok && av[k] > 0.f) ? dp[c] : 0.f;
+        E.gv[c] = gv;
+        E.kpack |= (uint32_t)k << (2 * c);
+        s1[c] += (double)gv;
+        s2[c] += (double)(gv * xk);
+        s3[c] += ok ? (double)dp[c] : 0.0;
       }
-      const size_t at = ((s * C + ci) * (size_t)Hp + yp) * Wp + xp;
-      *reinterpret_cast<float2 *>(g + at) = make_float2(gcv[0], gcv[1]);
-      *reinterpret_cast<uchar2 *>(kk + at) = make_uchar2((unsigned char)kcv[0], (unsigned char)kcv[1]);
+      ent[wv][lane] = E;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // A[u = (tap, map)][c] += (bit `tap` of the pattern around channel c's maximum) * g: lane <-> (u, c), records in list order
+      const int ne = min(64, cnt - c0);
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const int kidx = lane + 64 * j;
+        if (kidx < 144) {
+          const int c = kidx & 7, u = kidx >> 3, tap = u >> 1, cin = u & 1;
+          double a = accA[j];
+          for (int e2 = 0; e2 < ne; e2++) {
+            const FsEntry &R = ent[wv][e2];
+            const int kc = (R.kpack >> (2 * c)) & 3;
+            if ((R.pat[cin][kc] >> tap) & 1) a += (double)R.gv[c];
+          }
+          accA[j] = a;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
   }
 #pragma unroll
   for (int c = 0; c < C; c++) {
-    const double a = wave_sum(s1[c]), b2 = wave_sum(s2[c]);
-    if ((tid & 63) == 0) { red[tid >> 6][2 * c] = a; red[tid >> 6][2 * c + 1] = b2; }
+    const double a = wave_sum(s1[c]), b2 = wave_sum(s2[c]), d3 = wave_sum(s3[c]);
+    if (lane == 0) { red[wv][144 + c] = a; red[wv][152 + c] = b2; red[wv][160 + c] = d3; }
   }
+#pragma unroll
+  for (int j = 0; j < 3; j++)
+    if (lane + 64 * j < 144) red[wv][lane + 64 * j] = accA[j];
   __syncthreads();
-  if (tid < 2 * C) part[(size_t)blockIdx.x * 2 * C + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+  // part[block] = A as [tap][map][channel] (144), then sum g, sum g xhat, sum dp over the block's listed windows (8 each)
+  if (tid < FS_NV) part[(size_t)blockIdx.x * FS_NV + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
 }
 
-// A[tap][ci][co] = sum in_u g and sum g per co from the compact g: a wave owns an output channel, a lane a pooled pixel
-constexpr int B0_TR = 40;   // image rows of a tile (20 pooled rows x 50 pooled columns = 1000 windows)
-__global__ __launch_bounds__(512) void f_bw_first(int n, const uint32_t *__restrict__ bits, const float *__restrict__ gc,
-                                                  const unsigned char *__restrict__ kk, double *__restrict__ part) {
-  constexpr int TW = 100, LP = TW + 2, NA = 19, NPX = (B0_TR / 2) * (TW / 2), NGRP = (NPX + 63) / 64;
-  __shared__ float in[2][B0_TR + 2][LP];
-  __shared__ uint32_t wrow[2][B0_TR + 2][5];
-  __shared__ double dacc[8][NA];
-  const int tid = threadIdx.x, co = tid >> 6, lane = tid & 63;
-  int since = 0;
-  const int H = 400, W = 400, Hp = 200, Wp = 200, tx_n = W / TW, ty_n = H / B0_TR, per_s = tx_n * ty_n;
-  const long ntiles = (long)n * per_s;
-  float acc[NA];
-#pragma unroll
-  for (int k = 0; k < NA; k++) acc[k] = 0.f;
-  if (lane < NA) dacc[co][lane] = 0.0;
-  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const size_t s = tile / per_s;
-    const int t = (int)(tile - (long)s * per_s), y0 = (t / tx_n) * B0_TR, x0 = (t % tx_n) * TW;
-    __syncthreads();
-    // the tile's bit rows as words first (102 pixels of a row lie in at most 5 words), then one LDS word per pixel
-    for (int e = tid; e < 2 * (B0_TR + 2) * 5; e += 512) {
-      const int c = e / ((B0_TR + 2) * 5), rem = e - c * ((B0_TR + 2) * 5), yy = rem / 5, j = rem - 5 * yy;
-      const int y = y0 - 1 + yy;
-      uint32_t v = 0;
-      if (y >= 0 && y < H) {
-        const long b0 = 400L * y + x0 - 1;                 // bit position of the row's first tile pixel (column x0 - 1)
-        const int wi = (int)((b0 < 0 ? 0 : b0) >> 5) + j;
-        if (wi < 5000) v = bits[((size_t)s * 2 + c) * 5000 + wi];
-      }
-      wrow[c][yy][j] = v;
+// bpart[sample][co][8]: sums of the sample's dz plane (200 x 200) over its first / last row, first / last column, and its
+// four corners (0,0) (0,L) (L,0) (L,L); block = sample, wave = two channels
+__global__ __launch_bounds__(256) void f_first_border(int n, const float *__restrict__ dzn, double *__restrict__ bpart) {
+  constexpr int Hp = 200, Wp = 200;
+  const int s = blockIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int k = 0; k < 2; k++) {
+    const int co = 2 * wv + k;
+    const float *pl = dzn + ((size_t)s * 8 + co) * (Hp * Wp);
+    double r0 = 0.0, r1 = 0.0, c0 = 0.0, c1 = 0.0;
+    for (int i = lane; i < 200; i += 64) {
+      r0 += (double)pl[i];
+      r1 += (double)pl[(Hp - 1) * Wp + i];
+      c0 += (double)pl[i * Wp];
+      c1 += (double)pl[i * Wp + Wp - 1];
     }
-    __syncthreads();
-    for (int e = tid; e < 2 * (B0_TR + 2) * (TW + 2); e += 512) {
-      const int c = e / ((B0_TR + 2) * (TW + 2)), rem = e - c * ((B0_TR + 2) * (TW + 2));
-      const int yy = rem / (TW + 2), xx = rem - yy * (TW + 2);
-      const int y = y0 - 1 + yy, x = x0 - 1 + xx;
-      float v = 0.f;
-      if (y >= 0 && y < H && x >= 0 && x < W) {
-        const long b0 = 400L * y + x0 - 1, bp = 400L * y + x;
-        const int j = (int)(bp >> 5) - (int)((b0 < 0 ? 0 : b0) >> 5);
-        v = (float)((wrow[c][yy][j] >> (bp & 31)) & 1u);
-      }
-      in[c][yy][xx] = v;
+    r0 = wave_sum(r0); r1 = wave_sum(r1); c0 = wave_sum(c0); c1 = wave_sum(c1);
+    if (lane == 0) {
+      double *o = bpart + ((size_t)s * 8 + co) * 8;
+      o[0] = r0; o[1] = r1; o[2] = c0; o[3] = c1;
+      o[4] = (double)pl[0]; o[5] = (double)pl[Wp - 1]; o[6] = (double)pl[(Hp - 1) * Wp]; o[7] = (double)pl[Hp * Wp - 1];
     }
-    __syncthreads();
-    for (int grp = 0; grp < NGRP; grp++) {
-      const int p = 64 * grp + lane;
-      if (p < NPX) {
-        const int pr = p / (TW / 2), pc = p - pr * (TW / 2);
-        const size_t at = ((s * 8 + co) * (size_t)Hp + y0 / 2 + pr) * Wp + x0 / 2 + pc;
-        const float gv = gc[at];
-        const int k = kk[at];
-        const int yy = 2 * pr + (k >> 1), xx = 2 * pc + (k & 1);   // the window's maximum, tile coordinates of the pixel
-#pragma unroll
-        for (int tap = 0; tap < 9; tap++) {
-          acc[2 * tap] = fmaf(in[0][yy + tap / 3][xx + tap % 3], gv, acc[2 * tap]);
-          acc[2 * tap + 1] = fmaf(in[1][yy + tap / 3][xx + tap % 3], gv, acc[2 * tap + 1]);
-        }
-        acc[18] += gv;
-      }
-    }
-    // a flush every 4 tiles: 4000 windows = 64 fp32 terms per lane and sum
-    if (++since == 4) {
-      since = 0;
-#pragma unroll
-      for (int k = 0; k < NA; k++) {
-        const float v = wave_sum(acc[k]);
-        if (lane == 0) dacc[co][k] += (double)v;
-        acc[k] = 0.f;
-      }
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < NA; k++) {
-    const float v = wave_sum(acc[k]);
-    if (lane == 0) dacc[co][k] += (double)v;
-  }
-  __syncthreads();
-  // part[block] = A as [tap][ci][co] (144), then sum g [co] (8)
-  if (tid < 152) {
-    const int c = tid < 144 ? tid % 8 : tid - 144, u = tid < 144 ? tid / 8 : 18;
-    part[(size_t)blockIdx.x * 152 + tid] = dacc[c][u];
   }
 }
-// q[152] = A, sum g; cc[324] = the autocorrelation:  dw, db, dgamma, dbeta of the first layer (see above)
-__global__ void f_bw_first_finish(const double *q, const double *cc, const float *w, const float *b, const float *stat,
-                                  const float *gamma, const double *sums, double count, float *dw, float *db, float *dgamma,
-                                  float *dbeta) {
+
+// q[168] = A, and over the listed windows sum g, sum g xhat, sum dp; bsum[64] = the border sums of the second layer's dz;
+// cc[324] = the autocorrelation:  BatchNorm's sums of the first layer with the empty windows' share put back, then dw, db,
+// dgamma, dbeta (see "the first layer's weight gradient" above)
+__global__ __launch_bounds__(192) void f_first_bwd_finish(const double *q, const double *bsum, const float *wn,
+                                                          const float *lut_x, const double *cc, const float *w, const float *b,
+                                                          const float *stat, const float *gamma, const float *beta, double count,
+                                                          float *dw, float *db, float *dgamma, float *dbeta) {
+  __shared__ double sums[16];
   const int k = threadIdx.x;
+  if (k < 8) {
+    const int c = k;
+    // sum over ALL windows p of dp[c][p] = sum_{co, tap} w[tap][c][co] (sum of dz[co] over the cells q with q + d in the plane)
+    double all = 0.0;
+    for (int co = 0; co < 8; co++) {
+      const double *o = bsum + co * 8;
+      for (int t = 0; t < 9; t++) {
+        const int dy = t / 3 - 1, dx = t % 3 - 1;
+        double S = 0.0;   // the plane's total: zero (above)
+        if (dy == 1) S -= o[1]; else if (dy == -1) S -= o[0];
+        if (dx == 1) S -= o[3]; else if (dx == -1) S -= o[2];
+        if (dy != 0 && dx != 0) S += o[4 + (dy == 1 ? 2 : 0) + (dx == 1 ? 1 : 0)];
+        all += (double)wn[(t * 8 + c) * 8 + co] * S;
+      }
+    }
+    const double empty = all - q[160 + c];
+    const float xc = lut_x[c] + lut_x[512 * 8 + c];              // x-hat of a pixel with no bit around it, as the kernel forms it
+    const bool on = fmaxf(fmaf(gamma[c], xc, beta[c]), 0.f) > 0.f;
+    sums[2 * c] = q[144 + c] + (on ? empty : 0.0);
+    sums[2 * c + 1] = q[152 + c] + (on ? empty * (double)xc : 0.0);
+  }
+  __syncthreads();
   if (k < 144) {
     const int co = k % 8, u = k / 8;
     const double rs = 1.0 / sqrt((double)stat[2 * co + 1] + 1e-3), a = (double)gamma[co] * rs;
@@ -1484,6 +1502,7 @@ __global__ void f_bw_first_finish(const double *q, const double *cc, const float
     dgamma[co] = (float)sums[2 * co + 1];
   }
 }
+
 
 // ---------------------------------------------------------------- the top of head 2 for the textbook targets (ofx_dqn_fit)
 // One error per sample on the heat map: the loss reads o2 at ONE pixel (px, py) of a row and d o2 is non-zero there only.
@@ -1518,9 +1537,10 @@ __global__ void f_top_point_seed(int n, const ofx_transition *rows, const float 
   lpart[2 * s + 1] = e2 * e2 / (160000.f * n);
 }
 // block = sample: pw[s][73] = d U (the output convolution's weight-gradient share, then d for the bias); the 4 x 4 x 8 patch
-// of g (already zeroed elsewhere) and the sample's {sum g, sum g xhat} per channel in part[s][16]
+// of g - all of g that is not zero: gp[s][c][cell], read by f_bw<POINT> - and the sample's {sum g, sum g xhat} per channel
+// in part[s][16]
 __global__ __launch_bounds__(128) void f_top_point_bwd(int n, const ofx_transition *rows, FitSrc S, const float *w,
-                                                       const float *d2p, const float *stat, float *g, double *pw,
+                                                       const float *d2p, const float *stat, float *gp, double *pw,
                                                        double *part) {
   __shared__ float gv_[8][16], gx_[8][16];
   const int s = blockIdx.x, tid = threadIdx.x;
@@ -1559,8 +1579,8 @@ __global__ __launch_bounds__(128) void f_top_point_bwd(int n, const ofx_transiti
     const float zv = reinterpret_cast<const float *>(S.p)[at];
     gv = bn_act(zv, S.act[2 * c], S.act[2 * c + 1]) > 0.f ? da : 0.f;
     gx = gv * ((zv - stat[2 * c]) * rsqrtf(stat[2 * c + 1] + 1e-3f));
-    g[at] = gv;
   }
+  gp[((size_t)s * 8 + c) * 16 + cell] = gv;   // cells outside the plane: 0, never looked up
   gv_[c][cell] = gv;
   gx_[c][cell] = gx;
   __syncthreads();
@@ -1618,14 +1638,13 @@ int ofx_fit_pool_act(hipStream_t st, int n, int C, int H, int W, const float *z,
 }
 
 int ofx_fit_b1_pool(hipStream_t st, int n, int H, int W, int conv, const float *dzn, const float *wn, const float *z,
-                    const float *stat, const float *act, float *g, double *part, int *nblocks, unsigned char *kk) {
+                    const float *stat, const float *act, float *g, double *part, int *nblocks) {
   const int Hp = H / 2, Wp = W / 2;
   const long ntiles = (long)n * ((Hp + P_TR - 1) / P_TR) * ((Wp + P_TW - 1) / P_TW);
   const int grid = grid_for(ntiles, OFX_FIT_MAX_BLOCKS);
   *nblocks = grid;
-  if (conv == 2) hipLaunchKernelGGL((f_b1_pool<true, true>), dim3(grid), dim3(256), 0, st, n, H, W, dzn, wn, z, stat, act, g, part, kk);
-  else if (conv) hipLaunchKernelGGL(f_b1_pool<true>, dim3(grid), dim3(256), 0, st, n, H, W, dzn, wn, z, stat, act, g, part, kk);
-  else hipLaunchKernelGGL(f_b1_pool<false>, dim3(grid), dim3(256), 0, st, n, H, W, dzn, wn, z, stat, act, g, part, kk);
+  if (conv) hipLaunchKernelGGL(f_b1_pool<true>, dim3(grid), dim3(256), 0, st, n, H, W, dzn, wn, z, stat, act, g, part);
+  else hipLaunchKernelGGL(f_b1_pool<false>, dim3(grid), dim3(256), 0, st, n, H, W, dzn, wn, z, stat, act, g, part);
   OFX_HIP(hipGetLastError());
   return OFX_OK;
 }
@@ -1650,7 +1669,7 @@ int ofx_fit_b1_up(hipStream_t st, int n, int c, int con, int h, int w, int bn, c
 
 int ofx_fit_bw(hipStream_t st, int n, int ci, int co, int H, int W, const ofx_fit_src &src, int bn, float *g,
                const float *z, const float *stat, const float *gamma, const double *sums, double *part, float *dw,
-               float *db, float *dgamma, float *dbeta) {
+               float *db, float *dgamma, float *dbeta, const float *gpatch, const ofx_transition *rows) {
   const int TW = W >= 100 ? 100 : 50;
   if (W % TW) { ofx_set_error("ofx_dqn_fit: no weight-gradient tiling for %d x %d", H, W); return OFX_ERR_STATE; }
   int grid = 0;
@@ -1662,8 +1681,19 @@ int ofx_fit_bw(hipStream_t st, int n, int ci, int co, int H, int W, const ofx_fi
 #define BWK(CI_, CO_, SRC_, TW_, BN_, NT_, TR_) \
   if (!done && ci == CI_ && co == CO_ && src.kind == SRC_ && TW == TW_ && (bn != 0) == BN_) { \
     grid = grid_for((long)n * ((H + TR_ - 1) / TR_) * (W / TW), OFX_FIT_MAX_BLOCKS / 2); \
-    hipLaunchKernelGGL((f_bw<CI_, CO_, SRC_, TW_, BN_, NT_, TR_>), dim3(grid), dim3(NT_), 0, st, n, H, W, S, g, z, stat, gamma, sums, count, part); \
+    hipLaunchKernelGGL((f_bw<CI_, CO_, SRC_, TW_, BN_, NT_, TR_>), dim3(grid), dim3(NT_), 0, st, n, H, W, S, g, z, stat, gamma, sums, count, part, \
+                       (const float *)nullptr, (const ofx_transition *)nullptr); \
     done = true; }
+  if (gpatch) {   // g as one 4 x 4 patch per sample and channel (ofx_fit_top_point)
+    if (!(ci == 4 && co == 8 && src.kind == OFX_FIT_SRC_UP && TW == 100 && bn && rows)) {
+      ofx_set_error("ofx_dqn_fit: the patch form of g is built for the last head layer only");
+      return OFX_ERR_STATE;
+    }
+    grid = grid_for((long)n * ((H + OFX_FIT_BW_TR - 1) / OFX_FIT_BW_TR) * (W / TW), OFX_FIT_MAX_BLOCKS / 2);
+    hipLaunchKernelGGL((f_bw<4, 8, OFX_FIT_SRC_UP, 100, true, OFX_FIT_BW_NT, OFX_FIT_BW_TR, false, true>), dim3(grid),
+                       dim3(OFX_FIT_BW_NT), 0, st, n, H, W, S, g, z, stat, gamma, sums, count, part, gpatch, rows);
+    done = true;
+  }
   BWK(2, 8, OFX_FIT_SRC_BITS, 100, true, OFX_FIT_BW_NT, OFX_FIT_BW_TR)
   BWK(8, 8, OFX_FIT_SRC_POOL, 100, true, 512, 8)
   BWK(8, 8, OFX_FIT_SRC_POOL, 50, true, 512, 8)
@@ -1717,7 +1747,7 @@ int ofx_fit_out_bw(hipStream_t st, int n, const ofx_fit_src &src, const float *d
   const int grid = grid_for((long)n * ((200 + W_TR - 1) / W_TR) * 2, OFX_FIT_MAX_BLOCKS / 2);
   hipLaunchKernelGGL((f_bw<8, 4, OFX_FIT_SRC_ACTREP, 100, false, 512, 8, true>), dim3(grid), dim3(512), 0, st, n, 200, 200, S,
                      const_cast<float *>(d2), (const float *)nullptr, (const float *)nullptr, (const float *)nullptr,
-                     (const double *)nullptr, 1.0, part);
+                     (const double *)nullptr, 1.0, part, (const float *)nullptr, (const ofx_transition *)nullptr);
   hipLaunchKernelGGL(f_out_frame_bw, dim3(n), dim3(256), 0, st, n, S, d2, fpart);
   double *q = fpart + (size_t)n * 72, *fr = q + 292;      // behind the per-sample frame terms
   hipLaunchKernelGGL(f_sum_rows, dim3((292 + 15) / 16), dim3(256), 0, st, 292, grid, part, q);
@@ -1727,7 +1757,7 @@ int ofx_fit_out_bw(hipStream_t st, int n, const ofx_fit_src &src, const float *d
   return OFX_OK;
 }
 
-size_t ofx_fit_first_doubles(int n) { return (size_t)1024 * 324 + 324 + 152 + 0 * (size_t)n; }
+size_t ofx_fit_first_doubles(int n) { return (size_t)1024 * 324 + 324 + FS_NV + 64 + (size_t)n * 64; }   // correlation rows, cc, q, border sums + their per-sample rows
 size_t ofx_fit_first_floats(void) { return 2 * 8192; }
 // The first trunk layer's forward without its tensor: autocorrelation of the bit maps (cpart, kept for the backward) ->
 // batch statistics (stat, act) and the two tables (luts: ofx_fit_first_floats() floats) -> p0 = pool(relu(bn(conv1)))
@@ -1744,43 +1774,34 @@ int ofx_fit_first_fwd(ofx_handle *h, int n, const void *bits, const float *w, co
   OFX_HIP(hipGetLastError());
   return ofx_launch_conv1_lut(h, bits, n, luts, p0);
 }
-// g0 compact (gc, kk) + the BatchNorm-backward sums of the first layer from the second layer's dz (dzn, kernel wn)
-int ofx_fit_b1_first(hipStream_t st, int n, const void *bits, const float *dzn, const float *wn, const float *luts,
-                     const float *gamma, const float *beta, float *gc, unsigned char *kk, double *part, int *nblocks) {
-  const int grid = grid_for((long)n * (200 / P_TR) * (200 / P_TW), OFX_FIT_MAX_BLOCKS);
-  *nblocks = grid;
-  hipLaunchKernelGGL(f_b1_first, dim3(grid), dim3(256), 0, st, n, (const uint32_t *)bits, dzn, wn, luts + 8192, gamma, beta, gc, kk, part);
-  OFX_HIP(hipGetLastError());
-  return OFX_OK;
-}
-// dw / db / dgamma / dbeta of the first trunk layer from the compact g (gc, kk), the 1-bit maps, the autocorrelation in
-// cpart (ofx_fit_first_fwd) and the layer's own weights
-int ofx_fit_bw_first(hipStream_t st, int n, const void *bits, const float *gc, const unsigned char *kk, const float *w,
-                     const float *b, const float *stat, const float *gamma, const double *sums, double *part,
-                     double *cpart, float *dw, float *db, float *dgamma, float *dbeta) {
-  double *cc = cpart + (size_t)1024 * 324, *q = cc + 324;
-  const int grid = grid_for((long)n * (400 / B0_TR) * 4, OFX_FIT_MAX_BLOCKS / 2);
-  hipLaunchKernelGGL(f_bw_first, dim3(grid), dim3(512), 0, st, n, (const uint32_t *)bits, gc, kk, part);
-  hipLaunchKernelGGL(f_sum_rows, dim3((152 + 15) / 16), dim3(256), 0, st, 152, grid, part, q);
-  hipLaunchKernelGGL(f_bw_first_finish, dim3(1), dim3(192), 0, st, q, cc, w, b, stat, gamma, sums, (double)n * 160000.0, dw, db,
-                     dgamma, dbeta);
+// The first trunk layer's backward from the second layer's dz (dzn [n][8][200][200] out of BatchNorm's backward, kernel wn):
+// dw / db / dgamma / dbeta; cpart as left by ofx_fit_first_fwd
+int ofx_fit_first_bwd(hipStream_t st, int n, const void *bits, const float *dzn, const float *wn, const float *luts, const float *w, const float *b, const float *stat, const float *gamma,
+                      const float *beta, double *part, double *cpart, float *dw, float *db, float *dgamma, float *dbeta) {
+  double *cc = cpart + (size_t)1024 * 324, *q = cc + 324, *bsum = q + FS_NV, *bpart = bsum + 64;
+  const int grid = grid_for((long)n * (200 / FS_BR), OFX_FIT_MAX_BLOCKS);
+  hipLaunchKernelGGL(f_first_border, dim3(n), dim3(256), 0, st, n, dzn, bpart);
+  hipLaunchKernelGGL(f_sum_rows, dim3((64 + 15) / 16), dim3(256), 0, st, 64, n, bpart, bsum);
+  hipLaunchKernelGGL(f_first_bwd, dim3(grid), dim3(256), 0, st, n, (const uint32_t *)bits, dzn, wn, luts + 8192, gamma, beta, part);
+  hipLaunchKernelGGL(f_sum_rows, dim3((FS_NV + 15) / 16), dim3(256), 0, st, FS_NV, grid, part, q);
+  hipLaunchKernelGGL(f_first_bwd_finish, dim3(1), dim3(192), 0, st, q, bsum, wn, luts + 8192, cc, w, b, stat, gamma, beta,
+                     (double)n * 160000.0, dw, db, dgamma, dbeta);
   OFX_HIP(hipGetLastError());
   return OFX_OK;
 }
 
 size_t ofx_fit_point_doubles(int n) { return (size_t)n * (73 + 16); }
 // The top of head 2 for one error per sample (ofx_dqn_fit): o2 at the pointer (o2p [n]), the seeds of both heads (do1, d2p [n],
-// lpart [2 n]), the output convolution's dw / db, g of the last head layer (g, zeroed here, + its BatchNorm sums in `sums`);
-// scratch: ofx_fit_point_doubles(n) doubles
+// lpart [2 n]), the output convolution's dw / db, g of the last head layer as its 4 x 4 patch per sample and channel (gpatch
+// [n][8][16], for ofx_fit_bw's gpatch argument; + its BatchNorm sums in `sums`); scratch: ofx_fit_point_doubles(n) doubles
 int ofx_fit_top_point(hipStream_t st, int n, const ofx_transition *rows, const ofx_fit_src &src, const float *w, const float *b,
                       const float *o1, const float *y_act, const float *y_ptr, const float *stat, float *o2p, float *do1,
-                      float *d2p, float *lpart, float *g, double *scratch, double *sums, float *dw, float *db) {
+                      float *d2p, float *lpart, float *gpatch, double *scratch, double *sums, float *dw, float *db) {
   const FitSrc S = dev_src(src);
   double *pw = scratch, *part = scratch + (size_t)n * 73;
-  OFX_HIP(hipMemsetAsync(g, 0, sizeof(float) * (size_t)n * 8 * 40000, st));
   hipLaunchKernelGGL(f_top_point_fwd, dim3((n + 63) / 64), dim3(64), 0, st, n, rows, S, w, b, o2p);
   hipLaunchKernelGGL(f_top_point_seed, dim3((n + 255) / 256), dim3(256), 0, st, n, rows, o1, o2p, y_act, y_ptr, do1, d2p, lpart);
-  hipLaunchKernelGGL(f_top_point_bwd, dim3(n), dim3(128), 0, st, n, rows, S, w, d2p, stat, g, pw, part);
+  hipLaunchKernelGGL(f_top_point_bwd, dim3(n), dim3(128), 0, st, n, rows, S, w, d2p, stat, gpatch, pw, part);
   hipLaunchKernelGGL(f_bw_finish, dim3((73 + 15) / 16), dim3(256), 0, st, 73, 72, n, pw, dw, db, 0, (const double *)nullptr,
                      (float *)nullptr, (float *)nullptr);
   hipLaunchKernelGGL(f_finish, dim3(1), dim3(256), 0, st, n, 8, 1.0, part, (const float *)nullptr, (const float *)nullptr, sums,

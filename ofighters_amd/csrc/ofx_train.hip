@@ -634,16 +634,16 @@ static int dqn_fit_lean(ofx_handle *h, float *weights, float *adam_m, float *ada
   static const int tS[4] = {400, 200, 100, 50}, uS[3] = {50, 100, 200};
   size_t need = 0;
   auto sz = [&](size_t bytes) { need += (bytes + 255) & ~(size_t)255; };
-  for (int i = 0; i < 4; i++) { if (i) sz(4 * N * 8 * tS[i] * tS[i]); sz(4 * N * 8 * tS[i] * tS[i] / (i ? 1 : 4)); }  // z (not layer 0's), g (layer 0: compact)
+  for (int i = 1; i < 4; i++) { sz(4 * N * 8 * tS[i] * tS[i]); sz(4 * N * 8 * tS[i] * tS[i]); }  // z, g (layer 0 has neither)
   sz(4 * ofx_fit_first_floats()); sz(4 * 5008 * 100);
-  sz(N * 8 * 40000); sz(8 * ofx_fit_first_doubles(n));                                                     // window positions, correlation
+  sz(8 * ofx_fit_first_doubles(n));                                                                        // correlation, first-layer backward
   for (int i = 0; i < 3; i++) sz(4 * N * 8 * tS[i + 1] * tS[i + 1]);                                       // pooled activation
   for (int j = 0; j < 3; j++) { sz(4 * N * kUO[j] * uS[j] * uS[j]); sz(4 * N * kUO[j] * uS[j] * uS[j]); }
   sz(4 * N * 160000); sz(4 * N * 160000);                                                                  // o2, do2
   sz(4 * N * 5000); sz(4 * N * 5008); sz(4 * N * 100); sz(4 * N * 50); sz(4 * N * 2); sz(4 * N * 625);      // p3 f d1 d2 o1 u0
   sz(4 * N * 625); sz(4 * N * 2); sz(4 * N * 100); sz(4 * N * 50); sz(4 * N * 5008); sz(4 * N * 5000);      // gu0 do1 dd1 dd2 df dp3
   sz(4 * (size_t)L.n_floats); sz(4 * 64); sz(4 * (2 * N + 4096)); sz(8 * ofx_fit_part_doubles()); sz(8 * 32);
-  sz(4 * ofx_fit_out_floats()); sz(8 * ofx_fit_out_doubles(n)); sz(8 * ofx_fit_point_doubles(n));
+  sz(4 * ofx_fit_out_floats()); sz(8 * ofx_fit_out_doubles(n)); sz(8 * ofx_fit_point_doubles(n)); sz(4 * N * 128);
   for (int k = 0; k < 7; k++) { sz(4 * 32); sz(4 * 16); }   // stat (+ the mean's low parts), act
   if ((rc = keep_workspace(h, &h->fitws, &h->fitws_bytes, need))) return rc;
   Arena A{(char *)h->fitws, 0, need};
@@ -657,11 +657,11 @@ static int dqn_fit_lean(ofx_handle *h, float *weights, float *adam_m, float *ada
   double *part = A.d(ofx_fit_part_doubles()), *sums = A.d(32);
   float *weff = A.f(ofx_fit_out_floats());
   double *fpart = A.d(ofx_fit_out_doubles(n)), *pscratch = A.d(ofx_fit_point_doubles(n));
+  float *gpatch = A.f(N * 128);   // textbook targets: all of the last head layer's g that is not zero
   float *tz[4], *tg[4], *tstat[4], *tact[4], *uz[3], *ug[3], *ustat[3], *uact[3], *tp[3];
   for (int i = 0; i < 3; i++) tp[i] = A.f(N * 8 * tS[i + 1] * tS[i + 1]);
-  for (int i = 0; i < 4; i++) { tz[i] = i ? A.f(N * 8 * tS[i] * tS[i]) : nullptr; tg[i] = A.f(N * 8 * tS[i] * tS[i] / (i ? 1 : 4)); tstat[i] = A.f(32); tact[i] = A.f(16); }
+  for (int i = 0; i < 4; i++) { tz[i] = i ? A.f(N * 8 * tS[i] * tS[i]) : nullptr; tg[i] = i ? A.f(N * 8 * tS[i] * tS[i]) : nullptr; tstat[i] = A.f(32); tact[i] = A.f(16); }
   float *luts = A.f(ofx_fit_first_floats()), *w1t = A.f(5008 * 100);
-  unsigned char *kk0 = (unsigned char *)A.take(N * 8 * 40000);
   double *cpart = A.d(ofx_fit_first_doubles(n));
   for (int j = 0; j < 3; j++) { uz[j] = A.f(N * kUO[j] * uS[j] * uS[j]); ug[j] = A.f(N * kUO[j] * uS[j] * uS[j]); ustat[j] = A.f(32); uact[j] = A.f(16); }
   float *o2 = A.f(N * 160000), *do2 = A.f(N * 160000);
@@ -708,7 +708,7 @@ static int dqn_fit_lean(ofx_handle *h, float *weights, float *adam_m, float *ada
     // one error per sample on the heat map: the output convolution at the pointer only, its gradients and the last head
     // layer's g from that one pixel (ofx_fit.hip, "the top of head 2 for the textbook targets")
     float *o2p = o2, *d2p = o2 + N;                          // [n] each: the dense planes are not used on this path
-    if ((rc = ofx_fit_top_point(st, n, rows, head_src(3), T(50), T(51), o1, y_act, y_ptr, ustat[2], o2p, do1, d2p, lpart, ug[2],
+    if ((rc = ofx_fit_top_point(st, n, rows, head_src(3), T(50), T(51), o1, y_act, y_ptr, ustat[2], o2p, do1, d2p, lpart, gpatch,
                                 pscratch, sums, G(50), G(51)))) return rc;
     hipLaunchKernelGGL(t_sum_ordered, dim3(1), dim3(64), 0, st, n, 2, lpart, loss);
     OFX_HIP(hipGetLastError());
@@ -730,8 +730,10 @@ static int dqn_fit_lean(ofx_handle *h, float *weights, float *adam_m, float *ada
       if ((rc = ofx_fit_b1_up(st, n, kUO[j], kUO[j + 1], s, s, 1, dzn, T(32 + 6 * (j + 1)), uz[j], ustat[j], uact[j], legacy, ug[j], part, &nb))) return rc;
       if ((rc = ofx_fit_finish(st, nb, kUO[j], 1.0, part, nullptr, nullptr, sums, nullptr, nullptr))) return rc;
     }
+    const bool patch = j == 2 && !dense;   // (g of the last layer is a 4 x 4 patch per sample there: not read, dz written)
     if ((rc = ofx_fit_bw(st, n, kUI[j], kUO[j], s, s, head_src(j), 1, ug[j], uz[j], ustat[j], T(34 + 6 * j), sums, part,
-                         G(32 + 6 * j), G(33 + 6 * j), G(34 + 6 * j), G(35 + 6 * j)))) return rc;
+                         G(32 + 6 * j), G(33 + 6 * j), G(34 + 6 * j), G(35 + 6 * j), patch ? gpatch : nullptr,
+                         patch ? rows : nullptr))) return rc;
     dzn = ug[j];
   }
   if ((rc = ofx_fit_b1_up(st, n, 1, 2, 25, 25, 0, dzn, T(32), u0, nullptr, nullptr, legacy, gu0, part, &nb))) return rc;
@@ -755,16 +757,14 @@ static int dqn_fit_lean(ofx_handle *h, float *weights, float *adam_m, float *ada
   dzn = dp3;
   for (int i = 3; i >= 0; i--) {
     const int s = tS[i];
-    // the first layer's g is kept compact (one value + a window position per 2 x 2 window) and its weight gradient needs
-    // neither z0 nor dz0 (ofx_fit.hip, f_bw_first)
-    if (i == 0) rc = ofx_fit_b1_first(st, n, bits_prev, dzn, T(6), luts, T(2), T(3), tg[0], kk0, part, &nb);
-    else rc = ofx_fit_b1_pool(st, n, s, s, i < 3, dzn, i < 3 ? T(6 * (i + 1)) : nullptr, tz[i], tstat[i], tact[i], tg[i], part, &nb);
-    if (rc) return rc;
-    if ((rc = ofx_fit_finish(st, nb, 8, 1.0, part, nullptr, nullptr, sums, nullptr, nullptr))) return rc;
     if (i == 0) {
-      if ((rc = ofx_fit_bw_first(st, n, bits_prev, tg[0], kk0, T(0), T(1), tstat[0], T(2), sums, part, cpart, G(0), G(1), G(2), G(3)))) return rc;
+      // the first layer: neither z0, g0 nor dz0 exist; only the windows that see a set bit are visited (ofx_fit.hip, f_first_bwd)
+      if ((rc = ofx_fit_first_bwd(st, n, bits_prev, dzn, T(6), luts, T(0), T(1), tstat[0], T(2), T(3), part, cpart,
+                                  G(0), G(1), G(2), G(3)))) return rc;
       break;
     }
+    if ((rc = ofx_fit_b1_pool(st, n, s, s, i < 3, dzn, i < 3 ? T(6 * (i + 1)) : nullptr, tz[i], tstat[i], tact[i], tg[i], part, &nb))) return rc;
+    if ((rc = ofx_fit_finish(st, nb, 8, 1.0, part, nullptr, nullptr, sums, nullptr, nullptr))) return rc;
     if ((rc = ofx_fit_bw(st, n, kTI[i], 8, s, s, trunk_src(i, true), 1, tg[i], tz[i], tstat[i], T(6 * i + 2), sums, part,
                          G(6 * i), G(6 * i + 1), G(6 * i + 2), G(6 * i + 3)))) return rc;
     dzn = tg[i];

@@ -442,32 +442,10 @@ def _fit_once(b, kind, w, n, rows_d, bp_d, bn_d, y, y2, bufs):
     return l, g_d.download(np.float32, w.shape), w_d.download(np.float32, w.shape)
 
 
-@pytest.mark.parametrize("rows,skip", [(128, 0), (1024, 4), (1024, 0)])
-def test_lean_fit_equals_plain_fit_large_batches(rows, skip):
-    """lean == plain at 128 rows (every persistent kernel past its first tile: f_conv_fwd at 200x200 loops from 52 rows,
-    f_b1_pool / f_b1_up / f_b1_first / f_bw_first / f_bits_corr from 26 - 110) and at 1024 rows (the bench's regime; the
-    plain form holds 62 GB of workspace there), textbook and reference targets: the per-tensor bounds of
-    test_lean_fit_equals_plain_fit, equal moved statistics, and two lean runs give the same bits.
-
-    (1024, 0) - rows 0 .. 1023 of the collection - is the one minibatch found in r04 on which the two forms differ by more
-    than fp32 summation order in the textbook form: conv1.kernel 4.6e-4, conv1.gamma 1.1e-3, conv2.kernel 6.8e-4 of their
-    scales.  It is THAT set of rows, not the size: every window of the same collection shifted by 1, 4, 512, 1000 or 1024
-    rows, every prefix up to 1023 and the 2048-row batch agree to <= 1e-4 (tools/fit_bisect.py, profiles/r04_fit_bisect.txt);
-    against torch float64 the plain form sits at 9e-6 there and the lean form carries the difference
-    (tools/fit_check64.py, profiles/r04_fit_check64_1024.txt); carrying BatchNorm-backward's per-channel coefficients as
-    float pairs changed nothing.  The first layer's values come out of a 512-entry table per channel, so a near-tie that
-    the two forms round differently (a max-pool arg-max, a ReLU gate) flips for every window of that bit pattern at once -
-    a discontinuity of the function itself that any fp32 evaluation resolves one way or the other.  That case keeps the
-    strict bound everywhere except the three tensors named, which get 2e-3; (1024, 4) is the strict case at the same size."""
+def _check_lean_equals_plain(b, n, rows_d, bp_d, bn_d, loose=frozenset(), loose_both=frozenset()):
+    """Both forms of the fit on one minibatch, textbook and reference targets: the per-tensor bounds of
+    test_lean_fit_equals_plain_fit, equal moved statistics, and two lean runs give the same bits."""
     from ofighters_amd import DeviceBuffer, _native as nat
-    b, n_all, rows_all, bp_all, bn_all = _collect_minibatch((rows + skip + 3) // 4)
-    n = rows
-    assert n_all >= n + skip
-
-    class _Off:                     # the window [skip, skip + rows) of the gathered minibatch
-        def __init__(self, buf, stride): self.ptr = buf.ptr + skip * stride
-    rows_d, bp_d, bn_d = _Off(rows_all, b.TRANSITION_DTYPE.itemsize), _Off(bp_all, 40000), _Off(bn_all, 40000)
-    loose = {"conv1.kernel", "conv1.gamma", "conv1.beta", "conv2.kernel", "conv2.beta"} if (rows, skip) == (1024, 0) else set()
     w, shapes = pyoracle.policy_init(5, trained_like=True)
     rs = np.random.RandomState(3)
     y = DeviceBuffer(4 * n).upload(rs.uniform(-1, 2, n).astype(np.float32))
@@ -500,11 +478,70 @@ def test_lean_fit_equals_plain_fit_large_batches(rows, skip):
                 # gradient, not compared element by element
                 lean_scale = float(np.abs(ga[o:o + c]).max())
                 assert max(scale, lean_scale) <= 2e-4 * kscale, (kind, name, scale, lean_scale, kscale)
-                if layer == "conv1":        # the first layer's is written as the exact zero (f_bw_first)
+                if layer == "conv1":        # the first layer's is written as the exact zero (f_first_bwd_finish)
                     assert lean_scale == 0.0, (kind, name)
-            elif err > (2e-3 if (name in loose and kind == "textbook") else 1e-4) * scale + 5e-5 * kscale:
+            elif err > (2e-3 if ((name in loose and kind == "textbook") or name in loose_both) else 1e-4) * scale + 5e-5 * kscale:
                 bad.append((name, scale, err))
         assert not bad, (kind, n, bad)
+
+
+@pytest.mark.parametrize("rows,skip", [(128, 0), (1024, 4), (1024, 0)])
+def test_lean_fit_equals_plain_fit_large_batches(rows, skip):
+    """lean == plain at 128 rows (every persistent kernel past its first tile: f_conv_fwd at 200x200 loops from 52 rows,
+    f_b1_pool / f_b1_up / f_first_bwd / f_bits_corr from 26 - 205) and at 1024 rows (the bench's regime; the
+    plain form holds 62 GB of workspace there), textbook and reference targets: the per-tensor bounds of
+    test_lean_fit_equals_plain_fit, equal moved statistics, and two lean runs give the same bits.
+
+    (1024, 0) - rows 0 .. 1023 of the collection - is the one minibatch found in r04 on which the two forms differ by more
+    than fp32 summation order in the textbook form: conv1.kernel 4.6e-4, conv1.gamma 1.1e-3, conv2.kernel 6.8e-4 of their
+    scales.  It is THAT set of rows, not the size: every window of the same collection shifted by 1, 4, 512, 1000 or 1024
+    rows, every prefix up to 1023 and the 2048-row batch agree to <= 1e-4 (tools/fit_bisect.py, profiles/r04_fit_bisect.txt);
+    against torch float64 the plain form sits at 9e-6 there and the lean form carries the difference
+    (tools/fit_check64.py, profiles/r04_fit_check64_1024.txt); carrying BatchNorm-backward's per-channel coefficients as
+    float pairs changed nothing.  The first layer's values come out of a 512-entry table per channel, so a near-tie that
+    the two forms round differently (a max-pool arg-max, a ReLU gate) flips for every window of that bit pattern at once -
+    a discontinuity of the function itself that any fp32 evaluation resolves one way or the other.  That case keeps the
+    strict bound everywhere except the three tensors named, which get 2e-3; (1024, 4) is the strict case at the same size."""
+    from ofighters_amd import DeviceBuffer, _native as nat
+    b, n_all, rows_all, bp_all, bn_all = _collect_minibatch((rows + skip + 3) // 4)
+    n = rows
+    assert n_all >= n + skip
+
+    class _Off:                     # the window [skip, skip + rows) of the gathered minibatch
+        def __init__(self, buf, stride): self.ptr = buf.ptr + skip * stride
+    rows_d, bp_d, bn_d = _Off(rows_all, b.TRANSITION_DTYPE.itemsize), _Off(bp_all, 40000), _Off(bn_all, 40000)
+    loose = {"conv1.kernel", "conv1.gamma", "conv1.beta", "conv2.kernel", "conv2.beta"} if (rows, skip) == (1024, 0) else set()
+    _check_lean_equals_plain(b, n, rows_d, bp_d, bn_d, loose)
+    b.close()
+
+
+@pytest.mark.parametrize("case", ["dense", "half", "full", "frame"])
+def test_lean_fit_on_maps_without_empty_windows(case):
+    """The first layer's backward (f_first_bwd) visits only the 2 x 2 windows that see a set bit and takes the empty ones'
+    share from border sums of the second layer's dz.  Arena observations leave ~97 % of the windows empty; here NONE is
+    (30 % of the cells set; 60 % and 50 %), one half of the plane is and the other is not (the border
+    terms with both kinds of window on the frame), or only the plane's frame is set - same bounds against the plain form."""
+    b, n, rows_d, bp_d, bn_d = _collect_minibatch(3)
+    rs = np.random.RandomState(11)
+    for buf in (bp_d, bn_d):
+        x = np.zeros((n, 2, 400, 400), bool)
+        if case == "dense":
+            x[:, 0] = rs.uniform(size=(n, 400, 400)) < 0.3
+            x[:, 1] = rs.uniform(size=(n, 400, 400)) < 0.05
+        elif case == "half":
+            x[:, 0, :, :200] = rs.uniform(size=(n, 400, 200)) < 0.3
+            x[:, 1, 200:, :] = rs.uniform(size=(n, 200, 400)) < 0.02
+        elif case == "full":      # (every cell of a map set is degenerate: one table entry for 158 404 pixels of a plane,
+            x[:, 0] = rs.uniform(size=(n, 400, 400)) < 0.6     # every pooling window a four-way tie - both forms resolve it,
+            x[:, 1] = rs.uniform(size=(n, 400, 400)) < 0.5     # not the same way: conv2's own gradient moves by 1e-3 there)
+        else:
+            x[:, 0, [0, 399], :] = True
+            x[:, 0, :, [0, 399]] = True
+            x[:, 1, 100:300, 100:300] = rs.uniform(size=(n, 200, 200)) < 0.01
+        buf.upload(np.packbits(x.reshape(n, 2, 160000), axis=-1, bitorder="little").view(np.uint32))
+    # updense1: one ReLU gate of u0 that the two forms may decide differently on synthetic maps (the allowance of the float64
+    # comparisons above, tools/fit_precision.py) - this test is about the trunk's first layers
+    _check_lean_equals_plain(b, n, rows_d, bp_d, bn_d, loose_both={"updense1.kernel", "updense1.bias"})
     b.close()
 
 
