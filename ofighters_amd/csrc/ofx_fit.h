@@ -44,10 +44,14 @@ struct ofx_handle;
 // the first trunk layer without its tensor z0 (see ofx_fit.hip "the first layer is never materialised")
 int ofx_fit_first_fwd(ofx_handle *h, int n, const void *bits, const float *w, const float *b, const float *gamma,
                       const float *beta, double *cpart, float *stat, float *act, float *luts, float *p0);
-// its backward from the second layer's dz (dzn, out of BatchNorm's backward; kernel wn): only the 2 x 2 windows that see a
-// set bit are visited
-int ofx_fit_first_bwd(hipStream_t st, int n, const void *bits, const float *dzn, const float *wn, const float *luts, const float *w, const float *b, const float *stat, const float *gamma,
-                      const float *beta, double *part, double *cpart, float *dw, float *db, float *dgamma, float *dbeta);
+// the backward of the first TWO layers (ofx_fit.hip "... over the windows that see a set bit"): g1 / sums1 from
+// ofx_fit_b1_pool + ofx_fit_finish of the second layer; its dz is never stored.  part: ofx_fit_first_part_doubles(n) doubles
+size_t ofx_fit_first_part_doubles(int n);
+int ofx_fit_first_bwd(hipStream_t st, int n, const void *bits, const float *g1, const float *z1, const float *stat1,
+                      const float *gamma1, const double *sums1, const float *wn, const float *p0, const float *luts,
+                      const float *w, const float *b, const float *stat, const float *gamma, const float *beta, double *part,
+                      double *cpart, float *dw, float *db, float *dgamma, float *dbeta, float *dw2, float *db2, float *dgamma2,
+                      float *dbeta2);
 // the same through the x2 up-sampling in front of a convolution with `con` output channels at 2h x 2w
 int ofx_fit_b1_up(hipStream_t st, int n, int c, int con, int h, int w, int bn, const float *dzn, const float *wn,
                   const float *zp, const float *stat, const float *act, int legacy, float *g, double *part, int *nblocks);

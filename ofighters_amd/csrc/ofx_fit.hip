@@ -1158,41 +1158,45 @@ __global__ void f_out_bw_finish(const double *q, const double *fr, int legacy, f
 constexpr int C0_ROWS = 40;   // rows of a correlation chunk
 // part[block][324]: Cc over the block's rows of one sample; block = 384 threads, thread q < 324 owns the pair (q / 18, q % 18)
 __global__ __launch_bounds__(384) void f_bits_corr(int n, const uint32_t *__restrict__ bits, double *__restrict__ part) {
-  __shared__ uint32_t ver[18][13];   // the 18 shifted versions of image row y: bit x of version u = in_u at pixel (y, x)
+  constexpr int RB = 8;              // image rows per barrier pair (one row at a time the kernel was all barrier: 1.54 ms per 4096 rows)
+  static_assert(C0_ROWS % RB == 0, "rows per step");
+  __shared__ uint32_t ver[RB][18][13];   // the 18 shifted versions of an image row: bit x of version u = in_u at pixel (y, x)
   const int tid = threadIdx.x, ua = tid / 18, ub = tid - 18 * ua, nchunks = n * (400 / C0_ROWS);
   int acc = 0;   // at most (chunks per block) x 40 x 400 < 2^31
   for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-  const int s = chunk / (400 / C0_ROWS), y0 = (chunk % (400 / C0_ROWS)) * C0_ROWS;
-  for (int y = y0; y < y0 + C0_ROWS; y++) {
-    __syncthreads();
-    for (int e = tid; e < 18 * 13; e += 384) {
-      const int u = e / 13, wd = e - 13 * u, tap = u >> 1, ci = u & 1, r = y + tap / 3 - 1, dx = tap % 3 - 1;
-      uint32_t v = 0;
-      if (r >= 0 && r < 400) {
-        const uint32_t *pl = bits + ((size_t)s * 2 + ci) * 5000;
-        const int x0 = 32 * wd + dx;                     // plane column of the version's bit 0 of this word
-        const long b0 = 400L * r + x0;                   // its bit position in the plane (may be -1 at x0 = -1)
-        const long bb = b0 < 0 ? 0 : b0;
-        const int wi = (int)(bb >> 5), sh = (int)(bb & 31);
-        const uint32_t lo = pl[wi], hi = wi + 1 < 5000 ? pl[wi + 1] : 0u;
-        v = sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
-        if (b0 < 0) v <<= 1;                             // column -1 does not exist: bit 0 of the word is pixel column 0's left
-        // keep the bits whose column x0 + b lies in [0, 400)
-        uint32_t m = 0xFFFFFFFFu;
-        if (x0 < 0) m &= ~1u;
-        const int over = x0 + 32 - 400;
-        if (over > 0) m &= over >= 32 ? 0u : (0xFFFFFFFFu >> over);
-        if (wd == 12) m &= 0xFFFFu;                      // ... and whose OUTPUT pixel 32 wd + b lies in the row (400 = 12.5 words)
-        v &= m;
+    const int s = chunk / (400 / C0_ROWS), y0 = (chunk % (400 / C0_ROWS)) * C0_ROWS;
+    for (int yb = y0; yb < y0 + C0_ROWS; yb += RB) {
+      __syncthreads();
+      for (int e = tid; e < RB * 18 * 13; e += 384) {
+        const int wd = e % 13, u = (e / 13) % 18, y = yb + e / (18 * 13), tap = u >> 1, ci = u & 1, r = y + tap / 3 - 1, dx = tap % 3 - 1;
+        uint32_t v = 0;
+        if (r >= 0 && r < 400) {
+          const uint32_t *pl = bits + ((size_t)s * 2 + ci) * 5000;
+          const int x0 = 32 * wd + dx;                     // plane column of the version's bit 0 of this word
+          const long b0 = 400L * r + x0;                   // its bit position in the plane (may be -1 at x0 = -1)
+          const long bb = b0 < 0 ? 0 : b0;
+          const int wi = (int)(bb >> 5), sh = (int)(bb & 31);
+          const uint32_t lo = pl[wi], hi = wi + 1 < 5000 ? pl[wi + 1] : 0u;
+          v = sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
+          if (b0 < 0) v <<= 1;                             // column -1 does not exist: bit 0 of the word is pixel column 0's left
+          // keep the bits whose column x0 + b lies in [0, 400)
+          uint32_t m = 0xFFFFFFFFu;
+          if (x0 < 0) m &= ~1u;
+          const int over = x0 + 32 - 400;
+          if (over > 0) m &= over >= 32 ? 0u : (0xFFFFFFFFu >> over);
+          if (wd == 12) m &= 0xFFFFu;                      // ... and whose OUTPUT pixel 32 wd + b lies in the row (400 = 12.5 words)
+          v &= m;
+        }
+        ver[e / (18 * 13)][u][wd] = v;
       }
-      ver[u][wd] = v;
-    }
-    __syncthreads();
-    if (tid < 324) {
+      __syncthreads();
+      if (tid < 324) {
 #pragma unroll
-      for (int wd = 0; wd < 13; wd++) acc += __popc(ver[ua][wd] & ver[ub][wd]);
+        for (int k = 0; k < RB; k++)
+#pragma unroll
+          for (int wd = 0; wd < 13; wd++) acc += __popc(ver[k][ua][wd] & ver[k][ub][wd]);
+      }
     }
-  }
   }
   if (tid < 324) part[(size_t)blockIdx.x * 324 + tid] = (double)acc;
 }
@@ -1238,248 +1242,349 @@ __global__ __launch_bounds__(256) void f_first_prepare(const double *cc, const f
   }
 }
 
-// ---- the first layer's backward over the windows that see a set bit --------------------------------------------------------
-// g0 = d loss / d (BatchNorm output of layer 0) is the transposed convolution of the second layer's dz pushed back through the
-// pooling - and layer 0 reads 1-bit maps that are ~1 % set.  A 2 x 2 window whose 4 x 4 bit neighbourhood is EMPTY in both
-// maps has z0 = b at its four pixels: the same x-hat xc, the same activation ac, its first pixel as the maximum, and no input
-// under any tap of that pixel.  So such a window adds nothing to A = sum in_u g, and to BatchNorm's sums it adds
-// [ac > 0] dp and [ac > 0] xc dp, where dp is the transposed convolution at the window.  The sum of dp over ALL windows is
-// linear in sums of dz over the plane with a border row / column left out.  The batch total of dz itself is ZERO: the second
-// layer's dz comes out of BatchNorm's backward, dz = a (g - mean g - xhat mean(g xhat)), which sums to zero per channel; what
-// the stored fp32 values sum to is rounding noise (taking their exact total in doubles instead gives the same test results;
-// the float total the weight-gradient kernel has for the bias moved conv1's beta gradient by 7e-4 of its scale - r04).  So
-//   sum over all windows of dp = - sum_{co, tap} w (the border row / column / corner the tap shifts out)      (f_first_border)
-//   sum over the empty windows of dp = (sum over all) - (sum over the windows that see a bit),
-// and only the windows that see a bit are evaluated: ~2.5 % of them on arena observations (every window on a dense map -
-// the result is the same, only the time differs).  The 94 GMAC of the dense transposed convolution per 4096 rows, the
-// compact g0 (1.6 MB per row written and read back) and a kernel of its own for A are gone.
-// Per band of 20 pooled rows: the bit rows in LDS, every wave classifies its 5 rows x 200 windows into a list (ballot order:
-// fixed), walks the list 64 windows at a time (dz straight from global memory: the windows cluster), and adds A from the
-// 64 records it leaves in LDS, (tap, map, channel) per lane, in list order.
-constexpr int FS_BR = 20, FS_WR = FS_BR / 4, FS_NW = FS_WR * 200, FS_ROWS = 2 * FS_BR + 2, FS_WORDS = 14, FS_NV = 144 + 24;
+// ---- the backward of the first TWO layers over the windows that see a set bit ----------------------------------------------
+// Layer 0 reads 1-bit maps that are ~1 % set.  A 2 x 2 pooling window whose 4 x 4 bit neighbourhood is EMPTY in both maps
+// has z0 = b at its four pixels: the same x-hat xc, the same activation, its first pixel as the maximum, no input under
+// any tap of that pixel - and the pooled activation the second layer reads there is the constant K1 = relu(bn(b)).  So
+// (1) the first layer: an empty window adds nothing to A = sum in_u g; to BatchNorm's sums it adds [K1 > 0] dp and
+//     [K1 > 0] xc dp, with dp the transposed convolution of the second layer's dz at the window;
+// (2) the second layer's weight gradient: with in = K1 + delta (delta = 0 on empty windows, in = 0 outside the plane)
+//     dW2[t][ci][co] = K1[ci] (sum of dz[co] over the cells p with p + t - 1 inside) + sum over the LISTED windows q of
+//     delta[ci][q] dz[co][q - (t - 1)];
+// (3) sums of dz over the plane with a border row / column left out are all either needs from the unlisted part: the sum
+//     of dp over ALL windows is linear in them, and the batch total of dz itself is ZERO - the second layer's dz comes out
+//     of BatchNorm's backward, dz = a (g - mean g - xhat mean(g xhat)), which sums to zero per channel (taking the exact
+//     total of stored fp32 values in doubles instead gave the same test results; the float total the weight-gradient kernel
+//     has for the bias moved conv1's beta gradient by 7e-4 of its scale - r04);
+//     sum over the empty windows of dp = (sum over all) - (sum over the listed windows).
+// Only the windows that see a bit are evaluated: ~2.5 % on arena observations (every window on a dense map - the result is
+// the same, only the time differs), and dz of the second layer is never stored: it is an element-wise function of g and z
+// of that layer (f_bw's formula), formed where it is read - 9 x 8 cells around a listed window, the border lines.  Gone
+// per 4096 rows: the dense transposed convolution (94 GMAC), the compact g0 and its kernel (f_b1_first + f_bw_first: 13.6 ms),
+// the second layer's f_bw (6.7 ms: 1.28 MB per row written, 4 MB read).
+// Block = sample.  Per band of 20 pooled rows the bit rows go to LDS and every wave classifies 5 rows x 200 windows into
+// its queue (ballot order: fixed; an entry carries its 4 x 4 bits); whenever 64 are queued the wave works them off, one
+// window per lane.  The sums that cross lanes go through LDS records in queue order: A per (tap, map, channel) lane, dW2's
+// listed part per (quarter of the records, ci, co of a pair) lane.
+constexpr int FS_BR = 20, FS_WR = FS_BR / 4, FS_NW = FS_WR * 200, FS_ROWS = 2 * FS_BR + 2, FS_WORDS = 14;
+constexpr int FS_NV = 144 + 24 + 576;   // a block's row of sums: A | sum g, sum g xhat, sum dp (8 each) | dW2's listed part
 struct FsEntry {
   float gv[8];          // g of the window per channel (0 behind the ReLU)
   uint32_t kpack;       // window position of the maximum, 2 bits per channel
   uint16_t pat[2][4];   // the 3 x 3 bit pattern around each of the window's four pixels, per map
 };
-__global__ __launch_bounds__(256) void f_first_bwd(int n, const uint32_t *__restrict__ bits, const float *__restrict__ dzn,
-                                                   const float *__restrict__ wn, const float *__restrict__ lut_x,
+// BatchNorm's backward of the second layer per channel, as f_bw carries it: {a, m0, c, mean, m0 low, c low, mean low}
+__device__ __forceinline__ void fs_coef(int co, const float *stat, const float *gamma, const double *sums, double count, float *cf) {
+  const float rs = rsqrtf(stat[2 * co + 1] + 1e-3f);
+  const double m0 = sums[2 * co] / count, c = (double)rs * (sums[2 * co + 1] / count);
+  cf[0] = gamma[co] * rs;
+  cf[1] = (float)m0;
+  cf[2] = (float)c;
+  cf[3] = stat[2 * co];
+  cf[4] = (float)(m0 - (double)cf[1]);
+  cf[5] = (float)(c - (double)cf[2]);
+  cf[6] = stat[16 + co];
+}
+__device__ __forceinline__ float fs_dz(float g, float z, const float *cf) {
+  const float zm = (z - cf[3]) - cf[6];
+  return cf[0] * (((g - cf[1]) - zm * cf[2]) - (zm * cf[5] + cf[4]));
+}
+__global__ __launch_bounds__(256, 2) void f_first_bwd(int n, const uint32_t *__restrict__ bits, const float *__restrict__ g1,
+                                                   const float *__restrict__ z1, const float *__restrict__ stat1,
+                                                   const float *__restrict__ gamma1, const double *__restrict__ sums1,
+                                                   const float *__restrict__ wn, const float *__restrict__ p0,
+                                                   const float *__restrict__ lut_y, const float *__restrict__ lut_x,
                                                    const float *__restrict__ gamma, const float *__restrict__ beta,
                                                    double *__restrict__ part) {
-  constexpr int C = 8, H = 400, W = 400, Hp = 200, Wp = 200;
+  constexpr int C = 8, H = 400, W = 400, Hp = 200, Wp = 200, NSTEP = (Hp / FS_BR) * ((FS_NW + 63) / 64);
   __shared__ __align__(16) float wl[9 * C * C];   // [tap][co][ci]
-  __shared__ __align__(16) float slut[2 * 512 * 8];
+  __shared__ float cfl[C][8], gbk[3][C];            // the second layer's coefficients; gamma, beta, K1 of the first
   __shared__ uint32_t rows[2][FS_ROWS][FS_WORDS];   // bit i of a staged row <-> image column i - 1 (0 outside the plane)
-  __shared__ uint16_t list[4][FS_NW];
+  __shared__ uint16_t qwin[4][128];                 // a wave's queue: window index 200 yp + xp ...
+  __shared__ uint32_t qbits[4][128];                // ... and its 4 x 4 bits, 4 per (map, row): bit 16 map + 4 row + column
   __shared__ __align__(16) FsEntry ent[4][64];
-  __shared__ double red[4][FS_NV];
+  __shared__ float drec[4][64][8];                  // delta of the record's window per ci
+  __shared__ float vrec[4][64][18];                 // dz around the record's window for a pair of co: [co & 1][tap]; behind
+                                                    // the pairs: g xhat [8] and dp [8] of the record
+  __shared__ double dw2[4][C * 72];                 // a wave's dW2 sums [co][tap][ci]
+  __shared__ double red[4][168];
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const size_t s = blockIdx.x;
   for (int e = tid; e < 9 * C * C; e += 256) {
     const int ci = e % C, co = (e / C) % C, tap = e / (C * C);
     wl[e] = wn[(tap * C + ci) * C + co];
   }
-  for (int e = tid; e < 2 * 512 * 8 / 4; e += 256) reinterpret_cast<float4 *>(slut)[e] = reinterpret_cast<const float4 *>(lut_x)[e];
-  float gm[C], bt[C];
-#pragma unroll
-  for (int c = 0; c < C; c++) { gm[c] = gamma[c]; bt[c] = beta[c]; }
-  double s1[C], s2[C], s3[C], accA[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-  for (int c = 0; c < C; c++) { s1[c] = 0.0; s2[c] = 0.0; s3[c] = 0.0; }
+  if (tid < C) fs_coef(tid, stat1, gamma1, sums1, (double)n * (Hp * Wp), cfl[tid]);
+  for (int e = lane; e < C * 72; e += 64) dw2[wv][e] = 0.0;
+  if (tid < C) {
+    gbk[0][tid] = gamma[tid]; gbk[1][tid] = beta[tid];
+    gbk[2][tid] = fmaxf(lut_y[tid] + lut_y[512 * 8 + tid], 0.f);   // the pooled activation of an empty window, as k_conv1_lut forms it
+  }
+  double accA[3] = {0.0, 0.0, 0.0}, accS = 0.0;   // A: lane <-> (tap, map, channel); lanes 0-23: sum g | sum g xhat | sum dp per channel
   const uint64_t lt = lane ? (~0ull >> (64 - lane)) : 0ull;
-  const long nbands = (long)n * (Hp / FS_BR);
-  for (long band = blockIdx.x; band < nbands; band += gridDim.x) {
-    const size_t s = band / (Hp / FS_BR);
-    const int y0 = (int)(band - (long)s * (Hp / FS_BR)) * FS_BR;
-    __syncthreads();
-    // image rows 2 y0 - 1 .. 2 y0 + 2 FS_BR, columns -1 .. 400 (402 bits -> 13 words + one of zeros)
-    for (int e = tid; e < 2 * FS_ROWS * FS_WORDS; e += 256) {
-      const int wd = e % FS_WORDS, rr = (e / FS_WORDS) % FS_ROWS, ci = e / (FS_WORDS * FS_ROWS);
-      const int gy = 2 * y0 - 1 + rr;
-      uint32_t out = 0u;
-      if (gy >= 0 && gy < H && wd < 13) {
-        const int c0 = 32 * wd - 1;                                   // image column of the word's bit 0
-        const long s0 = (long)gy * W + c0;                            // its cell (-1 only at gy = 0, wd = 0)
-        const uint32_t *pl = bits + (s * 2 + ci) * 5000;
-        const long sw = s0 >> 5;
-        const uint32_t lo = (sw >= 0 && sw < 5000) ? pl[sw] : 0u, hi = (sw + 1 >= 0 && sw + 1 < 5000) ? pl[sw + 1] : 0u;
-        out = __funnelshift_r(lo, hi, (unsigned)(s0 & 31));
-        if (c0 < 0) out &= ~1u;                                       // column -1
-        const int over = c0 + 32 - W;                                 // bits past the last column of THIS row
-        if (over > 0) out &= 0xFFFFFFFFu >> over;
+  const float *g1s = g1 + s * (size_t)(C * Hp * Wp), *z1s = z1 + s * (size_t)(C * Hp * Wp), *p0s = p0 + s * (size_t)(C * Hp * Wp);
+  int cnt = 0;   // queued windows of the wave (wave-uniform)
+  for (int step = 0; step <= NSTEP; step++) {
+    if (step < NSTEP) {
+      const int band = step / ((FS_NW + 63) / 64), it = step - band * ((FS_NW + 63) / 64), y0 = band * FS_BR;
+      if (it == 0) {   // block-uniform
+        __syncthreads();
+        // image rows 2 y0 - 1 .. 2 y0 + 2 FS_BR, columns -1 .. 400 (402 bits -> 13 words + one of zeros)
+        for (int e = tid; e < 2 * FS_ROWS * FS_WORDS; e += 256) {
+          const int wd = e % FS_WORDS, rr = (e / FS_WORDS) % FS_ROWS, ci = e / (FS_WORDS * FS_ROWS);
+          const int gy = 2 * y0 - 1 + rr;
+          uint32_t out = 0u;
+          if (gy >= 0 && gy < H && wd < 13) {
+            const int c0 = 32 * wd - 1;                                   // image column of the word's bit 0
+            const long s0 = (long)gy * W + c0;                            // its cell (-1 only at gy = 0, wd = 0)
+            const uint32_t *pl = bits + (s * 2 + ci) * 5000;
+            const long sw = s0 >> 5;
+            const uint32_t lo = (sw >= 0 && sw < 5000) ? pl[sw] : 0u, hi = (sw + 1 >= 0 && sw + 1 < 5000) ? pl[sw + 1] : 0u;
+            out = __funnelshift_r(lo, hi, (unsigned)(s0 & 31));
+            if (c0 < 0) out &= ~1u;                                       // column -1
+            const int over = c0 + 32 - W;                                 // bits past the last column of THIS row
+            if (over > 0) out &= 0xFFFFFFFFu >> over;
+          }
+          rows[ci][rr][wd] = out;
+        }
+        __syncthreads();
       }
-      rows[ci][rr][wd] = out;
-    }
-    __syncthreads();
-    // window wi = 200 yl + xp of the wave's rows: staged rows 2 r .. 2 r + 3 (r = FS_WR wv + yl), staged bits 2 xp .. 2 xp + 3
-    auto window_bits = [&](int wi, uint32_t (&f)[2][4]) {
-      const int yl = wi / Wp, xp = wi - yl * Wp, r = FS_WR * wv + yl, wd = (2 * xp) >> 5;
+      // window (yl, xp) of the wave's 5 rows: staged rows 2 r .. 2 r + 3 (r = FS_WR wv + yl), staged bits 2 xp .. 2 xp + 3
+      const int wi = min(64 * it + lane, FS_NW - 1), yl = wi / Wp, xp = wi - yl * Wp, r = FS_WR * wv + yl, wd = (2 * xp) >> 5;
       const unsigned sh = (unsigned)((2 * xp) & 31);
+      uint32_t fb = 0u;
 #pragma unroll
       for (int ci = 0; ci < 2; ci++)
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           const uint32_t *rw = &rows[ci][2 * r + k][wd];
-          f[ci][k] = __funnelshift_r(rw[0], rw[1], sh) & 15u;
+          fb |= (__funnelshift_r(rw[0], rw[1], sh) & 15u) << (16 * ci + 4 * k);
         }
-    };
-    int cnt = 0;   // wave-uniform
-    for (int it = 0; it < (FS_NW + 63) / 64; it++) {
-      const int wi = 64 * it + lane;
-      uint32_t f[2][4], any = 0u;
-      window_bits(min(wi, FS_NW - 1), f);
-#pragma unroll
-      for (int k = 0; k < 4; k++) any |= f[0][k] | f[1][k];
-      const bool ne = wi < FS_NW && any != 0u;
+      const bool ne = 64 * it + lane < FS_NW && fb != 0u;
       const uint64_t m = __builtin_amdgcn_ballot_w64(ne);
-      if (ne) list[wv][cnt + __builtin_popcountll(m & lt)] = (uint16_t)wi;
+      if (ne) {
+        const int at = cnt + __builtin_popcountll(m & lt);
+        qwin[wv][at] = (uint16_t)((y0 + r) * Wp + xp);
+        qbits[wv][at] = fb;
+      }
       cnt += __builtin_popcountll(m);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const float *dzs = dzn + s * (size_t)(C * Hp * Wp);
-    for (int c0 = 0; c0 < cnt; c0 += 64) {
-      const bool ok = c0 + lane < cnt;
-      const int wi = list[wv][ok ? c0 + lane : c0];
-      uint32_t f[2][4];
-      window_bits(wi, f);
-      const int yl = wi / Wp, xp = wi - yl * Wp, yp = y0 + FS_WR * wv + yl;
-      float dp[C];
+    if (cnt < 64 && !(step == NSTEP && cnt > 0)) continue;   // wave-uniform
+    // ---- work off the first min(64, cnt) queued windows, one per lane
+    const int ne = min(64, cnt);
+    const bool ok = lane < ne;
+    const int qi = ok ? lane : 0;
+    const int win = qwin[wv][qi], yp = win / Wp, xp = win - yp * Wp;
+    const uint32_t fb = qbits[wv][qi];
+    {  // delta = in - K1 of the window per input channel of the second layer
+      float dl[C];
 #pragma unroll
-      for (int ci = 0; ci < C; ci++) dp[ci] = 0.f;
-#pragma unroll 2
-      for (int co = 0; co < C; co++) {
-        float v[9];
+      for (int ci = 0; ci < C; ci++) dl[ci] = ok ? p0s[(ci * Hp + yp) * Wp + xp] - gbk[2][ci] : 0.f;
+#pragma unroll
+      for (int ci = 0; ci < C; ci++) drec[wv][lane][ci] = dl[ci];
+    }
+    float dp[C];
+#pragma unroll
+    for (int ci = 0; ci < C; ci++) dp[ci] = 0.f;
+#pragma unroll 1
+    for (int cp = 0; cp < C / 2; cp++) {
+      float v[2][9];
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int co = 2 * cp + h;
+        float gq[9], zq[9];
 #pragma unroll
         for (int t = 0; t < 9; t++) {
           const int y = yp - (t / 3 - 1), x = xp - (t % 3 - 1);
-          v[t] = (y >= 0 && y < Hp && x >= 0 && x < Wp) ? dzs[(co * Hp + y) * Wp + x] : 0.f;
+          const bool in = y >= 0 && y < Hp && x >= 0 && x < Wp;
+          const int at = in ? (co * Hp + y) * Wp + x : 0;
+          gq[t] = g1s[at]; zq[t] = z1s[at];
         }
 #pragma unroll
         for (int t = 0; t < 9; t++) {
+          const int y = yp - (t / 3 - 1), x = xp - (t % 3 - 1);
+          v[h][t] = (ok && y >= 0 && y < Hp && x >= 0 && x < Wp) ? fs_dz(gq[t], zq[t], cfl[co]) : 0.f;
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
           float wv8[C];
-          lds_vec<C>(&wl[(t * C + co) * C], wv8);
-          fma_row<C>(dp, v[t], wv8);
+          lds_vec<C>(&wl[(t * C + 2 * cp + h) * C], wv8);
+          fma_row<C>(dp, v[h][t], wv8);
+          vrec[wv][lane][9 * h + t] = v[h][t];
         }
-      }
-      // x-hat of the window's four pixels (dy, dx): pattern = bits dx .. dx + 2 of staged rows dy .. dy + 2
-      float xh[4][C];
-      FsEntry E;
-#pragma unroll
-      for (int px = 0; px < 4; px++) {
-        const int dy = px >> 1, dx = px & 1;
-        float4 lo4, hi4;
-#pragma unroll
-        for (int ci = 0; ci < 2; ci++) {
-          const uint32_t pat = ((f[ci][dy] >> dx) & 7u) | (((f[ci][dy + 1] >> dx) & 7u) << 3) | (((f[ci][dy + 2] >> dx) & 7u) << 6);
-          E.pat[ci][px] = (uint16_t)pat;
-          const float4 *e = reinterpret_cast<const float4 *>(&slut[(ci * 512 + pat) * 8]);
-          if (ci == 0) { lo4 = e[0]; hi4 = e[1]; }
-          else { lo4.x += e[0].x; lo4.y += e[0].y; lo4.z += e[0].z; lo4.w += e[0].w; hi4.x += e[1].x; hi4.y += e[1].y; hi4.z += e[1].z; hi4.w += e[1].w; }
-        }
-        xh[px][0] = lo4.x; xh[px][1] = lo4.y; xh[px][2] = lo4.z; xh[px][3] = lo4.w;
-        xh[px][4] = hi4.x; xh[px][5] = hi4.y; xh[px][6] = hi4.z; xh[px][7] = hi4.w;
-      }
-      E.kpack = 0u;
-#pragma unroll
-      for (int c = 0; c < C; c++) {
-        float av[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) av[i] = fmaxf(fmaf(gm[c], xh[i][c], bt[c]), 0.f);
-        int k = 0;
-#pragma unroll
-        for (int i = 1; i < 4; i++) if (av[i] > av[k]) k = i;
-        const float xk = k == 0 ? xh[0][c] : k == 1 ? xh[1][c] : k == 2 ? xh[2][c] : xh[3][c];
-        const float gv = (ok && av[k] > 0.f) ? dp[c] : 0.f;
-        E.gv[c] = gv;
-        E.kpack |= (uint32_t)k << (2 * c);
-        s1[c] += (double)gv;
-        s2[c] += (double)(gv * xk);
-        s3[c] += ok ? (double)dp[c] : 0.0;
-      }
-      ent[wv][lane] = E;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      // A[u = (tap, map)][c] += (bit `tap` of the pattern around channel c's maximum) * g: lane <-> (u, c), records in list order
-      const int ne = min(64, cnt - c0);
+      // dW2's listed part for this pair of co: lane = (quarter of the records, ci, co of the pair), nine taps each;
+      // the four quarters are added in a fixed order
+      {
+        const int qd = lane >> 4, ci = (lane >> 1) & 7, hh = lane & 1;
+        double a[9];
 #pragma unroll
-      for (int j = 0; j < 3; j++) {
-        const int kidx = lane + 64 * j;
-        if (kidx < 144) {
-          const int c = kidx & 7, u = kidx >> 3, tap = u >> 1, cin = u & 1;
-          double a = accA[j];
-          for (int e2 = 0; e2 < ne; e2++) {
-            const FsEntry &R = ent[wv][e2];
-            const int kc = (R.kpack >> (2 * c)) & 3;
-            if ((R.pat[cin][kc] >> tap) & 1) a += (double)R.gv[c];
-          }
-          accA[j] = a;
+        for (int t = 0; t < 9; t++) a[t] = 0.0;
+        for (int e2 = 16 * qd; e2 < min(16 * qd + 16, ne); e2++) {
+          const double d = (double)drec[wv][e2][ci];
+#pragma unroll
+          for (int t = 0; t < 9; t++) a[t] += d * (double)vrec[wv][e2][9 * hh + t];
+        }
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+          const double b16 = a[t] + __shfl_xor(a[t], 16, 64);
+          const double b32 = b16 + __shfl_xor(b16, 32, 64);
+          if (qd == 0) dw2[wv][((2 * cp + hh) * 9 + t) * C + ci] += b32;
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
-  }
+    // x-hat of the window's four pixels (dy, dx): pattern = bits dx .. dx + 2 of rows dy .. dy + 2 of the 4 x 4 block
+    float xh[4][C];
+    FsEntry E;
 #pragma unroll
-  for (int c = 0; c < C; c++) {
-    const double a = wave_sum(s1[c]), b2 = wave_sum(s2[c]), d3 = wave_sum(s3[c]);
-    if (lane == 0) { red[wv][144 + c] = a; red[wv][152 + c] = b2; red[wv][160 + c] = d3; }
+    for (int px = 0; px < 4; px++) {
+      const int dy = px >> 1, dx = px & 1;
+      float4 lo4, hi4;
+#pragma unroll
+      for (int ci = 0; ci < 2; ci++) {
+        const uint32_t f = fb >> (16 * ci);
+        const uint32_t pat = ((f >> (4 * dy + dx)) & 7u) | (((f >> (4 * dy + 4 + dx)) & 7u) << 3) | (((f >> (4 * dy + 8 + dx)) & 7u) << 6);
+        E.pat[ci][px] = (uint16_t)pat;
+        const float4 *e = reinterpret_cast<const float4 *>(&lut_x[(ci * 512 + pat) * 8]);
+        const float4 e0 = e[0], e1 = e[1];
+        if (ci == 0) { lo4 = e0; hi4 = e1; }
+        else { lo4.x += e0.x; lo4.y += e0.y; lo4.z += e0.z; lo4.w += e0.w; hi4.x += e1.x; hi4.y += e1.y; hi4.z += e1.z; hi4.w += e1.w; }
+      }
+      xh[px][0] = lo4.x; xh[px][1] = lo4.y; xh[px][2] = lo4.z; xh[px][3] = lo4.w;
+      xh[px][4] = hi4.x; xh[px][5] = hi4.y; xh[px][6] = hi4.z; xh[px][7] = hi4.w;
+    }
+    E.kpack = 0u;
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+      float av[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) av[i] = fmaxf(fmaf(gbk[0][c], xh[i][c], gbk[1][c]), 0.f);
+      int k = 0;
+#pragma unroll
+      for (int i = 1; i < 4; i++) if (av[i] > av[k]) k = i;
+      const float xk = k == 0 ? xh[0][c] : k == 1 ? xh[1][c] : k == 2 ? xh[2][c] : xh[3][c];
+      const float gv = (ok && av[k] > 0.f) ? dp[c] : 0.f;
+      E.gv[c] = gv;
+      E.kpack |= (uint32_t)k << (2 * c);
+      vrec[wv][lane][c] = gv * xk;
+      vrec[wv][lane][8 + c] = ok ? dp[c] : 0.f;
+    }
+    ent[wv][lane] = E;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // A[u = (tap, map)][c] += (bit `tap` of the pattern around channel c's maximum) * g: lane <-> (u, c), records in queue order
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const int kidx = lane + 64 * j;
+      if (kidx < 144) {
+        const int c = kidx & 7, u = kidx >> 3, tap = u >> 1, cin = u & 1;
+        double a = accA[j];
+        for (int e2 = 0; e2 < ne; e2++) {
+          const FsEntry &R = ent[wv][e2];
+          const int kc = (R.kpack >> (2 * c)) & 3;
+          if ((R.pat[cin][kc] >> tap) & 1) a += (double)R.gv[c];
+        }
+        accA[j] = a;
+      }
+    }
+    if (lane < 24) {   // BatchNorm's sums over the listed windows, records in queue order
+      const int c = lane & 7, what = lane >> 3;
+      for (int e2 = 0; e2 < ne; e2++) accS += (double)(what == 0 ? ent[wv][e2].gv[c] : vrec[wv][e2][8 * (what - 1) + c]);
+    }
+    // the queue moves up
+    const int rest = cnt - ne;
+    uint16_t mw = 0;
+    uint32_t mb = 0u;
+    if (lane < rest) { mw = qwin[wv][64 + lane]; mb = qbits[wv][64 + lane]; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < rest) { qwin[wv][lane] = mw; qbits[wv][lane] = mb; }
+    cnt = rest;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
+  if (lane < 24) red[wv][144 + lane] = accS;
 #pragma unroll
   for (int j = 0; j < 3; j++)
     if (lane + 64 * j < 144) red[wv][lane + 64 * j] = accA[j];
   __syncthreads();
-  // part[block] = A as [tap][map][channel] (144), then sum g, sum g xhat, sum dp over the block's listed windows (8 each)
-  if (tid < FS_NV) part[(size_t)blockIdx.x * FS_NV + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+  // part[sample] = A as [tap][map][channel] (144) | sum g, sum g xhat, sum dp over the listed windows (8 each) | dW2's listed
+  // part as [tap][ci][co] (576)
+  for (int k = tid; k < FS_NV; k += 256) {
+    double v;
+    if (k < 168) v = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+    else {
+      const int j = k - 168, co = j & 7, ci = (j >> 3) & 7, t = j >> 6, a = (co * 9 + t) * C + ci;
+      v = (dw2[0][a] + dw2[1][a]) + (dw2[2][a] + dw2[3][a]);
+    }
+    part[s * FS_NV + k] = v;
+  }
 }
 
-// bpart[sample][co][8]: sums of the sample's dz plane (200 x 200) over its first / last row, first / last column, and its
-// four corners (0,0) (0,L) (L,0) (L,L); block = sample, wave = two channels
-__global__ __launch_bounds__(256) void f_first_border(int n, const float *__restrict__ dzn, double *__restrict__ bpart) {
+// bpart[sample][co][8]: sums of the sample's dz plane (200 x 200; dz from g and z of the layer, see above) over its first /
+// last row, first / last column, and its four corners (0,0) (0,L) (L,0) (L,L); block = sample, wave = two channels
+__global__ __launch_bounds__(256) void f_first_border(int n, const float *__restrict__ g1, const float *__restrict__ z1,
+                                                      const float *__restrict__ stat1, const float *__restrict__ gamma1,
+                                                      const double *__restrict__ sums1, double *__restrict__ bpart) {
   constexpr int Hp = 200, Wp = 200;
   const int s = blockIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int k = 0; k < 2; k++) {
     const int co = 2 * wv + k;
-    const float *pl = dzn + ((size_t)s * 8 + co) * (Hp * Wp);
+    float cf[7];
+    fs_coef(co, stat1, gamma1, sums1, (double)n * (Hp * Wp), cf);
+    const size_t base = ((size_t)s * 8 + co) * (Hp * Wp);
+    auto dz = [&](int at) { return (double)fs_dz(g1[base + at], z1[base + at], cf); };
     double r0 = 0.0, r1 = 0.0, c0 = 0.0, c1 = 0.0;
     for (int i = lane; i < 200; i += 64) {
-      r0 += (double)pl[i];
-      r1 += (double)pl[(Hp - 1) * Wp + i];
-      c0 += (double)pl[i * Wp];
-      c1 += (double)pl[i * Wp + Wp - 1];
+      r0 += dz(i);
+      r1 += dz((Hp - 1) * Wp + i);
+      c0 += dz(i * Wp);
+      c1 += dz(i * Wp + Wp - 1);
     }
     r0 = wave_sum(r0); r1 = wave_sum(r1); c0 = wave_sum(c0); c1 = wave_sum(c1);
     if (lane == 0) {
       double *o = bpart + ((size_t)s * 8 + co) * 8;
       o[0] = r0; o[1] = r1; o[2] = c0; o[3] = c1;
-      o[4] = (double)pl[0]; o[5] = (double)pl[Wp - 1]; o[6] = (double)pl[(Hp - 1) * Wp]; o[7] = (double)pl[Hp * Wp - 1];
+      o[4] = dz(0); o[5] = dz(Wp - 1); o[6] = dz((Hp - 1) * Wp); o[7] = dz(Hp * Wp - 1);
     }
   }
 }
 
-// q[168] = A, and over the listed windows sum g, sum g xhat, sum dp; bsum[64] = the border sums of the second layer's dz;
-// cc[324] = the autocorrelation:  BatchNorm's sums of the first layer with the empty windows' share put back, then dw, db,
-// dgamma, dbeta (see "the first layer's weight gradient" above)
-__global__ __launch_bounds__(192) void f_first_bwd_finish(const double *q, const double *bsum, const float *wn,
-                                                          const float *lut_x, const double *cc, const float *w, const float *b,
-                                                          const float *stat, const float *gamma, const float *beta, double count,
-                                                          float *dw, float *db, float *dgamma, float *dbeta) {
-  __shared__ double sums[16];
+// q[744] = the batch's A | sum g, sum g xhat, sum dp over the listed windows | dW2's listed part; bsum[64] = the border sums
+// of the second layer's dz; cc[324] = the autocorrelation of the bit maps.  Out: the second layer's dw2 / db2 / dgamma2 /
+// dbeta2 (sums1 = its BatchNorm sums), and the first layer's - BatchNorm's sums with the empty windows' share put back, then
+// dw, db, dgamma, dbeta (see "the first layer's weight gradient" above)
+__global__ __launch_bounds__(576) void f_first_bwd_finish(const double *q, const double *bsum, const float *wn,
+                                                          const float *lut_y, const float *lut_x, const double *cc,
+                                                          const float *w, const float *b, const float *stat, const float *gamma,
+                                                          const float *beta, double count, const double *sums1, float *dw,
+                                                          float *db, float *dgamma, float *dbeta, float *dw2, float *db2,
+                                                          float *dgamma2, float *dbeta2) {
+  __shared__ double sums[16], S[8][9];
   const int k = threadIdx.x;
+  if (k < 72) {   // S[co][t]: the sum of dz[co] over the cells p with p + (t - 1) inside the plane; the plane's total is zero
+    const int co = k / 9, t = k - 9 * co, dy = t / 3 - 1, dx = t % 3 - 1;
+    const double *o = bsum + co * 8;
+    double v = 0.0;
+    if (dy == 1) v -= o[1]; else if (dy == -1) v -= o[0];
+    if (dx == 1) v -= o[3]; else if (dx == -1) v -= o[2];
+    if (dy != 0 && dx != 0) v += o[4 + (dy == 1 ? 2 : 0) + (dx == 1 ? 1 : 0)];
+    S[co][t] = v;
+  }
+  __syncthreads();
   if (k < 8) {
     const int c = k;
-    // sum over ALL windows p of dp[c][p] = sum_{co, tap} w[tap][c][co] (sum of dz[co] over the cells q with q + d in the plane)
-    double all = 0.0;
-    for (int co = 0; co < 8; co++) {
-      const double *o = bsum + co * 8;
-      for (int t = 0; t < 9; t++) {
-        const int dy = t / 3 - 1, dx = t % 3 - 1;
-        double S = 0.0;   // the plane's total: zero (above)
-        if (dy == 1) S -= o[1]; else if (dy == -1) S -= o[0];
-        if (dx == 1) S -= o[3]; else if (dx == -1) S -= o[2];
-        if (dy != 0 && dx != 0) S += o[4 + (dy == 1 ? 2 : 0) + (dx == 1 ? 1 : 0)];
-        all += (double)wn[(t * 8 + c) * 8 + co] * S;
-      }
-    }
+    double all = 0.0;   // sum over ALL windows of dp[c]
+    for (int co = 0; co < 8; co++)
+      for (int t = 0; t < 9; t++) all += (double)wn[(t * 8 + c) * 8 + co] * S[co][t];
     const double empty = all - q[160 + c];
     const float xc = lut_x[c] + lut_x[512 * 8 + c];              // x-hat of a pixel with no bit around it, as the kernel forms it
     const bool on = fmaxf(fmaf(gamma[c], xc, beta[c]), 0.f) > 0.f;
@@ -1487,6 +1592,12 @@ __global__ __launch_bounds__(192) void f_first_bwd_finish(const double *q, const
     sums[2 * c + 1] = q[152 + c] + (on ? empty * (double)xc : 0.0);
   }
   __syncthreads();
+  {  // the second layer: dw2[t][ci][co], its bias gradient is exactly zero (a convolution in front of BatchNorm)
+    const int co = k & 7, ci = (k >> 3) & 7, t = k >> 6;
+    const double k1 = (double)fmaxf(lut_y[ci] + lut_y[512 * 8 + ci], 0.f);
+    dw2[k] = (float)(k1 * S[co][t] + q[168 + k]);
+    if (k < 8) { db2[k] = 0.f; dbeta2[k] = (float)sums1[2 * k]; dgamma2[k] = (float)sums1[2 * k + 1]; }
+  }
   if (k < 144) {
     const int co = k % 8, u = k / 8;
     const double rs = 1.0 / sqrt((double)stat[2 * co + 1] + 1e-3), a = (double)gamma[co] * rs;
@@ -1774,21 +1885,28 @@ int ofx_fit_first_fwd(ofx_handle *h, int n, const void *bits, const float *w, co
   OFX_HIP(hipGetLastError());
   return ofx_launch_conv1_lut(h, bits, n, luts, p0);
 }
-// The first trunk layer's backward from the second layer's dz (dzn [n][8][200][200] out of BatchNorm's backward, kernel wn):
-// dw / db / dgamma / dbeta; cpart as left by ofx_fit_first_fwd
-int ofx_fit_first_bwd(hipStream_t st, int n, const void *bits, const float *dzn, const float *wn, const float *luts, const float *w, const float *b, const float *stat, const float *gamma,
-                      const float *beta, double *part, double *cpart, float *dw, float *db, float *dgamma, float *dbeta) {
+// The backward of the first two trunk layers from g1 = d loss / d (BatchNorm output of the second layer) [n][8][200][200]
+// (ofx_fit_b1_pool) with sums1 = its {sum g, sum g xhat} per channel, z1 / stat1 / gamma1 of that layer, wn its kernel, p0 its
+// input (the pooled activation ofx_fit_first_fwd left), luts / cpart as left by ofx_fit_first_fwd: dw2 .. dbeta2 of the second
+// layer, dw .. dbeta of the first (w, b, stat, gamma, beta: its own tensors).  The second layer's dz is never stored.
+// part: n x 744 doubles
+int ofx_fit_first_bwd(hipStream_t st, int n, const void *bits, const float *g1, const float *z1, const float *stat1,
+                      const float *gamma1, const double *sums1, const float *wn, const float *p0, const float *luts,
+                      const float *w, const float *b, const float *stat, const float *gamma, const float *beta, double *part,
+                      double *cpart, float *dw, float *db, float *dgamma, float *dbeta, float *dw2, float *db2, float *dgamma2,
+                      float *dbeta2) {
   double *cc = cpart + (size_t)1024 * 324, *q = cc + 324, *bsum = q + FS_NV, *bpart = bsum + 64;
-  const int grid = grid_for((long)n * (200 / FS_BR), OFX_FIT_MAX_BLOCKS);
-  hipLaunchKernelGGL(f_first_border, dim3(n), dim3(256), 0, st, n, dzn, bpart);
+  hipLaunchKernelGGL(f_first_border, dim3(n), dim3(256), 0, st, n, g1, z1, stat1, gamma1, sums1, bpart);
   hipLaunchKernelGGL(f_sum_rows, dim3((64 + 15) / 16), dim3(256), 0, st, 64, n, bpart, bsum);
-  hipLaunchKernelGGL(f_first_bwd, dim3(grid), dim3(256), 0, st, n, (const uint32_t *)bits, dzn, wn, luts + 8192, gamma, beta, part);
-  hipLaunchKernelGGL(f_sum_rows, dim3((FS_NV + 15) / 16), dim3(256), 0, st, FS_NV, grid, part, q);
-  hipLaunchKernelGGL(f_first_bwd_finish, dim3(1), dim3(192), 0, st, q, bsum, wn, luts + 8192, cc, w, b, stat, gamma, beta,
-                     (double)n * 160000.0, dw, db, dgamma, dbeta);
+  hipLaunchKernelGGL(f_first_bwd, dim3(n), dim3(256), 0, st, n, (const uint32_t *)bits, g1, z1, stat1, gamma1, sums1, wn, p0, luts,
+                     luts + 8192, gamma, beta, part);
+  hipLaunchKernelGGL(f_sum_rows, dim3((FS_NV + 15) / 16), dim3(256), 0, st, FS_NV, n, part, q);
+  hipLaunchKernelGGL(f_first_bwd_finish, dim3(1), dim3(576), 0, st, q, bsum, wn, luts, luts + 8192, cc, w, b, stat, gamma, beta,
+                     (double)n * 160000.0, sums1, dw, db, dgamma, dbeta, dw2, db2, dgamma2, dbeta2);
   OFX_HIP(hipGetLastError());
   return OFX_OK;
 }
+size_t ofx_fit_first_part_doubles(int n) { return (size_t)n * FS_NV; }
 
 size_t ofx_fit_point_doubles(int n) { return (size_t)n * (73 + 16); }
 // The top of head 2 for one error per sample (ofx_dqn_fit): o2 at the pointer (o2p [n]), the seeds of both heads (do1, d2p [n],

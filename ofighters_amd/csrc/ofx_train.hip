@@ -636,7 +636,7 @@ static int dqn_fit_lean(ofx_handle *h, float *weights, float *adam_m, float *ada
   auto sz = [&](size_t bytes) { need += (bytes + 255) & ~(size_t)255; };
   for (int i = 1; i < 4; i++) { sz(4 * N * 8 * tS[i] * tS[i]); sz(4 * N * 8 * tS[i] * tS[i]); }  // z, g (layer 0 has neither)
   sz(4 * ofx_fit_first_floats()); sz(4 * 5008 * 100);
-  sz(8 * ofx_fit_first_doubles(n));                                                                        // correlation, first-layer backward
+  sz(8 * ofx_fit_first_doubles(n)); sz(8 * ofx_fit_first_part_doubles(n));                                 // correlation, first-layers backward
   for (int i = 0; i < 3; i++) sz(4 * N * 8 * tS[i + 1] * tS[i + 1]);                                       // pooled activation
   for (int j = 0; j < 3; j++) { sz(4 * N * kUO[j] * uS[j] * uS[j]); sz(4 * N * kUO[j] * uS[j] * uS[j]); }
   sz(4 * N * 160000); sz(4 * N * 160000);                                                                  // o2, do2
@@ -662,7 +662,7 @@ static int dqn_fit_lean(ofx_handle *h, float *weights, float *adam_m, float *ada
   for (int i = 0; i < 3; i++) tp[i] = A.f(N * 8 * tS[i + 1] * tS[i + 1]);
   for (int i = 0; i < 4; i++) { tz[i] = i ? A.f(N * 8 * tS[i] * tS[i]) : nullptr; tg[i] = i ? A.f(N * 8 * tS[i] * tS[i]) : nullptr; tstat[i] = A.f(32); tact[i] = A.f(16); }
   float *luts = A.f(ofx_fit_first_floats()), *w1t = A.f(5008 * 100);
-  double *cpart = A.d(ofx_fit_first_doubles(n));
+  double *cpart = A.d(ofx_fit_first_doubles(n)), *fpart2 = A.d(ofx_fit_first_part_doubles(n));
   for (int j = 0; j < 3; j++) { uz[j] = A.f(N * kUO[j] * uS[j] * uS[j]); ug[j] = A.f(N * kUO[j] * uS[j] * uS[j]); ustat[j] = A.f(32); uact[j] = A.f(16); }
   float *o2 = A.f(N * 160000), *do2 = A.f(N * 160000);
   float *p3 = A.f(N * 5000), *f = A.f(N * 5008), *d1 = A.f(N * 100), *d2 = A.f(N * 50), *o1 = A.f(N * 2), *u0 = A.f(N * 625);
@@ -757,14 +757,15 @@ static int dqn_fit_lean(ofx_handle *h, float *weights, float *adam_m, float *ada
   dzn = dp3;
   for (int i = 3; i >= 0; i--) {
     const int s = tS[i];
-    if (i == 0) {
-      // the first layer: neither z0, g0 nor dz0 exist; only the windows that see a set bit are visited (ofx_fit.hip, f_first_bwd)
-      if ((rc = ofx_fit_first_bwd(st, n, bits_prev, dzn, T(6), luts, T(0), T(1), tstat[0], T(2), T(3), part, cpart,
-                                  G(0), G(1), G(2), G(3)))) return rc;
-      break;
-    }
     if ((rc = ofx_fit_b1_pool(st, n, s, s, i < 3, dzn, i < 3 ? T(6 * (i + 1)) : nullptr, tz[i], tstat[i], tact[i], tg[i], part, &nb))) return rc;
     if ((rc = ofx_fit_finish(st, nb, 8, 1.0, part, nullptr, nullptr, sums, nullptr, nullptr))) return rc;
+    if (i == 1) {
+      // the first two layers: the first has neither z, g nor dz, the second's dz is never stored - only the windows that see
+      // a set bit are visited (ofx_fit.hip, f_first_bwd)
+      if ((rc = ofx_fit_first_bwd(st, n, bits_prev, tg[1], tz[1], tstat[1], T(8), sums, T(6), tp[0], luts, T(0), T(1), tstat[0],
+                                  T(2), T(3), fpart2, cpart, G(0), G(1), G(2), G(3), G(6), G(7), G(8), G(9)))) return rc;
+      break;
+    }
     if ((rc = ofx_fit_bw(st, n, kTI[i], 8, s, s, trunk_src(i, true), 1, tg[i], tz[i], tstat[i], T(6 * i + 2), sums, part,
                          G(6 * i), G(6 * i + 1), G(6 * i + 2), G(6 * i + 3)))) return rc;
     dzn = tg[i];
