@@ -36,8 +36,9 @@ int ofx_fit_finish(hipStream_t st, int nblocks, int c_n, double count, const dou
 int ofx_fit_pool_act(hipStream_t st, int n, int C, int H, int W, const float *z, const float *act, float *p);
 // g = d loss / d (BN output of the layer), ReLU-masked, through the pooling in front of the next convolution
 // (conv: dzn = that convolution's dz [n][8][H/2][W/2], wn its kernel; else dzn = d pooled output)
+// wtr: 576 floats of scratch (the kernel transposed for the scalar cache)
 int ofx_fit_b1_pool(hipStream_t st, int n, int H, int W, int conv, const float *dzn, const float *wn, const float *z,
-                    const float *stat, const float *act, float *g, double *part, int *nblocks);
+                    const float *stat, const float *act, float *g, double *part, int *nblocks, float *wtr);
 size_t ofx_fit_first_doubles(int n);
 size_t ofx_fit_first_floats(void);
 struct ofx_handle;
@@ -52,9 +53,11 @@ int ofx_fit_first_bwd(hipStream_t st, int n, const void *bits, const float *g1, 
                       const float *w, const float *b, const float *stat, const float *gamma, const float *beta, double *part,
                       double *cpart, float *dw, float *db, float *dgamma, float *dbeta, float *dw2, float *db2, float *dgamma2,
                       float *dbeta2);
-// the same through the x2 up-sampling in front of a convolution with `con` output channels at 2h x 2w
+// the same through the x2 up-sampling in front of a convolution with `con` output channels at 2h x 2w; zero: 16 bytes of
+// zeros in device memory (what an LDS-direct load reads for a cell outside the plane); wtr: 576 floats of scratch
 int ofx_fit_b1_up(hipStream_t st, int n, int c, int con, int h, int w, int bn, const float *dzn, const float *wn,
-                  const float *zp, const float *stat, const float *act, int legacy, float *g, double *part, int *nblocks);
+                  const float *zp, const float *stat, const float *act, int legacy, float *g, double *part, int *nblocks,
+                  const float *zero, float *wtr);
 // dz over g in place (bn), dw / db (/ dgamma, dbeta from sums); gpatch + rows (the last head layer under the textbook
 // targets): g is not read - it is zero but for the 4 x 4 patch per sample and channel ofx_fit_top_point left in gpatch
 int ofx_fit_bw(hipStream_t st, int n, int ci, int co, int H, int W, const ofx_fit_src &src, int bn, float *g,

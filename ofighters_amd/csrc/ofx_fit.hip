@@ -470,14 +470,8 @@ __global__ __launch_bounds__(256, 3) void f_b1_pool(int n, int H, int W, const f
                                                  float *__restrict__ g, double *__restrict__ part) {
   constexpr int C = 8, LP = P_TW + 4;
   __shared__ __align__(16) float dzt[CONV ? C : 1][P_TR + 2][LP];
-  __shared__ __align__(16) float wl[CONV ? 9 * C * C : 4];   // [tap][co][ci]: the C input channels of one read contiguous
   __shared__ double red[4][2 * C];
   const int Hp = H / 2, Wp = W / 2;
-  if constexpr (CONV)
-    for (int e = threadIdx.x; e < 9 * C * C; e += 256) {
-      const int ci = e % C, co = (e / C) % C, tap = e / (C * C);
-      wl[e] = wn[(tap * C + ci) * C + co];
-    }
   const int tid = threadIdx.x, r = tid / (P_TW / 2), q = tid - r * (P_TW / 2);
   const int tx_n = (Wp + P_TW - 1) / P_TW, ty_n = (Hp + P_TR - 1) / P_TR, per_s = tx_n * ty_n;
   const long ntiles = (long)n * per_s;
@@ -512,6 +506,12 @@ __global__ __launch_bounds__(256, 3) void f_b1_pool(int n, int H, int W, const f
     if (r >= P_TR || yp >= Hp || xp >= Wp) continue;
     float dp[2][C];
     if constexpr (CONV) {
+      // the kernel as [tap][co][ci] (wn here: the launcher's transposed copy) through the SCALAR cache, an SGPR pair per
+      // v_pk_fma_f32: as 2 broadcast ds_read_b128 per tap and co the weights took 2.3x the LDS time the tile's FMAs take on
+      // the vector ALU (r04).  The offset the compiler cannot see through keeps the loads inside the tile loop.
+      int zoff;
+      asm volatile("s_mov_b32 %0, 0" : "=s"(zoff));
+      const float *__restrict__ wt = wn + zoff;
 #pragma unroll
       for (int j = 0; j < 2; j++)
 #pragma unroll
@@ -527,7 +527,8 @@ __global__ __launch_bounds__(256, 3) void f_b1_pool(int n, int H, int W, const f
 #pragma unroll
           for (int kx = 0; kx < 3; kx++) {
             float wv[C];
-            lds_vec<C>(&wl[((ky * 3 + kx) * C + co) * C], wv);
+#pragma unroll
+            for (int ci = 0; ci < C; ci++) wv[ci] = wt[((ky * 3 + kx) * C + co) * C + ci];
             fma_row<C>(dp[0], v[2 - kx], wv);
             fma_row<C>(dp[1], v[3 - kx], wv);
           }
@@ -603,20 +604,16 @@ template <int C, int CON, int TRL, bool BN>
 __global__ __launch_bounds__(256, 2) void f_b1_up(int n, int h, int w, const float *__restrict__ dzn,
                                                const float *__restrict__ wn, const float *__restrict__ zp,
                                                const float *__restrict__ stat, const float *__restrict__ act, int legacy,
-                                               float *__restrict__ g, double *__restrict__ part) {
+                                               float *__restrict__ g, double *__restrict__ part, const float *__restrict__ zero) {
   constexpr int UR = 2 * TRL + 3, UC = 2 * U_TW + 3, UP_ = UC + 1;   // dU tile: up-res rows 2 y0 - 2 .., pitch
   constexpr int DR = UR + 2, DC = UC + 2, DP = DC + 1;               // dz tile: one more cell all round
   __shared__ float dzt[CON][DR][DP];
   __shared__ float du[C][UR][UP_];
-  __shared__ __align__(16) float wl[9 * CON * C];            // [tap][co][c]
   __shared__ double red[4][2 * C];
-  static_assert(sizeof(float) * (CON * DR * DP + C * UR * UP_ + 9 * CON * C) <= 62 * 1024, "LDS tiles too large");
-  for (int e = threadIdx.x; e < 9 * CON * C; e += 256) {
-    const int c = e % C, co = (e / C) % CON, tap = e / (C * CON);
-    wl[e] = wn[(tap * C + c) * CON + co];
-  }
+  static_assert(sizeof(float) * (CON * DR * DP + C * UR * UP_) <= 62 * 1024, "LDS tiles too large");
   const int H2 = 2 * h, W2 = 2 * w;
   const int tid = threadIdx.x, r = tid / U_TW, q = tid - r * U_TW;
+  const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tx_n = (w + U_TW - 1) / U_TW, ty_n = (h + TRL - 1) / TRL, per_s = tx_n * ty_n;
   const long ntiles = (long)n * per_s;
   // few weights (9 C CON <= 72): kept in registers for the whole kernel instead of re-read from LDS per position
@@ -626,7 +623,7 @@ __global__ __launch_bounds__(256, 2) void f_b1_up(int n, int h, int w, const flo
 #pragma unroll
     for (int k = 0; k < 9 * CON; k++)
 #pragma unroll
-      for (int c = 0; c < C; c++) wreg[k][c] = wn[((k / CON) * C + c) * CON + k % CON];
+      for (int c = 0; c < C; c++) wreg[k][c] = wn[k * C + c];   // wn: [tap][co][c], the launcher's transposed copy
   }
   double s1[C], s2[C];
   float rsv[C];
@@ -636,22 +633,31 @@ __global__ __launch_bounds__(256, 2) void f_b1_up(int n, int h, int w, const flo
     const size_t s = tile / per_s;
     const int t = (int)(tile - (long)s * per_s), y0 = (t / tx_n) * TRL, x0 = (t % tx_n) * U_TW;
     __syncthreads();
-    for (int e0 = tid; e0 < CON * DR * DC; e0 += 256 * 8) {
-      float v[FILL_U];
-#pragma unroll
-      for (int u = 0; u < FILL_U; u++) {
-        const int e = e0 + u * 256;
-        const int co = e / (DR * DC), rem = e - co * (DR * DC), i = rem / DC, j = rem - i * DC;
-        const int Y = 2 * y0 - 3 + i, X = 2 * x0 - 3 + j;
-        v[u] = (e < CON * DR * DC && Y >= 0 && Y < H2 && X >= 0 && X < W2) ? dzn[((s * CON + co) * (size_t)H2 + Y) * W2 + X] : 0.f;
+    // the dz tile by LDS-direct loads (lane l of a wave instruction writes dword l behind the instruction's base): every load
+    // of the tile is in flight at once and no register holds one - in batches of 8 loads per thread through registers the
+    // fill was five HBM round trips per tile and the kernel latency-bound (6.7 ms per 4096 rows for upconv3, r04).  The
+    // pad column and the cells outside the plane read a zero word.
+    {
+      constexpr int NE = CON * DR * DP;
+      float *flat = &dzt[0][0][0];
+#pragma unroll 1
+      for (int k = wvu; k < (NE + 63) / 64; k += 4) {
+        const int e = 64 * k + (tid & 63);
+        if (e < NE) {
+          const int co = e / (DR * DP), rem = e - co * (DR * DP), i = rem / DP, j = rem - i * DP;
+          const int Y = 2 * y0 - 3 + i, X = 2 * x0 - 3 + j;
+          const float *src = zero;
+          if (j < DC && Y >= 0 && Y < H2 && X >= 0 && X < W2) src = dzn + ((s * CON + co) * (size_t)H2 + Y) * W2 + X;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                           (__attribute__((address_space(3))) void *)(flat + 64 * k), 4, 0, 0);
+        }
       }
-#pragma unroll
-      for (int u = 0; u < FILL_U; u++) {
-        const int e = e0 + u * 256;
-        if (e < CON * DR * DC) (&dzt[0][0][0])[(e / DC) * DP + e % DC] = v[u];
-      }
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the loads have landed before the barrier publishes them
     }
     __syncthreads();
+    int zoff;   // weights [tap][co][c] through the scalar cache, the loads kept inside the tile loop (see f_b1_pool)
+    asm volatile("s_mov_b32 %0, 0" : "=s"(zoff));
+    const float *__restrict__ wt = wn + zoff;
     for (int e = tid; e < UR * UC; e += 256) {
       const int i = e / UC, j = e - i * UC;
       float acc[C];
@@ -671,7 +677,8 @@ __global__ __launch_bounds__(256, 2) void f_b1_up(int n, int h, int w, const flo
           for (int kx = 0; kx < 3; kx++) {
             const float v = dzt[co][i - ky + 2][j - kx + 2];
             float wv[C];
-            lds_vec<C>(&wl[((ky * 3 + kx) * CON + co) * C], wv);
+#pragma unroll
+            for (int c = 0; c < C; c++) wv[c] = wt[((ky * 3 + kx) * CON + co) * C + c];
             fma_row<C>(acc, v, wv);
           }
 #pragma unroll
@@ -1703,6 +1710,14 @@ __global__ __launch_bounds__(128) void f_top_point_bwd(int n, const ofx_transiti
   }
 }
 
+// wt[tap][co][ci] = w[tap][ci][co]: the kernel of a convolution as its transposed convolution reads it
+__global__ void f_transpose_w(int ci_n, int co_n, const float *w, float *wt) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 9 * ci_n * co_n) return;
+  const int ci = e % ci_n, co = (e / ci_n) % co_n, tap = e / (ci_n * co_n);
+  wt[e] = w[(tap * ci_n + ci) * co_n + co];
+}
+
 FitSrc dev_src(const ofx_fit_src &s) { return FitSrc{s.keep, s.p, s.act, s.h, s.w, s.legacy}; }
 int grid_for(long ntiles, int cap) { return (int)(ntiles < cap ? ntiles : cap); }
 
@@ -1749,25 +1764,30 @@ int ofx_fit_pool_act(hipStream_t st, int n, int C, int H, int W, const float *z,
 }
 
 int ofx_fit_b1_pool(hipStream_t st, int n, int H, int W, int conv, const float *dzn, const float *wn, const float *z,
-                    const float *stat, const float *act, float *g, double *part, int *nblocks) {
+                    const float *stat, const float *act, float *g, double *part, int *nblocks, float *wtr) {
   const int Hp = H / 2, Wp = W / 2;
   const long ntiles = (long)n * ((Hp + P_TR - 1) / P_TR) * ((Wp + P_TW - 1) / P_TW);
   const int grid = grid_for(ntiles, OFX_FIT_MAX_BLOCKS);
   *nblocks = grid;
-  if (conv) hipLaunchKernelGGL(f_b1_pool<true>, dim3(grid), dim3(256), 0, st, n, H, W, dzn, wn, z, stat, act, g, part);
+  if (conv) {
+    hipLaunchKernelGGL(f_transpose_w, dim3(3), dim3(192), 0, st, 8, 8, wn, wtr);
+    hipLaunchKernelGGL(f_b1_pool<true>, dim3(grid), dim3(256), 0, st, n, H, W, dzn, (const float *)wtr, z, stat, act, g, part);
+  }
   else hipLaunchKernelGGL(f_b1_pool<false>, dim3(grid), dim3(256), 0, st, n, H, W, dzn, wn, z, stat, act, g, part);
   OFX_HIP(hipGetLastError());
   return OFX_OK;
 }
 
 int ofx_fit_b1_up(hipStream_t st, int n, int c, int con, int h, int w, int bn, const float *dzn, const float *wn,
-                  const float *zp, const float *stat, const float *act, int legacy, float *g, double *part, int *nblocks) {
+                  const float *zp, const float *stat, const float *act, int legacy, float *g, double *part, int *nblocks,
+                  const float *zero, float *wtr) {
+  hipLaunchKernelGGL(f_transpose_w, dim3(3), dim3(192), 0, st, c, con, wn, wtr);
 #define B1U(C_, CON_, TRL_, BN_) \
   if (c == C_ && con == CON_ && (bn != 0) == BN_) { \
     const long ntiles = (long)n * ((h + TRL_ - 1) / TRL_) * ((w + U_TW - 1) / U_TW); \
     const int grid = grid_for(ntiles, OFX_FIT_MAX_BLOCKS); \
     *nblocks = grid; \
-    hipLaunchKernelGGL((f_b1_up<C_, CON_, TRL_, BN_>), dim3(grid), dim3(256), 0, st, n, h, w, dzn, wn, zp, stat, act, legacy, g, part); \
+    hipLaunchKernelGGL((f_b1_up<C_, CON_, TRL_, BN_>), dim3(grid), dim3(256), 0, st, n, h, w, dzn, (const float *)wtr, zp, stat, act, legacy, g, part, zero); \
     OFX_HIP(hipGetLastError()); return OFX_OK; }
   B1U(1, 2, 5, false)
   B1U(2, 4, 5, true)

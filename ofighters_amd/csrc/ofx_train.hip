@@ -642,7 +642,7 @@ static int dqn_fit_lean(ofx_handle *h, float *weights, float *adam_m, float *ada
   sz(4 * N * 160000); sz(4 * N * 160000);                                                                  // o2, do2
   sz(4 * N * 5000); sz(4 * N * 5008); sz(4 * N * 100); sz(4 * N * 50); sz(4 * N * 2); sz(4 * N * 625);      // p3 f d1 d2 o1 u0
   sz(4 * N * 625); sz(4 * N * 2); sz(4 * N * 100); sz(4 * N * 50); sz(4 * N * 5008); sz(4 * N * 5000);      // gu0 do1 dd1 dd2 df dp3
-  sz(4 * (size_t)L.n_floats); sz(4 * 64); sz(4 * (2 * N + 4096)); sz(8 * ofx_fit_part_doubles()); sz(8 * 32);
+  sz(4 * (size_t)L.n_floats); sz(4 * 64); sz(4 * 64); sz(4 * 576); sz(4 * (2 * N + 4096)); sz(8 * ofx_fit_part_doubles()); sz(8 * 32);
   sz(4 * ofx_fit_out_floats()); sz(8 * ofx_fit_out_doubles(n)); sz(8 * ofx_fit_point_doubles(n)); sz(4 * N * 128);
   for (int k = 0; k < 7; k++) { sz(4 * 32); sz(4 * 16); }   // stat (+ the mean's low parts), act
   if ((rc = keep_workspace(h, &h->fitws, &h->fitws_bytes, need))) return rc;
@@ -651,8 +651,8 @@ static int dqn_fit_lean(ofx_handle *h, float *weights, float *adam_m, float *ada
   float *grad = A.f(L.n_floats);
   OFX_HIP(hipMemsetAsync(grad, 0, sizeof(float) * L.n_floats, st));
   auto G = [&](int t) { return grad + L.offset[t]; };
-  float *loss = A.f(64);
-  OFX_HIP(hipMemsetAsync(loss, 0, 64 * sizeof(float), st));
+  float *loss = A.f(64), *zero = A.f(64), *wtr = A.f(576);
+  OFX_HIP(hipMemsetAsync(loss, 0, 2 * 256, st));   // loss and zero: adjacent 256-byte slots of the arena
   float *lpart = A.f(2 * N + 4096);
   double *part = A.d(ofx_fit_part_doubles()), *sums = A.d(32);
   float *weff = A.f(ofx_fit_out_floats());
@@ -727,7 +727,7 @@ static int dqn_fit_lean(ofx_handle *h, float *weights, float *adam_m, float *ada
   for (int j = 2; j >= 0; j--) {
     const int s = uS[j];
     if (j < 2 || dense) {   // (the textbook path has the last layer's g and its sums already)
-      if ((rc = ofx_fit_b1_up(st, n, kUO[j], kUO[j + 1], s, s, 1, dzn, T(32 + 6 * (j + 1)), uz[j], ustat[j], uact[j], legacy, ug[j], part, &nb))) return rc;
+      if ((rc = ofx_fit_b1_up(st, n, kUO[j], kUO[j + 1], s, s, 1, dzn, T(32 + 6 * (j + 1)), uz[j], ustat[j], uact[j], legacy, ug[j], part, &nb, zero, wtr))) return rc;
       if ((rc = ofx_fit_finish(st, nb, kUO[j], 1.0, part, nullptr, nullptr, sums, nullptr, nullptr))) return rc;
     }
     const bool patch = j == 2 && !dense;   // (g of the last layer is a 4 x 4 patch per sample there: not read, dz written)
@@ -736,7 +736,7 @@ static int dqn_fit_lean(ofx_handle *h, float *weights, float *adam_m, float *ada
                          patch ? rows : nullptr))) return rc;
     dzn = ug[j];
   }
-  if ((rc = ofx_fit_b1_up(st, n, 1, 2, 25, 25, 0, dzn, T(32), u0, nullptr, nullptr, legacy, gu0, part, &nb))) return rc;
+  if ((rc = ofx_fit_b1_up(st, n, 1, 2, 25, 25, 0, dzn, T(32), u0, nullptr, nullptr, legacy, gu0, part, &nb, zero, wtr))) return rc;
   // gu0 = d u0 [n][625], already behind u0's ReLU mask
   K(t_dense_bwd_w, (size_t)26 * 157 * 8, n, 100, 625, d1, gu0, G(30), G(31));
   K(t_dense_bwd_x, ((N + 3) / 4) * 25, n, 100, 625, gu0, T(30), dd1, 0);
@@ -757,7 +757,7 @@ static int dqn_fit_lean(ofx_handle *h, float *weights, float *adam_m, float *ada
   dzn = dp3;
   for (int i = 3; i >= 0; i--) {
     const int s = tS[i];
-    if ((rc = ofx_fit_b1_pool(st, n, s, s, i < 3, dzn, i < 3 ? T(6 * (i + 1)) : nullptr, tz[i], tstat[i], tact[i], tg[i], part, &nb))) return rc;
+    if ((rc = ofx_fit_b1_pool(st, n, s, s, i < 3, dzn, i < 3 ? T(6 * (i + 1)) : nullptr, tz[i], tstat[i], tact[i], tg[i], part, &nb, wtr))) return rc;
     if ((rc = ofx_fit_finish(st, nb, 8, 1.0, part, nullptr, nullptr, sums, nullptr, nullptr))) return rc;
     if (i == 1) {
       // the first two layers: the first has neither z, g nor dz, the second's dz is never stored - only the windows that see
