@@ -1430,17 +1430,17 @@ __global__ __launch_bounds__(256, 2) void f_first_bwd(int n, const uint32_t *__r
       // the four quarters are added in a fixed order
       {
         const int qd = lane >> 4, ci = (lane >> 1) & 7, hh = lane & 1;
-        double a[9];
+        float a[9];   // 16 products per sum in fp32 (the vector ALU's fp64 runs at half rate), the sums themselves in doubles
 #pragma unroll
-        for (int t = 0; t < 9; t++) a[t] = 0.0;
+        for (int t = 0; t < 9; t++) a[t] = 0.f;
         for (int e2 = 16 * qd; e2 < min(16 * qd + 16, ne); e2++) {
-          const double d = (double)drec[wv][e2][ci];
+          const float d = drec[wv][e2][ci];
 #pragma unroll
-          for (int t = 0; t < 9; t++) a[t] += d * (double)vrec[wv][e2][9 * hh + t];
+          for (int t = 0; t < 9; t++) a[t] = fmaf(d, vrec[wv][e2][9 * hh + t], a[t]);
         }
 #pragma unroll
         for (int t = 0; t < 9; t++) {
-          const double b16 = a[t] + __shfl_xor(a[t], 16, 64);
+          const double a0 = (double)a[t], b16 = a0 + __shfl_xor(a0, 16, 64);
           const double b32 = b16 + __shfl_xor(b16, 32, 64);
           if (qd == 0) dw2[wv][((2 * cp + hh) * 9 + t) * C + ci] += b32;
         }
@@ -1488,23 +1488,27 @@ __global__ __launch_bounds__(256, 2) void f_first_bwd(int n, const uint32_t *__r
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // A[u = (tap, map)][c] += (bit `tap` of the pattern around channel c's maximum) * g: lane <-> (u, c), records in queue order
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-      const int kidx = lane + 64 * j;
-      if (kidx < 144) {
-        const int c = kidx & 7, u = kidx >> 3, tap = u >> 1, cin = u & 1;
-        double a = accA[j];
-        for (int e2 = 0; e2 < ne; e2++) {
-          const FsEntry &R = ent[wv][e2];
-          const int kc = (R.kpack >> (2 * c)) & 3;
-          if ((R.pat[cin][kc] >> tap) & 1) a += (double)R.gv[c];
-        }
-        accA[j] = a;
+    {   // lane + 64 j <-> (u, c): c and the map are the lane's own for every j, the tap is (lane >> 4) + 4 j: one read of the
+        // record's pattern serves the three; <= 64 terms per sum in fp32, the sums themselves in doubles
+      const int c = lane & 7, cin = (lane >> 3) & 1, t0 = lane >> 4;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+      for (int e2 = 0; e2 < ne; e2++) {
+        const FsEntry &R = ent[wv][e2];
+        const uint32_t pt = R.pat[cin][(R.kpack >> (2 * c)) & 3];
+        const float gvc = R.gv[c];
+        a0 += ((pt >> t0) & 1u) ? gvc : 0.f;
+        a1 += ((pt >> (t0 + 4)) & 1u) ? gvc : 0.f;
+        a2 += ((pt >> (t0 + 8)) & 1u) ? gvc : 0.f;
       }
+      accA[0] += (double)a0;
+      accA[1] += (double)a1;
+      if (lane < 16) accA[2] += (double)a2;
     }
     if (lane < 24) {   // BatchNorm's sums over the listed windows, records in queue order
       const int c = lane & 7, what = lane >> 3;
-      for (int e2 = 0; e2 < ne; e2++) accS += (double)(what == 0 ? ent[wv][e2].gv[c] : vrec[wv][e2][8 * (what - 1) + c]);
+      float a = 0.f;
+      for (int e2 = 0; e2 < ne; e2++) a += what == 0 ? ent[wv][e2].gv[c] : vrec[wv][e2][8 * (what - 1) + c];
+      accS += (double)a;
     }
     // the queue moves up
     const int rest = cnt - ne;

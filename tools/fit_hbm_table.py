@@ -8,7 +8,7 @@ for line in open(sys.argv[1]):
     m = re.match(r'(FETCH_SIZE|WRITE_SIZE)=([0-9.e+\-]+)', rest)
     hb.setdefault(name.strip()[:58], {})[m.group(1)] = float(m.group(2))
 for line in open(sys.argv[2]):
-    m = re.match(r'(.*?)\s+(\d+)\s+([0-9.]+) ms$', line.rstrip())
+    m = re.match(r'(.*?)\s+(\d+)\s+([0-9.]+) ms(\s+[0-9.]+%)?$', line.rstrip())
     if m: ks[m.group(1).strip()[:58]] = (int(m.group(2)), float(m.group(3)))
 reps = int(sys.argv[3])
 rows = []
