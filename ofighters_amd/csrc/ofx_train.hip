@@ -590,9 +590,10 @@ __global__ void t_count_pads(int n, const ofx_transition *rows, int32_t *out) {
   if (i < n && rows[i].ship < 0) atomicAdd(out, 1);
 }
 
-// a workspace the handle keeps between calls (grown on demand; freed by ofx_destroy)
+// a workspace the handle keeps between calls: grown on demand, given back when a call needs less than a quarter of it (one
+// 4096-row fit leaves 40 GB behind - a handle that then trains on 256 rows should not hold them), freed by ofx_destroy
 static int keep_workspace(ofx_handle *h, void **buf, size_t *have, size_t need) {
-  if (*have >= need) return OFX_OK;
+  if (*have >= need && *have / 4 <= need) return OFX_OK;
   OFX_HIP(hipStreamSynchronize(h->stream));
   if (*buf) (void)hipFree(*buf);
   *buf = nullptr; *have = 0;
@@ -628,7 +629,7 @@ static int dqn_fit_lean(ofx_handle *h, float *weights, float *adam_m, float *ada
   ofx_policy_desc L;
   int rc = ofx_policy_layout(h, &L);
   if (rc) return rc;
-  if ((rc = refuse_pads(h, n, rows, "ofx_dqn_fit"))) return rc;
+  if (!dense && (rc = refuse_pads(h, n, rows, "ofx_dqn_fit"))) return rc;   // (dense targets: ofx_dqn_fit_reference has checked)
   const size_t N = (size_t)n;
   const int legacy = h->opt_bilinear_legacy;
   static const int tS[4] = {400, 200, 100, 50}, uS[3] = {50, 100, 200};
@@ -807,7 +808,7 @@ static int dqn_fit_impl(ofx_handle *h, float *weights, float *adam_m, float *ada
   ofx_policy_desc L;
   int rc = ofx_policy_layout(h, &L);
   if (rc) return rc;
-  if ((rc = refuse_pads(h, n, rows, "ofx_dqn_fit"))) return rc;
+  if (!dense && (rc = refuse_pads(h, n, rows, "ofx_dqn_fit"))) return rc;   // (dense targets: ofx_dqn_fit_reference has checked)
   const size_t N = (size_t)n;
   const int legacy = h->opt_bilinear_legacy;
   // activations: trunk sizes 400,200,100,50 (z, a per layer + pooled), head-2 sizes 50,100,200 (+ upsampled inputs)
