@@ -323,7 +323,7 @@ int ofx_policy_pin_weights(ofx_handle *h, const float *weights);
 #define OFX_OPT_POLICY_BF16 5
 /* Diagnostic: ofx_dqn_fit / ofx_dqn_fit_reference in their PLAIN form (value 1): one kernel per layer and pass, every
  * activation, pooled / up-sampled input and gradient of the graph in HBM (61 MB per row of the minibatch).  The default
- * (0) is the lean form: only the pre-activation tensor of every convolution and the trunk's pooled activations are kept (11 MB per row; the first layer is never materialised), everything else
+ * (0) is the lean form: only the pre-activation tensor of every convolution and the trunk's pooled activations are kept (9.4 MB per row; the first layer is never materialised), everything else
  * is recomputed inside fused tiles.  Same function; the results agree up to fp32 summation order (tests/test_train.py).*/
 #define OFX_OPT_FIT_PLAIN 6
 /* OPT-IN, EXACT: the streaming trunk (OFX_OPT_TRUNK_FUSE) uses the sparsity of its input.  The two input planes are 1-bit
@@ -457,9 +457,9 @@ int ofx_dqn_targets(ofx_handle *h, const float *weights, int32_t n, const ofx_tr
  * transitions' `state` observations and the pointer addresses heat[y][x] (the reference fits on next_state's inputs
  * and indexes [x][y], :280-283: that form is ofx_dqn_fit_reference).  Every row must be a real transition (ship >= 0; use
  * ofx_replay_gather_valid): a padding row would enter the BatchNorm batch statistics and the loss scale, so the call
- * fails with OFX_ERR_INVALID before anything is updated.  The handle keeps a workspace of 11 MB per row between calls
+ * fails with OFX_ERR_INVALID before anything is updated.  The handle keeps a workspace of 9.4 MB per row between calls (given back when a call needs less than a quarter of it)
  * (OFX_OPT_FIT_PLAIN: 61 MB); every reduction has a fixed order, so the same call on the same state gives the same bits.
- * fp32 on the vector ALU (not the hot path): 4.5 ms for 64 rows, 66 ms for 4096 with the target forward (ofx_dqn_fit_reference: 5.5 / 89 ms); synchronises. */
+ * fp32 on the vector ALU (not the hot path): 3.8 ms for 64 rows, 45 ms for 4096 with the target forward (ofx_dqn_fit_reference: 4.8 / 69 ms); synchronises. */
 int ofx_dqn_fit(ofx_handle *h, float *weights, float *adam_m, float *adam_v, int32_t step, float lr, int32_t n,
                 const ofx_transition *rows, const void *bits_prev, const float *y_act, const float *y_ptr,
                 float *grad_out, float *loss_host);

@@ -19,7 +19,10 @@ for k, v in hb.items():
     rows.append((calls / reps * ms, k, calls // reps, ms, rd / 1e9, wr / 1e9, (rd + wr) / 1e9 / ms))
 rows.sort(reverse=True)
 print("%-60s %5s %9s %9s %9s %9s" % ("kernel", "calls", "ms", "read GB", "write GB", "TB/s"))
-tot = totb = 0
+tot = totb = ftot = ftotb = 0
 for t, k, c, ms, rd, wr, bw in rows:
     print("%-60s %5d %9.3f %9.2f %9.2f %9.2f" % (k, c, ms, rd, wr, bw)); tot += t; totb += (rd + wr) * c
-print("sum over the fit's kernels per replay: %.1f ms, %.0f GB, %.2f TB/s" % (tot, totb, totb / tot))
+    if "::f_" in k or k.startswith("t_"):       # ofx_fit.hip / ofx_train.hip: the fit itself (the rest: target forward, the
+        ftot += t; ftotb += (rd + wr) * c        # tool's 12-tick rollout in front, counted as calls / replays)
+print("sum over all kernels of the run per replay: %.1f ms, %.0f GB, %.2f TB/s" % (tot, totb, totb / tot))
+print("sum over the fit's own kernels (f_*, t_*) per replay: %.1f ms, %.1f GB, %.2f TB/s" % (ftot, ftotb, ftotb / ftot))
