@@ -21,7 +21,8 @@ struct ofx_fit_src {
   int kind;
   float *keep;        // POOL in ofx_fit_conv_fwd: also store the pooled activation [n][C][H][W] here (null: do not)
   const void *p;      // bits [n][C][5000] or the producing layer's z [n][C][h][w]
-  const float *act;   // the producing layer's {scale, shift} per channel; null for bits / raw
+  const float *act;   // the producing layer's {scale, shift} per channel; null for bits / raw; PLANE: 16 bytes of zeros in
+                      // device memory (what an LDS-direct load reads for a cell outside the plane)
   int h, w;           // dims of p's planes
   int legacy;         // OFX_OPT_BILINEAR_LEGACY
 };

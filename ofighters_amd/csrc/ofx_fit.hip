@@ -69,7 +69,8 @@ struct FitSrc {
   float *keep;        // POOL in f_conv_fwd: where the pooled activation [n][C][H][W] is written (the weight gradient reads it
                       // back through the PLANE source instead of pooling four times the bytes of z again); may be null
   const void *p;      // bits [n][C][5000] or the producing layer's z [n][C][h][w]
-  const float *act;   // the producing layer's {scale, shift} per channel (relu(z * scale + shift)); unused for bits / raw
+  const float *act;   // the producing layer's {scale, shift} per channel (relu(z * scale + shift)); unused for bits / raw;
+                      // PLANE: 16 bytes of zeros in device memory
   int h, w;           // dims of p's planes
   int legacy;
 };
@@ -144,24 +145,30 @@ __device__ __forceinline__ void fill_input(float (*in)[TR + 2][LP], float *lo, c
         o[0] = bn_act(v.x, sc, sh); o[1] = bn_act(v.y, sc, sh); o[2] = bn_act(v.z, sc, sh); o[3] = bn_act(v.w, sc, sh);
       }
     }
-  } else if constexpr (SRC == OFX_FIT_SRC_PLANE && TW % 4 == 0) {
-    // a stored plane as it is (zero outside): one element at either end of a tile row, 16-byte loads between them
-    constexpr int ST = TW / 4 + 2;
+  } else if constexpr (SRC == OFX_FIT_SRC_PLANE) {
+    // a stored plane as it is (zero outside) by LDS-direct loads: lane l of a wave instruction writes dword l behind the
+    // instruction's base, so the tile is filled front to back, 64 dwords at a time - every load of the tile in flight at once,
+    // no staging register, no ds_write.  (Through registers, 16 bytes per load, the in-order vmcnt left one or two loads per
+    // thread in flight in front of their LDS stores: ~24 KB per CU where HBM's latency wants 64 - the conv2 forward ran at
+    // 3.2 TB/s.)  Cells outside the plane and the row's pad read a zero word (S.act: 16 bytes of zeros for this source).
+    static_assert(NT % 64 == 0, "whole waves");
+    constexpr int NE = CI * (TR + 2) * LP;
+    const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float *zp = reinterpret_cast<const float *>(S.p);
-    for (int e = tid; e < CI * (TR + 2) * ST; e += NT) {
-      const int c = e / ((TR + 2) * ST), rem = e - c * ((TR + 2) * ST), yy = rem / ST, st = rem - yy * ST;
-      const int y = y0 - 1 + yy;
-      const bool row = y >= 0 && y < H;
-      const float *zr = zp + ((s * CI + c) * (size_t)H + (row ? y : 0)) * W;
-      if (st == 0) in[c][yy][0] = (row && x0 > 0) ? zr[x0 - 1] : 0.f;
-      else if (st == ST - 1) in[c][yy][TW + 1] = (row && x0 + TW < W) ? zr[x0 + TW] : 0.f;
-      else {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row) v = *reinterpret_cast<const float4 *>(zr + x0 + 4 * (st - 1));
-        float *o = &in[c][yy][1 + 4 * (st - 1)];
-        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    float *flat = &in[0][0][0];
+#pragma unroll 1
+    for (int k = wvu; k < (NE + 63) / 64; k += NT / 64) {
+      const int e = 64 * k + (tid & 63);
+      if (e < NE) {
+        const int c = e / ((TR + 2) * LP), rem = e - c * ((TR + 2) * LP), yy = rem / LP, xx = rem - yy * LP;
+        const int y = y0 - 1 + yy, x = x0 - 1 + xx;
+        const float *src = S.act;
+        if (xx < TW + 2 && y >= 0 && y < H && x >= 0 && x < W) src = zp + ((s * CI + c) * (size_t)H + y) * W + x;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(flat + 64 * k), 4, 0, 0);
       }
     }
+    // the caller waits (fill_landed) in front of the barrier that publishes the tile
   } else if constexpr (SRC == OFX_FIT_SRC_POOL) {
     // two pooled pixels per step from two 16-byte loads (tile column 0 is an odd plane column: one single step at either
     // end of a row, TW / 2 pairs between them)
@@ -269,6 +276,13 @@ __device__ __forceinline__ void fill_input(float (*in)[TR + 2][LP], float *lo, c
   }
 }
 
+// in front of the barrier behind fill_input: LDS-direct loads are published by vmcnt(0), which the memory model does not
+// promise at a workgroup fence (k_conv3_stream)
+template <int SRC>
+__device__ __forceinline__ void fill_landed() {
+  if constexpr (SRC == OFX_FIT_SRC_PLANE) __builtin_amdgcn_s_waitcnt(0x0F70);
+}
+
 // sum of v over the 64 lanes (every lane gets it)
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -327,6 +341,7 @@ __global__ __launch_bounds__(256, 3) void f_conv_fwd(int n, int H, int W, FitSrc
     const int t = (int)(tile - (long)s * per_s), y0 = (t / tx_n) * F_TR, x0 = (t % tx_n) * TW;
     __syncthreads();
     if (OFX_FIT_ABLATE != 1) fill_input<SRC, CI, F_TR, TW, LP, 256>(in, lo, S, s, y0, x0, H, W, tid);
+    fill_landed<SRC>();
     __syncthreads();
     if constexpr (SRC == OFX_FIT_SRC_POOL) {
       if (S.keep) {   // block-uniform: the tile's own pixels of the pooled activation, once
@@ -860,6 +875,7 @@ __global__ __launch_bounds__(NT) void f_bw(int n, int H, int W, FitSrc S, float 
 #pragma unroll
       for (int k = 0; k < V; k++) dzt[co][yy][V * xv + k] = d[k];
     }
+    fill_landed<SRC>();
     __syncthreads();
     for (int grp = sub; grp < NGRP; grp += NSUB) {
       const int p = 64 * grp + lane;
@@ -980,6 +996,7 @@ __global__ __launch_bounds__(256) void f_bw_small(int n, int H, int W, FitSrc S,
         dzt[co][yy][xx] = d;
       }
     }
+    fill_landed<SRC>();
     __syncthreads();
     if (active) {
       float dv[CO][4];

@@ -674,7 +674,7 @@ static int dqn_fit_lean(ofx_handle *h, float *weights, float *adam_m, float *ada
   // of z's bytes); the weight gradient reads that plane back instead of pooling z a second time
   auto trunk_src = [&](int i, bool backward) {
     if (i == 0) return ofx_fit_src{OFX_FIT_SRC_BITS, nullptr, bits_prev, nullptr, 400, 400, legacy};
-    if (backward || i == 1) return ofx_fit_src{OFX_FIT_SRC_PLANE, nullptr, tp[i - 1], nullptr, tS[i], tS[i], legacy};
+    if (backward || i == 1) return ofx_fit_src{OFX_FIT_SRC_PLANE, nullptr, tp[i - 1], zero, tS[i], tS[i], legacy};
     return ofx_fit_src{OFX_FIT_SRC_POOL, tp[i - 1], tz[i - 1], tact[i - 1], tS[i - 1], tS[i - 1], legacy};
   };
   auto head_src = [&](int j) {   // input of head-2 layer j (3 = the output convolution)

@@ -443,9 +443,13 @@ class ArenaBatch:
         un = lambda x: np.unpackbits(x, bitorder="little").reshape(self.H, self.W)
         return un(a), un(b)
 
-    def replay_sample(self, seed, draw, batch):
-        """random.sample(memory, min(batch, len)) per arena -> (slot DeviceBuffer [N][batch], n DeviceBuffer [N])."""
-        slot, n = DeviceBuffer(4 * self.N * batch), DeviceBuffer(4 * self.N)
+    def replay_sample(self, seed, draw, batch, slot=None, n=None):
+        """random.sample(memory, min(batch, len)) per arena -> (slot DeviceBuffer [N][batch], n DeviceBuffer [N]); the
+        caller may hand in both buffers (DeviceTrainer keeps them between replays)."""
+        if slot is None:
+            slot = DeviceBuffer(4 * self.N * batch)
+        if n is None:
+            n = DeviceBuffer(4 * self.N)
         nat.check(nat.lib().ofx_replay_sample(self._h, seed, int(draw), int(batch), slot.ptr, n.ptr))
         return slot, n
 

@@ -74,7 +74,7 @@ class DeviceTrainer:
         cnt, _ = b.replay_count()
         if int(cnt.max()) == 0:
             return None
-        slot, n_s = b.replay_sample(self.seed, self.draws, bs)
+        slot, n_s = b.replay_sample(self.seed, self.draws, bs, self._scratch("slot", 4 * b.N * bs), self._scratch("n_s", 4 * b.N))
         self.draws += 1
         # the sampled transitions of all arenas, WITHOUT the -1 pads of arenas that hold fewer than bs (a pad would enter
         # the BatchNorm batch statistics and the loss scale of the fit; the reference's batch is min(bs, len(memory)) real

@@ -10,7 +10,7 @@ from ofighters_amd.agents.policy_weights import synthetic
 N, M = 4096, 8
 b = ArenaBatch(N, M)
 eps = Epsilon_decay(); eps.set(0.1)
-tr = DeviceTrainer(b, synthetic(), epsilon=eps, batch_size=8, memory_size=64, frames=96, fit_batch=64)
+tr = DeviceTrainer(b, synthetic(), epsilon=eps, batch_size=8, memory_size=64, frames=96, fit_batch=int(sys.argv[1]) if len(sys.argv) > 1 else 256)
 roll = TrainingRollout(b, tr, ["random"] * M, 1, policy_ships=(0,))
 roll.run(30); b.sync()
 import cProfile, pstats
