@@ -444,6 +444,9 @@ def main():
     ap.add_argument("--policy-bf16", type=int, nargs="?", const=1, default=0, choices=[0, 1, 2],
                     help="OFX_OPT_POLICY_BF16 for the main line: 1 bf16, 2 fp16 operands (opt-in reduced precision: NOT the "
                          "headline configuration)")
+    ap.add_argument("--trunk-sparse", action="store_true",
+                    help="OFX_OPT_TRUNK_SPARSE for the main line (exact, bit-identical, opt-in: NOT the headline "
+                         "configuration - for profiling the secondary lines)")
     ap.add_argument("--no-bf16-accuracy", dest="bf16_accuracy", action="store_false",
                     help="skip the float64 evaluation behind the bf16 lines' accuracy numbers (~20 s of CPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -553,9 +556,9 @@ def main():
         b.close()
         return rec
 
-    headline_full = N == 4096 and M == 8 and n_pol == M and not args.policy_alive_only and not args.policy_bf16
+    headline_full = N == 4096 and M == 8 and n_pol == M and not args.policy_alive_only and not args.policy_bf16 and not args.trunk_sparse
     head = measure(args.workload, n_pol, args.policy_alive_only, args.warmup, args.steps,
-                   headline_full or args.workload != "step+obs+policy", bf16=args.policy_bf16)
+                   headline_full or args.workload != "step+obs+policy", bf16=args.policy_bf16, sparse=args.trunk_sparse)
     do_policy = args.workload == "step+obs+policy"
     out = {
         "metric": METRIC,

@@ -1187,17 +1187,6 @@ __global__ __launch_bounds__(F12_THREADS) void k_trunk12(ConvParams p, const flo
     const bool more = nimg < p.images;
     const int na = last ? 0 : R0 + F12_TH + 1, nb = last ? F12_TH + 1 : min(R0 + 2 * F12_TH + 1, H1);
     unsigned nextw = 0u;
-    // SPARSE: the bit rows travel TWO steps ahead.  The dense GEMM phase hides the ~2 us of a fetch issued at its start;
-    // the sparse step is over before the word lands (stamps: 5 700 of a step's 12 600 cycles in front of bits_commit).
-    // Here the word fetched a whole step ago is committed (the next step's rows) and the step after that is requested.
-    if constexpr (SPARSE) {
-      if (more) bits_commit(buf ^ 1, na, nb, w_ahead);
-      int i2 = nimg, s2 = last ? 0 : step + 1;
-      if (++s2 == H1 / F12_TH) { s2 = 0; i2 += (int)gridDim.x; }
-      const int r2 = s2 * F12_TH;
-      w_ahead = i2 < p.images ? bits_fetch(i2, s2 ? r2 + 1 : 0, min(r2 + F12_TH + 1, H1)) : 0u;
-    }
-
     T12_STAMP(st_b);
     // ---- phase A: conv1 table look-up + pool + ReLU, two adjacent p1 pixels per thread ----
     if (step && pb - pa < F12_TH)  // last step: p1 row 200 does not exist - the tile row behind the image is zero
@@ -1275,6 +1264,18 @@ __global__ __launch_bounds__(F12_THREADS) void k_trunk12(ConvParams p, const flo
     T12_STAMP(st_a);
     // ---- phase B: conv2 on the tile; the next step's bit rows are fetched meanwhile ----
     if constexpr (!SPARSE) { if (more) nextw = bits_fetch(nimg, na, nb); }
+    // SPARSE: the bit rows travel TWO steps ahead.  The dense GEMM phase hides the ~2 us of a fetch issued at its start;
+    // the sparse step is over before the word lands.  Here, BETWEEN the two phases, the word fetched a whole step ago is
+    // committed (the next step's rows) and the step after that is requested: the wait for the word is a vmcnt(0), which
+    // also waits for every p2 store in flight - at the top of the step those are the stores the previous GEMM phase has
+    // just issued (stamps: 5 000 of a step's 12 700 cycles went there), behind phase A they are a table phase old.
+    if constexpr (SPARSE) {
+      if (more) bits_commit(buf ^ 1, na, nb, w_ahead);
+      int i2 = nimg, s2 = last ? 0 : step + 1;
+      if (++s2 == H1 / F12_TH) { s2 = 0; i2 += (int)gridDim.x; }
+      const int r2 = s2 * F12_TH;
+      w_ahead = i2 < p.images ? bits_fetch(i2, s2 ? r2 + 1 : 0, min(r2 + F12_TH + 1, H1)) : 0u;
+    }
 
     if constexpr (SPARSE) {
       float bwl[BF16 ? 1 : NK];
