@@ -1392,7 +1392,7 @@ __global__ __launch_bounds__(256, 2) void f_first_bwd(int n, const uint32_t *__r
         qbits[wv][at] = fb;
       }
       cnt += __builtin_popcountll(m);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
     if (cnt < 64 && !(step == NSTEP && cnt > 0)) continue;   // wave-uniform
@@ -1441,7 +1441,7 @@ __global__ __launch_bounds__(256, 2) void f_first_bwd(int n, const uint32_t *__r
           fma_row<C>(dp, v[h][t], wv8);
           vrec[wv][lane][9 * h + t] = v[h][t];
         }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
       // dW2's listed part for this pair of co: lane = (quarter of the records, ci, co of the pair), nine taps each;
       // the four quarters are added in a fixed order
@@ -1462,7 +1462,7 @@ __global__ __launch_bounds__(256, 2) void f_first_bwd(int n, const uint32_t *__r
           if (qd == 0) dw2[wv][((2 * cp + hh) * 9 + t) * C + ci] += b32;
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
     // x-hat of the window's four pixels (dy, dx): pattern = bits dx .. dx + 2 of rows dy .. dy + 2 of the 4 x 4 block
@@ -1502,7 +1502,7 @@ __global__ __launch_bounds__(256, 2) void f_first_bwd(int n, const uint32_t *__r
       vrec[wv][lane][8 + c] = ok ? dp[c] : 0.f;
     }
     ent[wv][lane] = E;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // A[u = (tap, map)][c] += (bit `tap` of the pattern around channel c's maximum) * g: lane <-> (u, c), records in queue order
     {   // lane + 64 j <-> (u, c): c and the map are the lane's own for every j, the tap is (lane >> 4) + 4 j: one read of the
@@ -1532,11 +1532,11 @@ __global__ __launch_bounds__(256, 2) void f_first_bwd(int n, const uint32_t *__r
     uint16_t mw = 0;
     uint32_t mb = 0u;
     if (lane < rest) { mw = qwin[wv][64 + lane]; mb = qbits[wv][64 + lane]; }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (lane < rest) { qwin[wv][lane] = mw; qbits[wv][lane] = mb; }
     cnt = rest;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
   if (lane < 24) red[wv][144 + lane] = accS;

@@ -322,7 +322,7 @@ __device__ __forceinline__ float hg_corner(G get, int n, int yc, int xc, const f
 
 __global__ __launch_bounds__(HG_THREADS) void k_head_frames(HeadParams2 p) {
   __shared__ __align__(16) float sm[HG_TOTAL];
-  __shared__ float efr_s[192];
+  __shared__ float efr_s[192], w4s[72];
   // the ship of a block rotates inside its group of 8 (blocks go round-robin over the 8 XCDs: a regular ship mask
   // must not leave all the live workgroups on one of them)
   const int s = hd_ship(p, (int)((blockIdx.x & ~7u) | ((blockIdx.x + (blockIdx.x >> 3)) & 7u)));
@@ -353,6 +353,7 @@ __global__ __launch_bounds__(HG_THREADS) void k_head_frames(HeadParams2 p) {
       if (u * HG_THREADS + tid < NE) l1p[at[u]] = v[u];
   }
   if (tid < 192) efr_s[tid] = p.efr[tid];
+  if (tid < 72) w4s[tid] = p.w4raw[tid];
   __syncthreads();
 
   // ---- uprelu2 bands: band v, M-tile m: pixels 16 m + n16 along the band (50), all four phases ----
@@ -468,17 +469,15 @@ __global__ __launch_bounds__(HG_THREADS) void k_head_frames(HeadParams2 p) {
   __syncthreads();
   // the tap planes along the four lines: V_t = sum_c w4[t][c] uprelu3_c (what k_head_stream's ring holds; the same
   // sequential sum over c as the 1x1's MFMA chain)
-  for (int cell = tid; cell < 4 * 200; cell += HG_THREADS) {   // a thread owns a cell: 8 channels in, 9 taps out (weights: scalar loads)
-    const f32x4 ua = *reinterpret_cast<const f32x4 *>(u3l + cell * 8), ub = *reinterpret_cast<const f32x4 *>(u3l + cell * 8 + 4);
-    const float u[8] = {ua[0], ua[1], ua[2], ua[3], ub[0], ub[1], ub[2], ub[3]};
-    float *dst = p.vfr + (size_t)s * 7200 + cell * 9;
+  // a thread owns one (cell, tap) of an iteration: consecutive lanes store consecutive floats.  (r04 also tried a thread per
+  // cell with its nine taps and the weights as scalar loads - a ninth of the iterations, but every store instruction of a
+  // wave then strides over 36 bytes: 0.91 against 0.79 ms for the kernel, tools/ab_frames.sh)
+  for (int e = tid; e < 4 * 200 * 9; e += HG_THREADS) {
+    const int tp = e % 9, cell = e / 9;
+    float acc = 0.f;
 #pragma unroll
-    for (int tp = 0; tp < 9; tp++) {
-      float acc = 0.f;
-#pragma unroll
-      for (int ci = 0; ci < 8; ci++) acc = fmaf(p.w4raw[tp * 8 + ci], u[ci], acc);
-      dst[tp] = acc;
-    }
+    for (int ci = 0; ci < 8; ci++) acc = fmaf(w4s[tp * 8 + ci], u3l[cell * 8 + ci], acc);
+    p.vfr[(size_t)s * 7200 + e] = acc;
   }
 
   // ---- corrections of the heat-map frame pixels (PrepLayout::efr: the conv taps of the row / column outside the
