@@ -126,26 +126,7 @@ template <int SRC, int CI, int TR, int TW> constexpr int lo_floats = src_is_up<S
 template <int SRC, int CI, int TR, int TW, int LP, int NT, int FU = 8, bool STAGE = true>
 __device__ __forceinline__ void fill_input(float (*in)[TR + 2][LP], float *lo, const FitSrc &S, size_t s, int y0, int x0,
                                            int H, int W, int tid) {
-  if constexpr (SRC == OFX_FIT_SRC_ACTREP) {
-    // rows of the plane itself: one element at either end of a tile row, TW / 4 aligned 16-byte loads between them
-    // (element-wise this fill was 79 % of the phase-form output convolution: tools/fit_ablate.sh)
-    static_assert(TW % 4 == 0, "tile width");
-    constexpr int ST = TW / 4 + 2;
-    const float *zp = reinterpret_cast<const float *>(S.p);
-    for (int e = tid; e < CI * (TR + 2) * ST; e += NT) {
-      const int c = e / ((TR + 2) * ST), rem = e - c * ((TR + 2) * ST), yy = rem / ST, st = rem - yy * ST;
-      const int yc = min(max(y0 - 1 + yy, 0), H - 1);
-      const float sc = S.act[2 * c], sh = S.act[2 * c + 1];
-      const float *zr = zp + ((s * CI + c) * (size_t)H + yc) * W;
-      if (st == 0) in[c][yy][0] = bn_act(zr[max(x0 - 1, 0)], sc, sh);
-      else if (st == ST - 1) in[c][yy][TW + 1] = bn_act(zr[min(x0 + TW, W - 1)], sc, sh);
-      else {
-        const float4 v = *reinterpret_cast<const float4 *>(zr + x0 + 4 * (st - 1));
-        float *o = &in[c][yy][1 + 4 * (st - 1)];
-        o[0] = bn_act(v.x, sc, sh); o[1] = bn_act(v.y, sc, sh); o[2] = bn_act(v.z, sc, sh); o[3] = bn_act(v.w, sc, sh);
-      }
-    }
-  } else if constexpr (SRC == OFX_FIT_SRC_PLANE) {
+  if constexpr (SRC == OFX_FIT_SRC_PLANE) {
     // a stored plane as it is (zero outside) by LDS-direct loads: lane l of a wave instruction writes dword l behind the
     // instruction's base, so the tile is filled front to back, 64 dwords at a time - every load of the tile in flight at once,
     // no staging register, no ds_write.  (Through registers, 16 bytes per load, the in-order vmcnt left one or two loads per
@@ -169,6 +150,25 @@ __device__ __forceinline__ void fill_input(float (*in)[TR + 2][LP], float *lo, c
       }
     }
     // the caller waits (fill_landed) in front of the barrier that publishes the tile
+  } else if constexpr (SRC == OFX_FIT_SRC_ACTREP) {
+    // rows of the plane itself: one element at either end of a tile row, TW / 4 aligned 16-byte loads between them
+    // (element-wise this fill was 79 % of the phase-form output convolution: tools/fit_ablate.sh)
+    static_assert(TW % 4 == 0, "tile width");
+    constexpr int ST = TW / 4 + 2;
+    const float *zp = reinterpret_cast<const float *>(S.p);
+    for (int e = tid; e < CI * (TR + 2) * ST; e += NT) {
+      const int c = e / ((TR + 2) * ST), rem = e - c * ((TR + 2) * ST), yy = rem / ST, st = rem - yy * ST;
+      const int yc = min(max(y0 - 1 + yy, 0), H - 1);
+      const float sc = S.act[2 * c], sh = S.act[2 * c + 1];
+      const float *zr = zp + ((s * CI + c) * (size_t)H + yc) * W;
+      if (st == 0) in[c][yy][0] = bn_act(zr[max(x0 - 1, 0)], sc, sh);
+      else if (st == ST - 1) in[c][yy][TW + 1] = bn_act(zr[min(x0 + TW, W - 1)], sc, sh);
+      else {
+        const float4 v = *reinterpret_cast<const float4 *>(zr + x0 + 4 * (st - 1));
+        float *o = &in[c][yy][1 + 4 * (st - 1)];
+        o[0] = bn_act(v.x, sc, sh); o[1] = bn_act(v.y, sc, sh); o[2] = bn_act(v.z, sc, sh); o[3] = bn_act(v.w, sc, sh);
+      }
+    }
   } else if constexpr (SRC == OFX_FIT_SRC_POOL) {
     // two pooled pixels per step from two 16-byte loads (tile column 0 is an odd plane column: one single step at either
     // end of a row, TW / 2 pairs between them)
