@@ -755,14 +755,19 @@ constexpr int OFX_FIT_BW_NT = 512, OFX_FIT_BW_TR = 8;   // f_bw workgroups (256 
 // (gp [n][CO][16], f_top_point_bwd; the patch starts at cell ((py - 1) / 2 - 1, (px - 1) / 2 - 1) of the sample's pointer):
 // g is not read - 1.28 MB per row that were a memset and a read of zeros - and dz is written to it.
 template <int CI, int CO, int SRC, int TW, bool BN, int NT, int TR, bool PHASE = false, bool POINT = false>
-__global__ __launch_bounds__(NT) void f_bw(int n, int H, int W, FitSrc S, float *__restrict__ g,
+__global__ __launch_bounds__(NT, NT == 512 ? 4 : 2) void f_bw(int n, int H, int W, FitSrc S, float *__restrict__ g,
                                             const float *__restrict__ z, const float *__restrict__ stat,
                                             const float *__restrict__ gamma, const double *__restrict__ sums, double count,
                                             double *__restrict__ part, const float *__restrict__ gp,
                                             const ofx_transition *__restrict__ rows) {
-  constexpr int LP = TW + 2, NA = 9 * CO + CO, NSUB = (NT / 64) / CI, NPX = TR * TW, NGRP = (NPX + 63) / 64;
+  // (the bias gradient of a convolution in front of a BatchNorm is exactly zero: no sums kept for it, written as 0)
+  constexpr int LP = TW + 2, NA = 9 * CO + (BN ? 0 : CO), NSUB = (NT / 64) / CI, NPX = TR * TW, NGRP = (NPX + 63) / 64;
   __shared__ float in[CI][TR + 2][LP];
-  float *const lo = nullptr;   // no staging here (STAGE = false)
+  // up-sampling sources: the low-res activation the tile interpolates is staged first (ONE batch of loads per thread, then
+  // LDS reads) - element by element from global memory the fill was 8 dependent HBM round trips and 4 bilinear set-ups per cell
+  constexpr bool STG = src_is_up<SRC>;
+  constexpr int FU = STG ? (lo_floats<SRC, CI, TR, TW> + NT - 1) / NT : 1;
+  __shared__ float lo[STG ? lo_floats<SRC, CI, TR, TW> : 1];
   __shared__ float dzt[CO][TR][TW];
   __shared__ double dacc[NT / 64][NA];
   // BatchNorm's backward per channel: dz = a (g - m0 - (z - mean) c).  Computed once: written out per element, the two
@@ -811,7 +816,7 @@ __global__ __launch_bounds__(NT) void f_bw(int n, int H, int W, FitSrc S, float 
       pm0 = (((min(max(rows[s].px, 0), 399)) - 1) >> 1) - 1;
     }
     __syncthreads();
-    fill_input<SRC, CI, TR, TW, LP, NT, 1, false>(in, lo, S, s, y0, x0, H, W, tid);
+    fill_input<SRC, CI, TR, TW, LP, NT, FU, STG>(in, lo, S, s, y0, x0, H, W, tid);
     // V gradient values per step (16-byte loads where the rows allow): the index arithmetic is paid once per V values
     constexpr int V = TW % 4 == 0 ? 4 : 2, TWV = TW / V;
     static_assert(TW % V == 0, "tile width");
@@ -898,8 +903,10 @@ __global__ __launch_bounds__(NT) void f_bw(int n, int H, int W, FitSrc S, float 
             for (int co = 0; co < CO; co++) acc[(ky * 3 + kx) * CO + co] = fmaf(v, dv[co], acc[(ky * 3 + kx) * CO + co]);
           }
         }
+      if constexpr (!BN) {
 #pragma unroll
-      for (int co = 0; co < CO; co++) acc[9 * CO + co] += dv[co];
+        for (int co = 0; co < CO; co++) acc[9 * CO + co] += dv[co];
+      }
     }
     if (++since == W_FLUSH) { flush(); since = 0; }
   }
@@ -911,7 +918,7 @@ __global__ __launch_bounds__(NT) void f_bw(int n, int H, int W, FitSrc S, float 
     if (k < 9 * CI * CO) {
       const int co = k % CO, c = (k / CO) % CI, tap = k / (CO * CI);
       for (int sb = 0; sb < NSUB; sb++) v += dacc[sb * CI + c][tap * CO + co];
-    } else {
+    } else if constexpr (!BN) {
       const int co = k - 9 * CI * CO;
       for (int sb = 0; sb < NSUB; sb++) v += dacc[sb * CI][9 * CO + co];
     }
