@@ -109,6 +109,30 @@ __device__ __forceinline__ float src_value(const FitSrc &S, size_t s, int c, int
   }
 }
 
+// A tile of NROWS rows x PITCH floats in LDS by LDS-direct loads, a ROW per wave and step: lane l of a wave instruction writes
+// dword l behind the instruction's base, so a row takes ceil(PITCH / 64) instructions.  row_ptr(r) (wave-uniform: scalar
+// registers) is the global address of the plane row under tile row r, or null outside the plane; tile column c <-> plane
+// column xlo + c; columns >= NCOL (the pad) and cells outside the plane read *zero.  Every load of the tile is in flight at
+// once, no register holds one; per load a lane spends two compares, one select and one address add - enumerating the tile
+// flat (element -> row, column by division, 64-bit address per lane) cost ~30 vector instructions per load, 40 % of what the
+// conv2 forward issued (SQ_INSTS_VALU, profiles/r04_fit_pmc_sq.txt).  The caller waits (fill_landed) in front of its barrier.
+template <int NROWS, int PITCH, int NCOL, int NWAVES, class RowPtr>
+__device__ __forceinline__ void lds_direct_rows(float *tile, int wvu, int lane, int xlo, int W, const float *zero, RowPtr row_ptr) {
+#pragma unroll 1
+  for (int r = wvu; r < NROWS; r += NWAVES) {
+    const float *rp = row_ptr(r);
+#pragma unroll
+    for (int h = 0; h < (PITCH + 63) / 64; h++) {
+      const int c = 64 * h + lane, x = xlo + c;
+      if (c < PITCH) {
+        const float *src = (rp != nullptr && c < NCOL && x >= 0 && x < W) ? rp + x : zero;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(tile + r * PITCH + 64 * h), 4, 0, 0);
+      }
+    }
+  }
+}
+
 // Fill loops run in batches of FILL_U elements per thread, all global loads of a batch requested before the first value
 // is used: written as a plain `load, compute, store to LDS` loop the compiler waits for every load in turn, and with two
 // or three workgroups per CU nothing hides ~2 us of HBM latency per iteration (the first lean build spent 38 000 cycles
@@ -127,28 +151,16 @@ template <int SRC, int CI, int TR, int TW, int LP, int NT, int FU = 8, bool STAG
 __device__ __forceinline__ void fill_input(float (*in)[TR + 2][LP], float *lo, const FitSrc &S, size_t s, int y0, int x0,
                                            int H, int W, int tid) {
   if constexpr (SRC == OFX_FIT_SRC_PLANE) {
-    // a stored plane as it is (zero outside) by LDS-direct loads: lane l of a wave instruction writes dword l behind the
-    // instruction's base, so the tile is filled front to back, 64 dwords at a time - every load of the tile in flight at once,
-    // no staging register, no ds_write.  (Through registers, 16 bytes per load, the in-order vmcnt left one or two loads per
-    // thread in flight in front of their LDS stores: ~24 KB per CU where HBM's latency wants 64 - the conv2 forward ran at
-    // 3.2 TB/s.)  Cells outside the plane and the row's pad read a zero word (S.act: 16 bytes of zeros for this source).
+    // a stored plane as it is (zero outside) by LDS-direct loads (lds_direct_rows).  (Through registers, 16 bytes per load,
+    // the in-order vmcnt left one or two loads per thread in flight in front of their LDS stores: ~24 KB per CU where HBM's
+    // latency wants 64.)  Cells outside the plane and the row's pad read a zero word (S.act: 16 bytes of zeros for this source).
     static_assert(NT % 64 == 0, "whole waves");
-    constexpr int NE = CI * (TR + 2) * LP;
-    const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float *zp = reinterpret_cast<const float *>(S.p);
-    float *flat = &in[0][0][0];
-#pragma unroll 1
-    for (int k = wvu; k < (NE + 63) / 64; k += NT / 64) {
-      const int e = 64 * k + (tid & 63);
-      if (e < NE) {
-        const int c = e / ((TR + 2) * LP), rem = e - c * ((TR + 2) * LP), yy = rem / LP, xx = rem - yy * LP;
-        const int y = y0 - 1 + yy, x = x0 - 1 + xx;
-        const float *src = S.act;
-        if (xx < TW + 2 && y >= 0 && y < H && x >= 0 && x < W) src = zp + ((s * CI + c) * (size_t)H + y) * W + x;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                         (__attribute__((address_space(3))) void *)(flat + 64 * k), 4, 0, 0);
-      }
-    }
+    lds_direct_rows<CI * (TR + 2), LP, TW + 2, NT / 64>(&in[0][0][0], __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63, x0 - 1, W,
+                                                         S.act, [&](int r) -> const float * {
+      const int c = r / (TR + 2), y = y0 - 1 + (r - c * (TR + 2));
+      return (y >= 0 && y < H) ? zp + ((s * CI + c) * (size_t)H + y) * W : nullptr;
+    });
     // the caller waits (fill_landed) in front of the barrier that publishes the tile
   } else if constexpr (SRC == OFX_FIT_SRC_ACTREP) {
     // rows of the plane itself: one element at either end of a tile row, TW / 4 aligned 16-byte loads between them
@@ -653,20 +665,10 @@ __global__ __launch_bounds__(256, 2) void f_b1_up(int n, int h, int w, const flo
     // fill was five HBM round trips per tile and the kernel latency-bound (6.7 ms per 4096 rows for upconv3, r04).  The
     // pad column and the cells outside the plane read a zero word.
     {
-      constexpr int NE = CON * DR * DP;
-      float *flat = &dzt[0][0][0];
-#pragma unroll 1
-      for (int k = wvu; k < (NE + 63) / 64; k += 4) {
-        const int e = 64 * k + (tid & 63);
-        if (e < NE) {
-          const int co = e / (DR * DP), rem = e - co * (DR * DP), i = rem / DP, j = rem - i * DP;
-          const int Y = 2 * y0 - 3 + i, X = 2 * x0 - 3 + j;
-          const float *src = zero;
-          if (j < DC && Y >= 0 && Y < H2 && X >= 0 && X < W2) src = dzn + ((s * CON + co) * (size_t)H2 + Y) * W2 + X;
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                           (__attribute__((address_space(3))) void *)(flat + 64 * k), 4, 0, 0);
-        }
-      }
+      lds_direct_rows<CON * DR, DP, DC, 4>(&dzt[0][0][0], wvu, tid & 63, 2 * x0 - 3, W2, zero, [&](int r) -> const float * {
+        const int co = r / DR, Y = 2 * y0 - 3 + (r - co * DR);
+        return (Y >= 0 && Y < H2) ? dzn + ((s * CON + co) * (size_t)H2 + Y) * W2 : nullptr;
+      });
       __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the loads have landed before the barrier publishes them
     }
     __syncthreads();
