@@ -37,9 +37,10 @@ int ofx_fit_finish(hipStream_t st, int nblocks, int c_n, double count, const dou
 int ofx_fit_pool_act(hipStream_t st, int n, int C, int H, int W, const float *z, const float *act, float *p);
 // g = d loss / d (BN output of the layer), ReLU-masked, through the pooling in front of the next convolution
 // (conv: dzn = that convolution's dz [n][8][H/2][W/2], wn its kernel; else dzn = d pooled output)
-// wtr: 576 floats of scratch (the kernel transposed for the scalar cache)
+// wtr: 576 floats of scratch (the kernel transposed for the scalar cache); zero: 16 bytes of zeros (LDS-direct loads)
 int ofx_fit_b1_pool(hipStream_t st, int n, int H, int W, int conv, const float *dzn, const float *wn, const float *z,
-                    const float *stat, const float *act, float *g, double *part, int *nblocks, float *wtr);
+                    const float *stat, const float *act, float *g, double *part, int *nblocks, float *wtr,
+                    const float *zero);
 size_t ofx_fit_first_doubles(int n);
 size_t ofx_fit_first_floats(void);
 struct ofx_handle;

@@ -410,9 +410,11 @@ __global__ __launch_bounds__(256, 3) void f_conv_fwd(int n, int H, int W, FitSrc
       }
       continue;
     }
+    float *const zs = z + s * (size_t)(CO * H) * W;   // the sample's planes (block-uniform); 32-bit offsets behind it
+    const int pix = y * W + x;
 #pragma unroll
     for (int co = 0; co < CO; co++) {
-      float *zp = z + ((s * CO + co) * (size_t)H + y) * W + x;
+      float *zp = zs + co * H * W + pix;
       float f1 = 0.f, f2 = 0.f;
       if (4 * q + 4 <= TW) {
         *reinterpret_cast<float4 *>(zp) = make_float4(acc[0][co], acc[1][co], acc[2][co], acc[3][co]);
@@ -494,7 +496,8 @@ template <bool CONV>
 __global__ __launch_bounds__(256, 3) void f_b1_pool(int n, int H, int W, const float *__restrict__ dzn,
                                                  const float *__restrict__ wn, const float *__restrict__ z,
                                                  const float *__restrict__ stat, const float *__restrict__ act,
-                                                 float *__restrict__ g, double *__restrict__ part) {
+                                                 float *__restrict__ g, double *__restrict__ part,
+                                                 const float *__restrict__ zero) {
   constexpr int C = 8, LP = P_TW + 4;
   __shared__ __align__(16) float dzt[CONV ? C : 1][P_TR + 2][LP];
   __shared__ double red[4][2 * C];
@@ -510,23 +513,12 @@ __global__ __launch_bounds__(256, 3) void f_b1_pool(int n, int H, int W, const f
     const int t = (int)(tile - (long)s * per_s), y0 = (t / tx_n) * P_TR, x0 = (t % tx_n) * P_TW;
     if constexpr (CONV) {
       __syncthreads();
-      constexpr int NE = C * (P_TR + 2) * (P_TW + 2);
-      for (int e0 = tid; e0 < NE; e0 += 256 * 8) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-          const int e = e0 + u * 256;
-          const int co = e / ((P_TR + 2) * (P_TW + 2)), rem = e - co * ((P_TR + 2) * (P_TW + 2));
-          const int yy = rem / (P_TW + 2), xx = rem - yy * (P_TW + 2);
-          const int y = y0 - 1 + yy, x = x0 - 1 + xx;
-          v[u] = (e < NE && y >= 0 && y < Hp && x >= 0 && x < Wp) ? dzn[((s * C + co) * (size_t)Hp + y) * Wp + x] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < FILL_U; u++) {
-          const int e = e0 + u * 256;
-          if (e < NE) (&dzt[0][0][0])[(e / (P_TW + 2)) * LP + e % (P_TW + 2)] = v[u];
-        }
-      }
+      lds_direct_rows<C * (P_TR + 2), LP, P_TW + 2, 4>(&dzt[0][0][0], __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63, x0 - 1, Wp,
+                                                        zero, [&](int rr) -> const float * {
+        const int co = rr / (P_TR + 2), y = y0 - 1 + (rr - co * (P_TR + 2));
+        return (y >= 0 && y < Hp) ? dzn + ((s * C + co) * (size_t)Hp + y) * Wp : nullptr;
+      });
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): landed before the barrier publishes the tile
       __syncthreads();
     }
     const int yp = y0 + r, xp = x0 + 2 * q;
@@ -563,22 +555,24 @@ __global__ __launch_bounds__(256, 3) void f_b1_pool(int n, int H, int W, const f
       }
     }
     const bool both = xp + 1 < Wp;   // the thread's second pooled pixel exists (always, but for the odd-width last layer)
+    const float *const zs = z + s * (size_t)(C * H) * W;   // the sample's planes (block-uniform); 32-bit offsets behind them
+    float *const gs = g + s * (size_t)(C * H) * W;
 #pragma unroll
     for (int ci = 0; ci < C; ci++) {
       const float mean = stat[2 * ci], rs = rsqrtf(stat[2 * ci + 1] + 1e-3f), sc = act[2 * ci], sh = act[2 * ci + 1];
-      const size_t base = ((s * C + ci) * (size_t)H + 2 * yp) * W + 2 * xp;
+      const int base = (ci * H + 2 * yp) * W + 2 * xp;   // behind the sample's planes zs / gs
       float zr[2][4];   // rows 2 yp, 2 yp + 1; columns 2 xp .. 2 xp + 3
       const bool vec = both && (W & 3) == 0;   // 16-byte accesses: the rows of the 50 x 50 layer are only 8-byte aligned
       if (vec) {
-        const float4 r0 = *reinterpret_cast<const float4 *>(z + base), r1 = *reinterpret_cast<const float4 *>(z + base + W);
+        const float4 r0 = *reinterpret_cast<const float4 *>(zs + base), r1 = *reinterpret_cast<const float4 *>(zs + base + W);
         zr[0][0] = r0.x; zr[0][1] = r0.y; zr[0][2] = r0.z; zr[0][3] = r0.w;
         zr[1][0] = r1.x; zr[1][1] = r1.y; zr[1][2] = r1.z; zr[1][3] = r1.w;
       } else {
-        const float2 r0 = *reinterpret_cast<const float2 *>(z + base), r1 = *reinterpret_cast<const float2 *>(z + base + W);
+        const float2 r0 = *reinterpret_cast<const float2 *>(zs + base), r1 = *reinterpret_cast<const float2 *>(zs + base + W);
         zr[0][0] = r0.x; zr[0][1] = r0.y; zr[1][0] = r1.x; zr[1][1] = r1.y;
         zr[0][2] = zr[0][3] = zr[1][2] = zr[1][3] = 0.f;
         if (both) {
-          const float2 q0 = *reinterpret_cast<const float2 *>(z + base + 2), q1 = *reinterpret_cast<const float2 *>(z + base + W + 2);
+          const float2 q0 = *reinterpret_cast<const float2 *>(zs + base + 2), q1 = *reinterpret_cast<const float2 *>(zs + base + W + 2);
           zr[0][2] = q0.x; zr[0][3] = q0.y; zr[1][2] = q1.x; zr[1][3] = q1.y;
         }
       }
@@ -601,14 +595,14 @@ __global__ __launch_bounds__(256, 3) void f_b1_pool(int n, int H, int W, const f
         s2[ci] += (double)(gv * ((zv[k] - mean) * rs));
       }
       if (vec) {
-        *reinterpret_cast<float4 *>(g + base) = make_float4(o[0][0], o[0][1], o[0][2], o[0][3]);
-        *reinterpret_cast<float4 *>(g + base + W) = make_float4(o[1][0], o[1][1], o[1][2], o[1][3]);
+        *reinterpret_cast<float4 *>(gs + base) = make_float4(o[0][0], o[0][1], o[0][2], o[0][3]);
+        *reinterpret_cast<float4 *>(gs + base + W) = make_float4(o[1][0], o[1][1], o[1][2], o[1][3]);
       } else {
-        *reinterpret_cast<float2 *>(g + base) = make_float2(o[0][0], o[0][1]);
-        *reinterpret_cast<float2 *>(g + base + W) = make_float2(o[1][0], o[1][1]);
+        *reinterpret_cast<float2 *>(gs + base) = make_float2(o[0][0], o[0][1]);
+        *reinterpret_cast<float2 *>(gs + base + W) = make_float2(o[1][0], o[1][1]);
         if (both) {
-          *reinterpret_cast<float2 *>(g + base + 2) = make_float2(o[0][2], o[0][3]);
-          *reinterpret_cast<float2 *>(g + base + W + 2) = make_float2(o[1][2], o[1][3]);
+          *reinterpret_cast<float2 *>(gs + base + 2) = make_float2(o[0][2], o[0][3]);
+          *reinterpret_cast<float2 *>(gs + base + W + 2) = make_float2(o[1][2], o[1][3]);
         }
       }
     }
@@ -704,6 +698,8 @@ __global__ __launch_bounds__(256, 2) void f_b1_up(int n, int h, int w, const flo
     __syncthreads();
     const int y = y0 + r, x = x0 + q;
     if (r >= TRL || y >= h || x >= w) continue;
+    const float *const zps = zp + s * (size_t)(C * h) * w;   // the sample's planes (block-uniform); 32-bit offsets behind them
+    float *const gs = g + s * (size_t)(C * h) * w;
     float cy[5], cx[5];
 #pragma unroll
     for (int k = 0; k < 5; k++) {
@@ -725,15 +721,15 @@ __global__ __launch_bounds__(256, 2) void f_b1_up(int n, int h, int w, const flo
         for (int kx = 1; kx < 5; kx++) row = fmaf(cx[kx], du[c][2 * r + ky][2 * q + kx], row);
         acc = fmaf(cy[ky], row, acc);
       }
-      const size_t at = ((s * C + c) * (size_t)h + y) * w + x;
-      const float zv = zp[at];
+      const int at = (c * h + y) * w + x;   // behind the sample's planes zps / gs
+      const float zv = zps[at];
       if constexpr (BN) {
         const float gv = bn_act(zv, act[2 * c], act[2 * c + 1]) > 0.f ? acc : 0.f;
-        g[at] = gv;
+        gs[at] = gv;
         s1[c] += (double)gv;
         s2[c] += (double)(gv * ((zv - stat[2 * c]) * rsv[c]));
       } else {
-        g[at] = zv > 0.f ? acc : 0.f;
+        gs[at] = zv > 0.f ? acc : 0.f;
       }
     }
   }
@@ -845,7 +841,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 2) void f_bw(int n, int H, int 
 #pragma unroll
       for (int k = 0; k < V; k++) d[k] = 0.f;
       if (y < H) {
-        const size_t at = ((s * CO + co) * (size_t)H + y) * W + x0 + V * xv;
+        const size_t at = s * (size_t)(CO * H) * W + (unsigned)((co * H + y) * W + x0 + V * xv);   // uniform 64-bit part + 32-bit offset
         float zz[V];
         if constexpr (POINT) {
           static_assert(!POINT || (V == 4 && BN), "patch form");
@@ -1794,16 +1790,16 @@ int ofx_fit_pool_act(hipStream_t st, int n, int C, int H, int W, const float *z,
 }
 
 int ofx_fit_b1_pool(hipStream_t st, int n, int H, int W, int conv, const float *dzn, const float *wn, const float *z,
-                    const float *stat, const float *act, float *g, double *part, int *nblocks, float *wtr) {
+                    const float *stat, const float *act, float *g, double *part, int *nblocks, float *wtr, const float *zero) {
   const int Hp = H / 2, Wp = W / 2;
   const long ntiles = (long)n * ((Hp + P_TR - 1) / P_TR) * ((Wp + P_TW - 1) / P_TW);
   const int grid = grid_for(ntiles, OFX_FIT_MAX_BLOCKS);
   *nblocks = grid;
   if (conv) {
     hipLaunchKernelGGL(f_transpose_w, dim3(3), dim3(192), 0, st, 8, 8, wn, wtr);
-    hipLaunchKernelGGL(f_b1_pool<true>, dim3(grid), dim3(256), 0, st, n, H, W, dzn, (const float *)wtr, z, stat, act, g, part);
+    hipLaunchKernelGGL(f_b1_pool<true>, dim3(grid), dim3(256), 0, st, n, H, W, dzn, (const float *)wtr, z, stat, act, g, part, zero);
   }
-  else hipLaunchKernelGGL(f_b1_pool<false>, dim3(grid), dim3(256), 0, st, n, H, W, dzn, wn, z, stat, act, g, part);
+  else hipLaunchKernelGGL(f_b1_pool<false>, dim3(grid), dim3(256), 0, st, n, H, W, dzn, wn, z, stat, act, g, part, zero);
   OFX_HIP(hipGetLastError());
   return OFX_OK;
 }

@@ -758,7 +758,7 @@ static int dqn_fit_lean(ofx_handle *h, float *weights, float *adam_m, float *ada
   dzn = dp3;
   for (int i = 3; i >= 0; i--) {
     const int s = tS[i];
-    if ((rc = ofx_fit_b1_pool(st, n, s, s, i < 3, dzn, i < 3 ? T(6 * (i + 1)) : nullptr, tz[i], tstat[i], tact[i], tg[i], part, &nb, wtr))) return rc;
+    if ((rc = ofx_fit_b1_pool(st, n, s, s, i < 3, dzn, i < 3 ? T(6 * (i + 1)) : nullptr, tz[i], tstat[i], tact[i], tg[i], part, &nb, wtr, zero))) return rc;
     if ((rc = ofx_fit_finish(st, nb, 8, 1.0, part, nullptr, nullptr, sums, nullptr, nullptr))) return rc;
     if (i == 1) {
       // the first two layers: the first has neither z, g nor dz, the second's dz is never stored - only the windows that see
