@@ -1185,12 +1185,20 @@ __global__ void f_out_bw_finish(const double *q, const double *fr, int legacy, f
 // So the 5.12 MB per row of z0 are not read again and dz0 is never formed; A comes out of the kernel that forms g0
 // (f_first_bwd, below).  The bias gradient of a convolution in front of BatchNorm is exactly 0.
 constexpr int C0_ROWS = 40;   // rows of a correlation chunk
-// part[block][324]: Cc over the block's rows of one sample; block = 384 threads, thread q < 324 owns the pair (q / 18, q % 18)
+// part[block][324]: Cc over the block's rows; block = 384 threads (all stage the shifted rows, 171 count the pairs ua <= ub)
 __global__ __launch_bounds__(384) void f_bits_corr(int n, const uint32_t *__restrict__ bits, double *__restrict__ part) {
   constexpr int RB = 8;              // image rows per barrier pair (one row at a time the kernel was all barrier: 1.54 ms per 4096 rows)
   static_assert(C0_ROWS % RB == 0, "rows per step");
   __shared__ uint32_t ver[RB][18][13];   // the 18 shifted versions of an image row: bit x of version u = in_u at pixel (y, x)
-  const int tid = threadIdx.x, ua = tid / 18, ub = tid - 18 * ua, nchunks = n * (400 / C0_ROWS);
+  const int tid = threadIdx.x, nchunks = n * (400 / C0_ROWS);
+  // Cc is symmetric: thread q < 171 owns the pair (ua <= ub) and writes both entries (half the popcounts: the kernel is bound
+  // by its vector instructions)
+  int ua = 0, ub = 0;
+  if (tid < 171) {
+    int rem = tid;
+    while (rem >= 18 - ua) { rem -= 18 - ua; ua++; }
+    ub = ua + rem;
+  }
   int acc = 0;   // at most (chunks per block) x 40 x 400 < 2^31
   for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
     const int s = chunk / (400 / C0_ROWS), y0 = (chunk % (400 / C0_ROWS)) * C0_ROWS;
@@ -1219,7 +1227,7 @@ __global__ __launch_bounds__(384) void f_bits_corr(int n, const uint32_t *__rest
         ver[e / (18 * 13)][u][wd] = v;
       }
       __syncthreads();
-      if (tid < 324) {
+      if (tid < 171) {
 #pragma unroll
         for (int k = 0; k < RB; k++)
 #pragma unroll
@@ -1227,7 +1235,10 @@ __global__ __launch_bounds__(384) void f_bits_corr(int n, const uint32_t *__rest
       }
     }
   }
-  if (tid < 324) part[(size_t)blockIdx.x * 324 + tid] = (double)acc;
+  if (tid < 171) {
+    part[(size_t)blockIdx.x * 324 + ua * 18 + ub] = (double)acc;
+    part[(size_t)blockIdx.x * 324 + ub * 18 + ua] = (double)acc;
+  }
 }
 
 // ---- the first layer is never materialised -------------------------------------------------------------------------------
