@@ -459,7 +459,7 @@ int ofx_dqn_targets(ofx_handle *h, const float *weights, int32_t n, const ofx_tr
  * ofx_replay_gather_valid): a padding row would enter the BatchNorm batch statistics and the loss scale, so the call
  * fails with OFX_ERR_INVALID before anything is updated.  The handle keeps a workspace of 9.4 MB per row between calls (given back when a call needs less than a quarter of it)
  * (OFX_OPT_FIT_PLAIN: 61 MB); every reduction has a fixed order, so the same call on the same state gives the same bits.
- * fp32 on the vector ALU (not the hot path): 3.8 ms for 64 rows, 45 ms for 4096 with the target forward (ofx_dqn_fit_reference: 4.8 / 69 ms); synchronises. */
+ * fp32 on the vector ALU (not the hot path): 3.6 ms for 64 rows, 42 ms for 4096 with the target forward (ofx_dqn_fit_reference: 4.7 / 65 ms); synchronises. */
 int ofx_dqn_fit(ofx_handle *h, float *weights, float *adam_m, float *adam_v, int32_t step, float lr, int32_t n,
                 const ofx_transition *rows, const void *bits_prev, const float *y_act, const float *y_ptr,
                 float *grad_out, float *loss_host);

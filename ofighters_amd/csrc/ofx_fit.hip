@@ -27,7 +27,7 @@
 // Every reduction has a fixed order (tile -> block assignment by index, ordered combines): two fits from the same state
 // give the same bits.  fp32 on the vector ALU (accumulators paired over the channel index: v_pk_fma_f32) with FMA
 // contraction; checked against torch autograd in float64 and against the plain form (tests/test_train.py).  Per row of
-// the minibatch 9.4 MB of workspace instead of 61 MB; 4096 rows in 45 ms (r03: 66).
+// the minibatch 9.4 MB of workspace instead of 61 MB; 4096 rows in 42 ms (r03: 66).
 #include "ofx_internal.h"
 #include "ofx_fit.h"
 #include "ofx_diag.h"

@@ -3,7 +3,7 @@
 //
 // Two forms of the same step.  The default is the LEAN form (dqn_fit_lean below + the kernels of ofx_fit.hip): only the
 // pre-activation tensor of every convolution is kept in HBM, the rest is recomputed inside fused tiles (9.4 MB of
-// workspace per minibatch row; 4096 rows in 45 ms, 69 ms with the reference's dense targets).  The PLAIN form (OFX_OPT_FIT_PLAIN, dqn_fit_impl) is the layer-by-layer
+// workspace per minibatch row; 4096 rows in 42 ms, 65 ms with the reference's dense targets).  The PLAIN form (OFX_OPT_FIT_PLAIN, dqn_fit_impl) is the layer-by-layer
 // original - one fp32 VALU kernel per layer and pass, every tensor of the graph in HBM (61 MB per row) - kept as the
 // reference of the lean form.  Both: fixed-order reductions (no atomics: a fit is reproducible to the bit), the dense
 // forwards on the f32 MFMA GEMM of the forward, every gradient tensor checked against torch autograd in float64 and the

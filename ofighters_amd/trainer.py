@@ -26,8 +26,8 @@ class DeviceTrainer:
         self.batch_size = batch_size                        # 8 (:307)
         self.seed = seed
         self.fit_batch = fit_batch                          # rows per optimisation step (the reference fits on 8): one
-                                                            # replay takes 3.8 ms at 64 rows, 6.0 at 256 - about one
-                                                            # lock-step of a 4096-arena batch -, 45 ms at 4096
+                                                            # replay takes 3.6 ms at 64 rows, 5.8 at 256 - about one
+                                                            # lock-step of a 4096-arena batch -, 42 ms at 4096
         self.reference_quirks = bool(reference_quirks)      # Trainer.replay as written instead of the textbook DQN step
         self.fit_steps = 0
         self.draws = 0
