@@ -469,15 +469,26 @@ __global__ __launch_bounds__(HG_THREADS) void k_head_frames(HeadParams2 p) {
   __syncthreads();
   // the tap planes along the four lines: V_t = sum_c w4[t][c] uprelu3_c (what k_head_stream's ring holds; the same
   // sequential sum over c as the 1x1's MFMA chain)
-  // a thread owns one (cell, tap) of an iteration: consecutive lanes store consecutive floats.  (r04 also tried a thread per
-  // cell with its nine taps and the weights as scalar loads - a ninth of the iterations, but every store instruction of a
-  // wave then strides over 36 bytes: 0.91 against 0.79 ms for the kernel, tools/ab_frames.sh)
-  for (int e = tid; e < 4 * 200 * 9; e += HG_THREADS) {
-    const int tp = e % 9, cell = e / 9;
-    float acc = 0.f;
+  // 252 threads = 28 cells x 9 taps per pass: a thread keeps ITS tap (its 8 weights in registers), consecutive lanes store
+  // consecutive floats, a cell's channels arrive as two 16-byte LDS reads.  (r04 also tried a thread per cell with its nine taps
+  // and the weights as scalar loads - every store instruction of a wave then strides over 36 bytes: 0.91 against 0.79 ms for the
+  // kernel - and (cell, tap) = (e / 9, e % 9) over all 256 threads with the weights read from LDS per FMA: 0.73 ms;
+  // tools/ab_frames.sh)
+  if (tid < 252) {
+    const int tp = tid % 9, c0 = tid / 9;
+    float wt[8];
 #pragma unroll
-    for (int ci = 0; ci < 8; ci++) acc = fmaf(w4s[tp * 8 + ci], u3l[cell * 8 + ci], acc);
-    p.vfr[(size_t)s * 7200 + e] = acc;
+    for (int ci = 0; ci < 8; ci++) wt[ci] = w4s[tp * 8 + ci];
+    float *dst = p.vfr + (size_t)s * 7200 + tid;
+    for (int cell = c0; cell < 4 * 200; cell += 28) {
+      const f32x4 ua = *reinterpret_cast<const f32x4 *>(u3l + cell * 8), ub = *reinterpret_cast<const f32x4 *>(u3l + cell * 8 + 4);
+      float acc = 0.f;
+#pragma unroll
+      for (int ci = 0; ci < 4; ci++) acc = fmaf(wt[ci], ua[ci], acc);
+#pragma unroll
+      for (int ci = 0; ci < 4; ci++) acc = fmaf(wt[4 + ci], ub[ci], acc);
+      dst[(cell - c0) * 9] = acc;   // element (cell, tp) = 9 cell + tp = tid + 9 (cell - c0)
+    }
   }
 
   // ---- corrections of the heat-map frame pixels (PrepLayout::efr: the conv taps of the row / column outside the
